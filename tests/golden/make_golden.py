@@ -1,0 +1,262 @@
+#!/usr/bin/env python
+"""Generate the golden vectors that pin the oracle (and, through it, the HIP path).
+
+Runs ONLY in the build container: it imports the reference implementation from
+/root/reference (via oracle/ref_import.py stubs) on CPU, feeds it procedurally
+generated weights (diff-foley_amd/synth.py) and seeded inputs, and stores the
+reference's *outputs* as small .npz fixtures next to this script.  Inputs are
+regenerated from seeds by the tests; no reference source is copied.
+
+    python tests/golden/make_golden.py --tiny     # seconds
+    python tests/golden/make_golden.py --full     # ~10 min (860 M-param reference on CPU)
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import diff_foley_amd  # noqa: E402,F401
+from diff_foley_amd import synth  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+
+def rnd(shape, seed):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def save(name, **arrs):
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def check_spec(model, spec):
+    rsd = model.state_dict()
+    for k, s in spec.items():
+        assert tuple(rsd[k].shape) == tuple(s), (k, tuple(rsd[k].shape), s)
+    ref_keys = [k for k in rsd if k.startswith(("model.diffusion_model", "first_stage_model.decoder",
+                                                "first_stage_model.post_quant", "cond_stage_model"))]
+    assert set(ref_keys) == set(spec.keys()), set(ref_keys) ^ set(spec.keys())
+
+
+def g1_schedules(model, ns):
+    """G1: DDPM buffers, DDIM tables S in {25,50}, DPM-Solver (t, lambda, alpha, sigma) S in {25,50}."""
+    names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+             "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+             "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+             "posterior_mean_coef1", "posterior_mean_coef2"]
+    out = {n: getattr(model, n) for n in names}
+    for S in (25, 50):
+        s = ns.DDIMSampler(model)
+        s.make_schedule(S, ddim_eta=0.0, verbose=False)
+        out[f"ddim{S}_timesteps"] = s.ddim_timesteps
+        out[f"ddim{S}_alphas"] = np.asarray(s.ddim_alphas, dtype=np.float64)
+        out[f"ddim{S}_alphas_prev"] = np.asarray(s.ddim_alphas_prev, dtype=np.float64)
+        out[f"ddim{S}_sqrt_one_minus_alphas"] = np.asarray(s.ddim_sqrt_one_minus_alphas, dtype=np.float64)
+        out[f"ddim{S}_sigmas"] = np.asarray(s.ddim_sigmas, dtype=np.float64)
+        nsch = ns.dpm.NoiseScheduleVP("discrete", alphas_cumprod=model.alphas_cumprod)
+        t = torch.linspace(1.0, 1.0 / 1000, S + 1)
+        out[f"dpm{S}_t"] = t
+        out[f"dpm{S}_lambda"] = nsch.marginal_lambda(t)
+        out[f"dpm{S}_alpha"] = nsch.marginal_alpha(t)
+        out[f"dpm{S}_sigma"] = nsch.marginal_std(t)
+    tq = torch.tensor([0.0005, 0.001, 0.00137, 0.5, 0.73219, 0.999, 1.0, 1.2])
+    out["interp_t"] = tq
+    out["interp_log_alpha"] = nsch.marginal_log_mean_coeff(tq)
+    # G2: timestep embedding, int and fractional t
+    te_t = torch.tensor([0.0, 1.0, 41.0, 961.0, 999.0, 500.25, 37.7, 0.999])
+    out["temb_t"] = te_t
+    out["temb_320"] = ns.util.timestep_embedding(te_t, 320)
+    out["temb_64"] = ns.util.timestep_embedding(te_t, 64)
+    save("g1_schedules.npz", **out)
+
+
+def tiny(seed=0):
+    spec = synth.state_dict_spec(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
+    sd = synth.make_state_dict(spec, seed)
+    cfg = ref_import.load_ldm_config(unet=synth.UNET_TINY, vae=synth.VAE_TINY, cond=synth.COND_TINY)
+    model, ns = ref_import.build_reference_ldm(cfg, sd)
+    check_spec(model, spec)
+    g1_schedules(model, ns)
+
+    # ---- G3: per-op tensors, tiny config, latent 8x16 (hooks on the reference modules)
+    unet = model.model.diffusion_model
+    cap = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            cap[name + "__in"] = inp[0].detach().clone()
+            if len(inp) > 1 and torch.is_tensor(inp[1]):
+                cap[name + "__in1"] = inp[1].detach().clone()
+            cap[name + "__out"] = out.detach().clone()
+        return f
+    watch = {
+        "input_blocks.1.0": unet.input_blocks[1][0],       # ResBlock C->C  @ full res
+        "input_blocks.1.1": unet.input_blocks[1][1],       # SpatialTransformer
+        "input_blocks.3.0": unet.input_blocks[3][0],       # Downsample
+        "input_blocks.4.0": unet.input_blocks[4][0],       # ResBlock C->2C (skip conv)
+        "middle_block.1": unet.middle_block[1],            # ST at lowest res
+        "output_blocks.2.1": unet.output_blocks[2][1],     # Upsample
+        "output_blocks.5.0": unet.output_blocks[5][0],     # ResBlock on concat input
+        "output_blocks.5.1": unet.output_blocks[5][1],     # ST
+    }
+    hs = [m.register_forward_hook(hook(n)) for n, m in watch.items()]
+    x = rnd((2, 4, 8, 16), 100)
+    t = torch.tensor([500, 37])
+    c = rnd((2, 32, 128), 101)
+    with torch.no_grad():
+        y = model.apply_model(x, t, c)
+    for h in hs:
+        h.remove()
+    save("g3_tiny_ops.npz", x=x, t=t, c=c, y=y, **cap)
+
+    # tiny UNet at the real latent size, long and float t
+    x = rnd((2, 4, 16, 64), 102)
+    tf = torch.tensor([500.25, 37.7])
+    with torch.no_grad():
+        y_int = model.apply_model(x, t, c)
+        y_flt = model.apply_model(x, tf, c)
+        zdec = model.decode_first_stage(rnd((2, 4, 16, 64), 103))
+        cond = model.get_learned_conditioning(rnd((2, 32, 64), 104))
+    save("g3_tiny_unet.npz", y_int=y_int, y_flt=y_flt, decode=zdec, cond=cond)
+
+    # ---- tiny sampler trajectories (all three samplers + ancestral), CFG 4.5
+    B = 2
+    xT = synth.synthetic_xT(B, seed=21)
+    feats = synth.synthetic_cavp(B, 32, 64, seed=1234)
+    with torch.no_grad():
+        c = model.get_learned_conditioning(feats)
+        uc = torch.zeros_like(c)
+        out = {}
+        for name, S in (("DDIM", 25), ("DDIM", 50), ("DPM_Solver", 25), ("DPM_Solver", 10), ("PLMS", 25)):
+            z, inter = model.sample_log_diff_sampler(c, B, name, S, unconditional_guidance_scale=4.5,
+                                                     unconditional_conditioning=uc, x_T=xT.clone())
+            out[f"{name}_{S}_z"] = z
+            if inter is not None:
+                out[f"{name}_{S}_pred_x0_last"] = inter["pred_x0"][-1]
+                out[f"{name}_{S}_n_inter"] = len(inter["x_inter"])
+        z, _ = model.sample_log_diff_sampler(c, B, "DDIM", 25, x_T=xT.clone())     # no CFG
+        out["DDIM_25_nocfg_z"] = z
+        out["DDIM_25_mel"] = model.decode_first_stage(out["DDIM_25_z"])
+        # ancestral sampler, 6 steps, noise from a seeded CPU generator (torch.manual_seed)
+        torch.manual_seed(77)
+        z, inter = model.sample(c, batch_size=B, return_intermediates=True, x_T=xT.clone(), timesteps=6,
+                                shape=(B, 4, 16, 64), verbose=False)
+        out["ancestral_6_z"] = z
+    save("g5_tiny_samplers.npz", **out)
+
+    # ---- G6: classifier prob + grad (tiny), and double-guidance DDIM / DPM trajectories
+    cspec = synth.classifier_spec(synth.CLS_TINY)
+    csd = synth.make_state_dict(cspec, seed)
+    cls_cfg = {k: v for k, v in synth.CLS_TINY.items()}
+    cls = ref_import.build_reference_classifier(cls_cfg, csd)
+    rsd = cls.state_dict()
+    assert set("model." + k for k in rsd) == set(cspec), set("model." + k for k in rsd) ^ set(cspec)
+
+    class Wrap:
+        def __call__(self, x, t, video_feat):
+            return cls(x, context=video_feat, timesteps=t)
+    wrap = Wrap()
+    x = rnd((2, 4, 16, 64), 105)
+    vf = synth.synthetic_cavp(B, 33, 64, seed=4321)
+    tt = torch.tensor([500, 37])
+    xin = x.clone().requires_grad_(True)
+    p = wrap(xin, t=tt, video_feat=vf)
+    g = torch.autograd.grad(torch.log(p).sum(), xin)[0]
+    out = {"cls_p": p, "cls_grad": g}
+    with torch.no_grad():
+        for name, S in (("DDIM", 10), ("DPM_Solver", 10)):
+            z, _ = model.sample_log_with_classifier_diff_sampler(
+                c, origin_cond=vf, batch_size=B, sampler_name=name, ddim_steps=S,
+                unconditional_guidance_scale=4.5, unconditional_conditioning=uc,
+                classifier=wrap, classifier_guide_scale=50.0, x_T=xT.clone())
+            out[f"{name}_{S}_cg_z"] = z
+    save("g6_tiny_classifier.npz", **out)
+
+
+def full(seed=0):
+    t0 = time.time()
+    spec = synth.state_dict_spec()
+    sd = synth.make_state_dict(spec, seed)
+    print("weights", time.time() - t0)
+    cfg = ref_import.load_ldm_config()
+    model, ns = ref_import.build_reference_ldm(cfg, sd)
+    check_spec(model, spec)
+    print("model", time.time() - t0)
+    # ---- G4: one full-size UNet forward (CFG batch of 2), inputs by seed
+    x = rnd((2, 4, 16, 64), 200)
+    t = torch.tensor([961, 41])
+    c = rnd((2, 32, 768), 201)
+    out = {}
+    with torch.no_grad():
+        out["unet_y"] = model.apply_model(x, t, c)
+        out["unet_y_float_t"] = model.apply_model(x, torch.tensor([960.2, 40.96]), c)
+        out["decode"] = model.decode_first_stage(rnd((1, 4, 16, 64), 202))[:, 0]
+    save("g4_full_unet.npz", **out)
+    print("g4", time.time() - t0)
+    # ---- G5: full trajectories, B=1 (config 1 of BASELINE.json), seeds 21 and 22
+    out = {}
+    with torch.no_grad():
+        for s in (21, 22):
+            xT = synth.synthetic_xT(1, seed=s)
+            feats = synth.synthetic_cavp(1, 32, 512, seed=1234 + s - 21)
+            c = model.get_learned_conditioning(feats)
+            uc = torch.zeros_like(c)
+            out[f"cond_{s}"] = c[:, :2]
+            z, inter = model.sample_log_diff_sampler(c, 1, "DDIM", 25, unconditional_guidance_scale=4.5,
+                                                     unconditional_conditioning=uc, x_T=xT.clone())
+            out[f"ddim25_z_{s}"] = z
+            out[f"ddim25_mel_{s}"] = model.decode_first_stage(z)[:, 0]
+            print("ddim", s, time.time() - t0)
+        xT = synth.synthetic_xT(1, seed=21)
+        feats = synth.synthetic_cavp(1, 32, 512, seed=1234)
+        c = model.get_learned_conditioning(feats)
+        uc = torch.zeros_like(c)
+        # first 4 DDIM steps (short trajectory: bf16 comparisons are meaningful before chaos sets in)
+        s4 = ns.DDIMSampler(model)
+        s4.make_schedule(25, ddim_eta=0.0, verbose=False)
+        img = xT.clone()
+        steps = np.flip(s4.ddim_timesteps)
+        for i in range(4):
+            ts = torch.full((1,), int(steps[i]), dtype=torch.long)
+            img, _ = s4.p_sample_ddim(img, c, ts, index=25 - i - 1, unconditional_guidance_scale=4.5,
+                                      unconditional_conditioning=uc)
+        out["ddim25_first4_x"] = img
+        z, _ = model.sample_log_diff_sampler(c, 1, "DPM_Solver", 50, unconditional_guidance_scale=4.5,
+                                             unconditional_conditioning=uc, x_T=xT.clone())
+        out["dpm50_z_21"] = z
+        out["dpm50_mel_21"] = model.decode_first_stage(z)[:, 0]
+        print("dpm", time.time() - t0)
+    save("g5_full_samplers.npz", **out)
+
+    # ---- G6 full-size classifier
+    cspec = synth.classifier_spec(synth.CLS_FULL)
+    csd = synth.make_state_dict(cspec, seed)
+    cls = ref_import.build_reference_classifier(dict(synth.CLS_FULL), csd)
+    x = rnd((2, 4, 16, 64), 205)
+    vf = synth.synthetic_cavp(2, 33, 512, seed=4321)
+    tt = torch.tensor([500, 37])
+    xin = x.clone().requires_grad_(True)
+    p = cls(xin, context=vf, timesteps=tt)
+    g = torch.autograd.grad(torch.log(p).sum(), xin)[0]
+    save("g6_full_classifier.npz", cls_p=p, cls_grad=g)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--full", action="store_true")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    if a.tiny:
+        tiny()
+    if a.full:
+        full()

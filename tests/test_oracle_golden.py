@@ -1,0 +1,168 @@
+"""CPU: the oracle (oracle/*.py) against every golden vector produced by the reference
+(tests/golden/make_golden.py).  fp32 on both sides, so tolerances are tight (the two
+differ only in op association order)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import gold, rnd, tiny_state_dict, tiny_classifier_sd, full_state_dict, full_classifier_sd
+from diff_foley_amd import synth
+from oracle import schedule as osch, unet as ou, vae as ov, samplers as osamp
+
+TOL = 2e-5
+
+
+def close(a, b, tol=TOL):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a.double() - b.double()).abs().max().item()
+    assert err <= tol * max(1.0, b.abs().max().item()), err
+
+
+def test_g1_ddpm_buffers():
+    g = gold("g1_schedules.npz")
+    s = osch.ddpm_schedule()
+    for k, v in s.items():
+        assert torch.equal(v, g[k]), k
+
+
+@pytest.mark.parametrize("S", [25, 50])
+def test_g1_ddim_tables(S):
+    g = gold("g1_schedules.npz")
+    sch = osch.ddim_schedule(osch.ddpm_schedule()["alphas_cumprod"], S)
+    assert np.array_equal(sch["timesteps"], g[f"ddim{S}_timesteps"].numpy())
+    assert np.array_equal(np.asarray(sch["alphas"], dtype=np.float64), g[f"ddim{S}_alphas"].numpy())
+    assert np.array_equal(np.asarray(sch["alphas_prev"], dtype=np.float64), g[f"ddim{S}_alphas_prev"].numpy())
+    assert np.array_equal(np.asarray(sch["sqrt_one_minus_alphas"], dtype=np.float64),
+                          g[f"ddim{S}_sqrt_one_minus_alphas"].numpy())
+    assert np.all(np.asarray(sch["sigmas"], dtype=np.float64) == 0)
+
+
+@pytest.mark.parametrize("S", [25, 50])
+def test_g1_dpm_tables(S):
+    g = gold("g1_schedules.npz")
+    ns = osch.NoiseScheduleVP(osch.ddpm_schedule()["alphas_cumprod"])
+    t = torch.linspace(1.0, 1.0 / 1000, S + 1)
+    assert torch.equal(t, g[f"dpm{S}_t"])
+    close(ns.marginal_lambda(t), g[f"dpm{S}_lambda"], 1e-6)
+    close(ns.marginal_alpha(t), g[f"dpm{S}_alpha"], 1e-6)
+    close(ns.marginal_std(t), g[f"dpm{S}_sigma"], 1e-6)
+    close(ns.marginal_log_mean_coeff(g["interp_t"]), g["interp_log_alpha"], 1e-6)
+
+
+def test_g2_timestep_embedding():
+    g = gold("g1_schedules.npz")
+    assert torch.equal(ou.timestep_embedding(g["temb_t"], 320), g["temb_320"])
+    assert torch.equal(ou.timestep_embedding(g["temb_t"], 64), g["temb_64"])
+
+
+def _tiny_parts():
+    sd = tiny_state_dict()
+    return (ou.sub_state_dict(sd, "model.diffusion_model."), ou.sub_state_dict(sd, "first_stage_model."),
+            ou.sub_state_dict(sd, "cond_stage_model."))
+
+
+def test_g3_tiny_ops():
+    g = gold("g3_tiny_ops.npz")
+    usd, _, _ = _tiny_parts()
+    cfg = synth.UNET_TINY
+    emb = ou.time_embed(usd, cfg, g["t"])
+    c = g["c"]
+    h = cfg["num_heads"]
+    close(ou.unet_forward(usd, cfg, g["x"], g["t"], c), g["y"])
+    for p in ("input_blocks.1.0", "input_blocks.4.0", "output_blocks.5.0"):
+        close(g[p + "__in1"], emb)
+        close(ou.resblock(usd, p, g[p + "__in"], emb), g[p + "__out"])
+    for p in ("input_blocks.1.1", "middle_block.1", "output_blocks.5.1"):
+        close(ou.spatial_transformer(usd, p, g[p + "__in"], c, h), g[p + "__out"])
+    close(ou._run_block(usd, [("down", "input_blocks.3.0")], g["input_blocks.3.0__in"], emb, c, h),
+          g["input_blocks.3.0__out"])
+    close(ou._run_block(usd, [("up", "output_blocks.2.1")], g["output_blocks.2.1__in"], emb, c, h),
+          g["output_blocks.2.1__out"])
+
+
+def test_g3_tiny_unet_vae_cond():
+    g = gold("g3_tiny_unet.npz")
+    usd, vsd, csd = _tiny_parts()
+    x, c = rnd((2, 4, 16, 64), 102), rnd((2, 32, 128), 101)
+    close(ou.unet_forward(usd, synth.UNET_TINY, x, torch.tensor([500, 37]), c), g["y_int"])
+    close(ou.unet_forward(usd, synth.UNET_TINY, x, torch.tensor([500.25, 37.7]), c), g["y_flt"])
+    close(ov.decode_first_stage(vsd, synth.VAE_TINY, rnd((2, 4, 16, 64), 103)), g["decode"])
+    close(ov.cond_stage(csd, rnd((2, 32, 64), 104)), g["cond"])
+
+
+def _tiny_sampling_setup():
+    usd, vsd, csd = _tiny_parts()
+    B = 2
+    xT = synth.synthetic_xT(B, seed=21)
+    c = ov.cond_stage(csd, synth.synthetic_cavp(B, 32, 64, seed=1234))
+    uc = torch.zeros_like(c)
+    apply_model = lambda x, t, cc: ou.unet_forward(usd, synth.UNET_TINY, x, t, cc)
+    return apply_model, xT, c, uc, vsd
+
+
+def test_g5_tiny_samplers():
+    g = gold("g5_tiny_samplers.npz")
+    apply_model, xT, c, uc, vsd = _tiny_sampling_setup()
+    acp = osch.ddpm_schedule()["alphas_cumprod"]
+    tol = 2e-4      # 25-50 fp32 steps of a random-weight UNet: association-order noise accumulates
+    for S in (25, 50):
+        z, inter = osamp.ddim_sample(apply_model, acp, S, xT, c, 4.5, uc)
+        close(z, g[f"DDIM_{S}_z"], tol)
+        close(inter["pred_x0"][-1], g[f"DDIM_{S}_pred_x0_last"], tol)
+        assert len(inter["x_inter"]) == int(g[f"DDIM_{S}_n_inter"])
+        if S == 25:
+            close(ov.decode_first_stage(vsd, synth.VAE_TINY, z), g["DDIM_25_mel"], tol)
+    z, _ = osamp.ddim_sample(apply_model, acp, 25, xT, c)
+    close(z, g["DDIM_25_nocfg_z"], tol)
+    for S in (25, 10):
+        z, _ = osamp.dpm_solver_sample(apply_model, acp, S, xT, c, 4.5, uc)
+        close(z, g[f"DPM_Solver_{S}_z"], tol)
+    z, inter = osamp.plms_sample(apply_model, acp, 25, xT, c, 4.5, uc)
+    close(z, g["PLMS_25_z"], tol)
+    close(inter["pred_x0"][-1], g["PLMS_25_pred_x0_last"], tol)
+    torch.manual_seed(77)
+    z, _ = osamp.ddpm_sample(apply_model, osch.ddpm_schedule(), xT, c, timesteps=6)
+    close(z, g["ancestral_6_z"], tol)
+
+
+def test_g6_tiny_classifier_and_double_guidance():
+    g = gold("g6_tiny_classifier.npz")
+    csd = ou.sub_state_dict(tiny_classifier_sd(), "model.")
+    cls = lambda x, t, vf: ou.classifier_forward(csd, synth.CLS_TINY, x, t, vf)
+    x = rnd((2, 4, 16, 64), 105)
+    vf = synth.synthetic_cavp(2, 33, 64, seed=4321)
+    tt = torch.tensor([500, 37])
+    close(cls(x, tt, vf), g["cls_p"], 1e-5)
+    close(osamp.classifier_grad(cls, x, tt, vf), g["cls_grad"], 1e-4)
+    apply_model, xT, c, uc, _ = _tiny_sampling_setup()
+    acp = osch.ddpm_schedule()["alphas_cumprod"]
+    z, _ = osamp.ddim_sample(apply_model, acp, 10, xT, c, 4.5, uc, classifier=cls, origin_cond=vf,
+                             classifier_scale=50.0)
+    close(z, g["DDIM_10_cg_z"], 5e-4)
+    z, _ = osamp.dpm_solver_sample(apply_model, acp, 10, xT, c, 4.5, uc, classifier=cls, origin_cond=vf,
+                                   classifier_scale=50.0)
+    close(z, g["DPM_Solver_10_cg_z"], 5e-4)
+
+
+@pytest.mark.slow
+def test_g4_full_unet_forward():
+    g = gold("g4_full_unet.npz")
+    sd = full_state_dict()
+    usd = ou.sub_state_dict(sd, "model.diffusion_model.")
+    x, c = rnd((2, 4, 16, 64), 200), rnd((2, 32, 768), 201)
+    close(ou.unet_forward(usd, synth.UNET_FULL, x, torch.tensor([961, 41]), c), g["unet_y"], 5e-5)
+    close(ou.unet_forward(usd, synth.UNET_FULL, x, torch.tensor([960.2, 40.96]), c), g["unet_y_float_t"], 5e-5)
+    vsd = ou.sub_state_dict(sd, "first_stage_model.")
+    close(ov.decode_first_stage(vsd, synth.VAE_FULL, rnd((1, 4, 16, 64), 202))[:, 0], g["decode"], 5e-5)
+
+
+@pytest.mark.slow
+def test_g6_full_classifier():
+    g = gold("g6_full_classifier.npz")
+    csd = ou.sub_state_dict(full_classifier_sd(), "model.")
+    cls = lambda x, t, vf: ou.classifier_forward(csd, synth.CLS_FULL, x, t, vf)
+    x = rnd((2, 4, 16, 64), 205)
+    vf = synth.synthetic_cavp(2, 33, 512, seed=4321)
+    tt = torch.tensor([500, 37])
+    close(cls(x, tt, vf), g["cls_p"], 1e-5)
+    close(osamp.classifier_grad(cls, x, tt, vf), g["cls_grad"], 1e-4)
