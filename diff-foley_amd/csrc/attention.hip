@@ -1,0 +1,203 @@
+// Fused softmax(Q K^T * scale) V on MFMA for gfx950 (UNet self-attention, tokens 16..1024, and
+// cross-attention over 32/33 CAVP context tokens).  Scores never touch HBM.
+//
+// Work split: block = NW wavefronts, each wavefront owns 32 query rows of one (sample, head);
+// keys are walked in tiles of 32 staged in LDS (K tile row-major, V tile already transposed by
+// the producer GEMM, so both stage with plain 16-B copies).
+//
+// MFMA formulation (v_mfma_f32_32x32x16_bf16, "swapped" so softmax stays lane-local):
+//   S^T[key][q]  = sum_d K[key][d] Q[q][d]          A = K tile (LDS), B = Q (registers, loaded once)
+//   O^T[d][q]   += sum_key V^T[d][key] P^T[key][q]  A = V^T tile (LDS), B = P (registers, straight from S^T)
+// The C layout of S^T gives lane (q = lane&31, h = lane>>5) the 16 keys {(r&3) + 8(r>>2) + 4h}.  The PV
+// contraction index is relabelled so that operand slot p of half h in 16-key chunk c means key
+// (p&3) + 4h + 8(p>>2) + 16c: then P's registers 8c..8c+7 ARE the B fragment (no cross-lane traffic)
+// and the A fragment is two 8-byte LDS reads of V^T (keys 16c+4h..+3 and 16c+8+4h..+3).
+// Softmax statistics (running max m, running sum l) are fp32; one __shfl_xor(32) joins the two
+// half-waves that share a query.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int KT = 32;          // keys per tile
+constexpr int VROW = 36;        // V^T LDS row stride in bf16 (72 B: conflict-free ds_read_b64, 8-B aligned)
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __restrict__ Q, int ldq,
+                                                            const bf16_t* __restrict__ K, int ldk,
+                                                            const bf16_t* __restrict__ Vt, int ldvt,
+                                                            bf16_t* __restrict__ O, int ldo, int heads, int Tq,
+                                                            int Tk, float scale_log2e) {
+  constexpr int DKC = (D + 15) / 16;      // 16-wide contraction chunks for Q K^T
+  constexpr int DKP = DKC * 16;           // padded head dim
+  constexpr int DT = (D + 31) / 32;       // 32-row tiles of O^T
+  constexpr int KROW = DKP + 8;           // K LDS row stride (bf16): +16 B pad de-conflicts ds_read_b128
+  __shared__ __attribute__((aligned(16))) bf16_t sK[KT * KROW];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[DT * 32 * VROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int n = blockIdx.z, h = blockIdx.y;
+  const int q0 = (blockIdx.x * NW + wid) * 32;
+  const int q = q0 + l31;
+  const bool qv = q < Tq;
+
+  // ---- Q fragment (B operand of S^T): lane (q, lh) holds Q[q][16c + 8*lh .. +8], zero beyond D / Tq
+  bf16x8 qf[DKC];
+  {
+    const bf16_t* qr = Q + ((long)n * Tq + (qv ? q : 0)) * ldq + h * D;
+#pragma unroll
+    for (int c = 0; c < DKC; ++c) {
+      const int d0 = 16 * c + 8 * lh;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qv && d0 < D) v = *reinterpret_cast<const uint4*>(qr + d0);   // D % 8 == 0
+      qf[c] = *reinterpret_cast<bf16x8*>(&v);
+    }
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const bf16_t* Kb = K + (long)n * Tk * ldk + h * D;
+  const bf16_t* Vb = Vt + ((long)n * heads + h) * D * ldvt;
+  const int ntiles = (Tk + KT - 1) / KT;
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * KT;
+    __syncthreads();   // previous tile fully consumed
+    // ---- stage K tile [32 keys][DKP] (zero padded) : 16-B chunks
+    for (int i = tid; i < KT * (DKP / 8); i += NW * 64) {
+      const int key = i / (DKP / 8), ch = i - key * (DKP / 8);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (k0 + key < Tk && ch * 8 < D) v = *reinterpret_cast<const uint4*>(Kb + (long)(k0 + key) * ldk + ch * 8);
+      *reinterpret_cast<uint4*>(&sK[key * KROW + ch * 8]) = v;
+    }
+    // ---- stage V^T tile [DT*32 d-rows][32 keys] : 8-B chunks (rows beyond D zero)
+    for (int i = tid; i < DT * 32 * 8; i += NW * 64) {
+      const int d = i >> 3, ch = i & 7;
+      uint2 v = make_uint2(0, 0);
+      const int nvalid = Tk - (k0 + ch * 4);   // keys of this 4-key chunk that exist
+      if (d < D && nvalid > 0) {
+        v = *reinterpret_cast<const uint2*>(Vb + (long)d * ldvt + k0 + ch * 4);  // ldvt padded to 32
+        if (nvalid < 4) {   // ragged tail (e.g. 33 context tokens): padding may hold stale bits
+          if (nvalid < 3) v.y = 0; else v.y &= 0xFFFFu;
+          if (nvalid < 2) v.x &= 0xFFFFu;
+        }
+      }
+      *reinterpret_cast<uint2*>(&sV[d * VROW + ch * 4]) = v;
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < DKC; ++c) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[l31 * KROW + 16 * c + 8 * lh]);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], s, 0, 0, 0);
+    }
+    // ---- online softmax over this lane's 16 keys (+ partner half-wave)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      s[r] = (key < Tk) ? s[r] * scale_log2e : -INFINITY;
+      mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 valid key
+    const float alpha = exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
+    m_run = m_new;
+    float ps = 0.f;
+    uint32_t pk[8];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = exp2f(s[r] - m_new), p1 = exp2f(s[r + 1] - m_new);
+      ps += p0 + p1;
+      pk[r >> 1] = pack_bf2(p0, p1);
+    }
+    l_run = l_run * alpha + ps;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      uint4 pv = make_uint4(pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]);
+      const bf16x8 pf = *reinterpret_cast<bf16x8*>(&pv);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const bf16_t* vr = &sV[(t * 32 + l31) * VROW + 16 * c + 4 * lh];
+        const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
+        uint4 vv = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        const bf16x8 vf = *reinterpret_cast<bf16x8*>(&vv);
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane (q, lh) holds O[q][32t + (r&3) + 8(r>>2) + 4lh]
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (qv) {
+    bf16_t* orow = O + ((long)n * Tq + q) * ldo + h * D;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * t + 8 * g + 4 * lh;
+        if (d0 < D) {   // D % 4 == 0
+          uint2 w;
+          w.x = pack_bf2(o[t][4 * g] * inv, o[t][4 * g + 1] * inv);
+          w.y = pack_bf2(o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+          *reinterpret_cast<uint2*>(orow + d0) = w;
+        }
+      }
+  }
+}
+
+template <int D>
+hipError_t launch_d(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt,
+                    uint16_t* O, int ldo, int N, int heads, int Tq, int Tk, float scale, hipStream_t s) {
+  const float sl2 = scale * 1.4426950408889634f;
+  if (Tq >= 128) {
+    dim3 grid((Tq + 127) / 128, heads, N);
+    hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, heads, Tq,
+                       Tk, sl2);
+  } else if (Tq >= 64) {
+    dim3 grid((Tq + 63) / 64, heads, N);
+    hipLaunchKernelGGL((attention_kernel<D, 2>), grid, dim3(128), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, heads, Tq,
+                       Tk, sl2);
+  } else {
+    dim3 grid((Tq + 31) / 32, heads, N);
+    hipLaunchKernelGGL((attention_kernel<D, 1>), grid, dim3(64), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, heads, Tq,
+                       Tk, sl2);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool attention_supported(int D) { return D == 32 || D == 40 || D == 64 || D == 80 || D == 128 || D == 160; }
+
+hipError_t launch_attention(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt,
+                            uint16_t* O, int ldo, int N, int heads, int D, int Tq, int Tk, float scale,
+                            hipStream_t s) {
+  if (ldvt % 32 != 0 || ldvt < ((Tk + 31) / 32) * 32) return hipErrorInvalidValue;
+  switch (D) {
+    case 32:  return launch_d<32>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    case 40:  return launch_d<40>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    case 64:  return launch_d<64>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    case 80:  return launch_d<80>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    case 128: return launch_d<128>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    case 160: return launch_d<160>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    default:  return hipErrorInvalidValue;
+  }
+}

@@ -1,0 +1,389 @@
+// Normalisation, small linears, packing and sampler-update kernels (gfx950).  All HBM/L2-bound.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------ GroupNorm(32) [+SiLU] -> bf16
+// One block per (group, sample).  The group slab (HW x cpg fp32, <= 1 MB) is read three times
+// (mean, centred variance, apply); passes 2-3 hit L1/L2.  Stats in fp32, two-pass variance.
+__global__ void groupnorm_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                 int silu, bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw) {
+  __shared__ float red[16];
+  const int g = blockIdx.x, n = blockIdx.y;
+  const float* xb = x + (long)n * HW * ld + g * cpg;
+  const int half = cpg >> 1;              // cpg is even: float2 granularity
+  const int items = HW * half;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < items; i += blockDim.x) {
+    const int px = i / half, j = i - px * half;
+    const float2 v = *reinterpret_cast<const float2*>(xb + (long)px * ld + 2 * j);
+    s += v.x + v.y;
+  }
+  const float cnt = (float)HW * (float)cpg;
+  const float mean = block_sum(s, red) / cnt;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < items; i += blockDim.x) {
+    const int px = i / half, j = i - px * half;
+    const float2 v = *reinterpret_cast<const float2*>(xb + (long)px * ld + 2 * j);
+    const float a = v.x - mean, b = v.y - mean;
+    q += a * a + b * b;
+  }
+  const float rstd = rsqrtf(block_sum(q, red) / cnt + eps);
+  bf16_t* ob = out + (long)n * HW * ldo + g * cpg;
+  bf16_t* rb = raw ? raw + (long)n * HW * ldo + g * cpg : nullptr;
+  for (int i = threadIdx.x; i < items; i += blockDim.x) {
+    const int px = i / half, j = i - px * half;
+    const float2 v = *reinterpret_cast<const float2*>(xb + (long)px * ld + 2 * j);
+    const int c = g * cpg + 2 * j;
+    float a = (v.x - mean) * rstd * gamma[c] + beta[c];
+    float b = (v.y - mean) * rstd * gamma[c + 1] + beta[c + 1];
+    if (silu) {
+      a = silu_f(a);
+      b = silu_f(b);
+    }
+    *reinterpret_cast<uint32_t*>(ob + (long)px * ldo + 2 * j) = pack_bf2(a, b);
+    if (rb) *reinterpret_cast<uint32_t*>(rb + (long)px * ldo + 2 * j) = pack_bf2(v.x, v.y);
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm -> bf16, one wave per row
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ld, int rows, int C,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        bf16_t* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ld;
+  float v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = (c < C) ? xr[c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    const float d = (c < C) ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  bf16_t* orow = out + (long)row * C;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = i * 64 + lane;
+    if (c < C) orow[c] = f2bf((v[i] - mean) * rstd * gamma[c] + beta[c]);
+  }
+}
+
+// ------------------------------------------------------------------ row softmax fp32 -> bf16 (one wave per row)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
+                                                           int rows, int T) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* sr = s + (long)row * T;
+  float m = -INFINITY;
+  for (int c = lane; c < T; c += 64) m = fmaxf(m, sr[c]);
+  m = wave_max(m);
+  float l = 0.f;
+  for (int c = lane; c < T; c += 64) l += __expf(sr[c] - m);
+  l = 1.0f / wave_sum(l);
+  bf16_t* pr = p + (long)row * T;
+  for (int c = lane; c < T; c += 64) pr[c] = f2bf(__expf(sr[c] - m) * l);
+}
+
+// ------------------------------------------------------------------ small-M linear (time-embed MLP, emb projections,
+// classifier head): one wave per output column, bf16 weights streamed once with 16-B loads, fp32 activations.
+template <int MR>
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ a, int lda,
+                                                          const bf16_t* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          int ldo, int M, int N, int K, int silu_out) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+  const bf16_t* wr = W + (long)n * K;
+  for (int k = lane * 8; k < K; k += 64 * 8) {
+    const uint4 wv = *reinterpret_cast<const uint4*>(wr + k);
+    float w[8];
+    w[0] = bf2f(wv.x & 0xFFFF); w[1] = bf2f(wv.x >> 16);
+    w[2] = bf2f(wv.y & 0xFFFF); w[3] = bf2f(wv.y >> 16);
+    w[4] = bf2f(wv.z & 0xFFFF); w[5] = bf2f(wv.z >> 16);
+    w[6] = bf2f(wv.w & 0xFFFF); w[7] = bf2f(wv.w >> 16);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      if (m < M) {
+        const float4 a0 = *reinterpret_cast<const float4*>(a + (long)m * lda + k);
+        const float4 a1 = *reinterpret_cast<const float4*>(a + (long)m * lda + k + 4);
+        acc[m] += a0.x * w[0] + a0.y * w[1] + a0.z * w[2] + a0.w * w[3] + a1.x * w[4] + a1.y * w[5] + a1.z * w[6] +
+                  a1.w * w[7];
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    const float v = wave_sum(acc[m]);
+    if (lane == 0 && m < M) {
+      float r = v + (bias ? bias[n] : 0.f);
+      if (silu_out == 1) r = silu_f(r);
+      else if (silu_out == 2) r = 1.0f / (1.0f + __expf(-r));
+      out[(long)m * ldo + n] = r;
+    }
+  }
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int N, int dim) {
+  const int half = dim >> 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * half) return;
+  const int n = i / half, k = i - n * half;
+  // freqs = exp(-ln(10000) * k / half), computed like the reference in fp32
+  const float f = expf(-9.210340371976184f * (float)k / (float)half);
+  const float a = t[n] * f;
+  out[(long)n * dim + k] = cosf(a);
+  out[(long)n * dim + half + k] = sinf(a);
+}
+
+__global__ void pack_latent_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B, int C, int HW,
+                                   int cpad, int rep, float in_scale, const float* __restrict__ wpq,
+                                   const float* __restrict__ bpq) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)rep * B * HW;
+  if (i >= total) return;
+  const int px = (int)(i % HW);
+  const int b = (int)((i / HW) % B);
+  float v[8];
+  for (int c = 0; c < C; ++c) v[c] = x[((long)b * C + c) * HW + px] * in_scale;
+  bf16_t* o = out + i * cpad;
+  if (wpq) {
+    for (int oc = 0; oc < C; ++oc) {
+      float s = bpq[oc];
+      for (int c = 0; c < C; ++c) s += wpq[oc * C + c] * v[c];
+      o[oc] = f2bf(s);
+    }
+  } else {
+    for (int c = 0; c < C; ++c) o[c] = f2bf(v[c]);
+  }
+  for (int c = C; c < cpad; ++c) o[c] = 0;
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = f2bf(x[i]);
+}
+
+__global__ void cast_bf16_2d_kernel(const float* __restrict__ x, int ld, bf16_t* __restrict__ out, long rows, int C) {
+  const long total = rows * (C >> 1);
+  const int half = C >> 1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / half;
+    const int j = (int)(i - r * half);
+    const float2 v = *reinterpret_cast<const float2*>(x + r * ld + 2 * j);
+    *reinterpret_cast<uint32_t*>(out + r * C + 2 * j) = pack_bf2(v.x, v.y);
+  }
+}
+
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int O, int I, int KH,
+                                        int KW, int Ipad) {
+  const long total = (long)O * KH * KW * Ipad;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(e % Ipad);
+    long r = e / Ipad;
+    const int kw = (int)(r % KW);
+    r /= KW;
+    const int kh = (int)(r % KH);
+    const int o = (int)(r / KH);
+    out[e] = (ci < I) ? f2bf(w[(((long)o * I + ci) * KH + kh) * KW + kw]) : (bf16_t)0;
+  }
+}
+
+__global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                  bf16_t* __restrict__ wout, float* __restrict__ bout, int half_rows, int K) {
+  const long total = (long)2 * half_rows * K;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % K);
+    const int prow = (int)(e / K);               // packed row
+    const int blk = prow >> 6, r = prow & 63;
+    const int src = (r < 32) ? (blk * 32 + r) : (half_rows + blk * 32 + (r - 32));
+    wout[e] = f2bf(w[(long)src * K + k]);
+    if (k == 0) bout[prow] = b[src];
+  }
+}
+
+__global__ void cfg_combine_kernel(const float* __restrict__ e2, float* __restrict__ e, long n, float scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float u = e2[i], c = e2[n + i];
+    e[i] = u + scale * (c - u);
+  }
+}
+
+struct LinArgs {
+  const float* in[4];
+  float coef[4];
+  int n;
+};
+__global__ void lincomb_kernel(float* __restrict__ out, LinArgs a, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int j = 0; j < a.n; ++j) v += a.coef[j] * a.in[j][i];
+    out[i] = v;
+  }
+}
+
+__global__ void ddim_update_kernel(const float* __restrict__ x, const float* __restrict__ e,
+                                   const float* __restrict__ noise, float* __restrict__ x_prev,
+                                   float* __restrict__ pred_x0, long n, float sqrt_at, float s1m, float sqrt_aprev,
+                                   float dir_coef, float sigma) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float ev = e[i];
+    const float p0 = (x[i] - s1m * ev) / sqrt_at;
+    float xp = sqrt_aprev * p0 + dir_coef * ev;
+    if (noise) xp += sigma * noise[i];
+    pred_x0[i] = p0;
+    x_prev[i] = xp;
+  }
+}
+
+__global__ void avgpool_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int HW, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  float s = 0.f;
+  for (int p = 0; p < HW; ++p) s += x[((long)n * HW + p) * C + c];
+  out[i] = s / (float)HW;
+}
+
+inline int grid_for(long n, int block = 256, int cap = 4096) {
+  long g = (n + block - 1) / block;
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+hipError_t launch_groupnorm(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
+                            float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, hipStream_t s) {
+  if (C % 64 != 0) return hipErrorInvalidValue;
+  const int cpg = C / 32;
+  const long items = (long)HW * (cpg / 2);
+  const int threads = items >= 8192 ? 1024 : (items >= 2048 ? 512 : 256);
+  hipLaunchKernelGGL(groupnorm_kernel, dim3(32, N), dim3(threads), 0, s, x, ld, HW, C, cpg, gamma, beta, eps, silu,
+                     out, ldo, raw_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const float* x, int ld, int rows, int C, const float* gamma, const float* beta,
+                            float eps, uint16_t* out, hipStream_t s) {
+  const int blocks = (rows + 3) / 4;
+  if (C <= 320)
+    hipLaunchKernelGGL(layernorm_kernel<5>, dim3(blocks), dim3(256), 0, s, x, ld, rows, C, gamma, beta, eps, out);
+  else if (C <= 640)
+    hipLaunchKernelGGL(layernorm_kernel<10>, dim3(blocks), dim3(256), 0, s, x, ld, rows, C, gamma, beta, eps, out);
+  else if (C <= 1280)
+    hipLaunchKernelGGL(layernorm_kernel<20>, dim3(blocks), dim3(256), 0, s, x, ld, rows, C, gamma, beta, eps, out);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_softmax_rows(const float* sc, uint16_t* p, int rows, int T, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, p, rows, T);
+  return hipGetLastError();
+}
+
+hipError_t launch_linear_rows(const float* a, int lda, const uint16_t* W, const float* bias, float* out, int ldo,
+                              int M, int N, int K, int silu_out, hipStream_t s) {
+  if (K % 8 != 0 || lda % 4 != 0) return hipErrorInvalidValue;
+  const int blocks = (N + 3) / 4;
+  for (int m0 = 0; m0 < M; m0 += 16) {   // chunks of 16 rows (weights re-streamed per chunk; M is tiny here)
+    const int mm = (M - m0) < 16 ? (M - m0) : 16;
+    if (mm <= 4)
+      hipLaunchKernelGGL(linear_rows_kernel<4>, dim3(blocks), dim3(256), 0, s, a + (long)m0 * lda, lda, W, bias,
+                         out + (long)m0 * ldo, ldo, mm, N, K, silu_out);
+    else if (mm <= 8)
+      hipLaunchKernelGGL(linear_rows_kernel<8>, dim3(blocks), dim3(256), 0, s, a + (long)m0 * lda, lda, W, bias,
+                         out + (long)m0 * ldo, ldo, mm, N, K, silu_out);
+    else
+      hipLaunchKernelGGL(linear_rows_kernel<16>, dim3(blocks), dim3(256), 0, s, a + (long)m0 * lda, lda, W, bias,
+                         out + (long)m0 * ldo, ldo, mm, N, K, silu_out);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_timestep_embedding(const float* t, float* out, int N, int dim, hipStream_t s) {
+  const int n = N * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, out, N, dim);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_latent(const float* x, uint16_t* out, int B, int C, int HW, int cpad, int rep, float in_scale,
+                              const float* wpq, const float* bpq, hipStream_t s) {
+  if (C > 8) return hipErrorInvalidValue;
+  const long n = (long)rep * B * HW;
+  hipLaunchKernelGGL(pack_latent_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, x, out, B, C, HW, cpad, rep,
+                     in_scale, wpq, bpq);
+  return hipGetLastError();
+}
+
+hipError_t launch_cast_bf16(const float* x, uint16_t* out, long n, hipStream_t s) {
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_cast_bf16_2d(const float* x, int ld, uint16_t* out, long rows, int C, hipStream_t s) {
+  if (C % 2 != 0 || ld % 2 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cast_bf16_2d_kernel, dim3(grid_for(rows * (C / 2))), dim3(256), 0, s, x, ld, out, rows, C);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_conv_weight(const float* w, uint16_t* out, int O, int I, int KH, int KW, int Ipad,
+                                   hipStream_t s) {
+  const long n = (long)O * KH * KW * Ipad;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for(n)), dim3(256), 0, s, w, out, O, I, KH, KW, Ipad);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_geglu(const float* w, const float* b, uint16_t* wout, float* bout, int half_rows, int K,
+                             hipStream_t s) {
+  if (half_rows % 32 != 0) return hipErrorInvalidValue;
+  const long n = (long)2 * half_rows * K;
+  hipLaunchKernelGGL(pack_geglu_kernel, dim3(grid_for(n)), dim3(256), 0, s, w, b, wout, bout, half_rows, K);
+  return hipGetLastError();
+}
+
+hipError_t launch_cfg_combine(const float* e2, float* e, long n, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(cfg_combine_kernel, dim3(grid_for(n)), dim3(256), 0, s, e2, e, n, scale);
+  return hipGetLastError();
+}
+
+hipError_t launch_lincomb(float* out, const float* const* in, const float* coef, int nterms, long n, hipStream_t s) {
+  if (nterms < 1 || nterms > 4) return hipErrorInvalidValue;
+  LinArgs a;
+  a.n = nterms;
+  for (int i = 0; i < 4; ++i) {
+    a.in[i] = i < nterms ? in[i] : nullptr;
+    a.coef[i] = i < nterms ? coef[i] : 0.f;
+  }
+  hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, a, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_ddim_update(const float* x, const float* e, const float* noise, float* x_prev, float* pred_x0,
+                              long n, float sqrt_at, float s1m, float sqrt_aprev, float dir_coef, float sigma,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(ddim_update_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, e, noise, x_prev, pred_x0, n, sqrt_at,
+                     s1m, sqrt_aprev, dir_coef, sigma);
+  return hipGetLastError();
+}
+
+hipError_t launch_avgpool(const float* x, float* out, int N, int HW, int C, hipStream_t s) {
+  hipLaunchKernelGGL(avgpool_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, x, out, N, HW, C);
+  return hipGetLastError();
+}

@@ -1,0 +1,1354 @@
+// libdfengine: MI355X engine for the Diff-Foley Stage-2 sampling path (C ABI in include/df_engine.h).
+//
+// Host side: owns the fp32 checkpoint tensors (device copies), re-packs them to bf16 MFMA layouts, and
+// compiles each network (UNet / VAE decoder / cond stage / alignment classifier) for a given batch and
+// latent size into a static *plan*: a flat list of kernel launches over pre-allocated HBM buffers.
+// Executing a plan is a loop of launches on the caller's stream -- no allocation, no host sync.
+//
+// Data layout in HBM
+//   residual stream / block outputs : fp32 NHWC  [N*H*W][ld]   (skip tensors are written straight into their
+//                                     slot of the decoder's concat buffer: concat costs nothing, ld = ctot)
+//   MFMA operands                   : bf16 NHWC  [N*H*W][C]    (emitted by the norm kernels)
+//   conv weights                    : bf16 [Cout][ky][kx][Cin] ; linear weights bf16 [out][in]
+//   attention V                     : bf16 transposed [N][C][T] (produced directly by a batched GEMM)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/df_engine.h"
+#include "gemm.h"
+#include "kernels.h"
+
+typedef uint16_t bf16_t;
+
+namespace {
+
+thread_local std::string g_err;
+
+[[noreturn]] void fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw std::runtime_error(buf);
+}
+#define HIPCHK(x)                                                                          \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct RawT {
+  float* d = nullptr;
+  std::vector<int64_t> shape;
+  size_t n = 0;
+};
+
+struct RunArgs {
+  const float* x = nullptr;      // external latent input
+  const float* t = nullptr;      // external timesteps
+  const float* aux = nullptr;    // external context / features
+  float* out = nullptr;          // external output
+  float scale = 1.f;             // guidance scale
+};
+
+struct Op {
+  bool is_gemm = false;
+  GemmParams gp{};
+  int tile = 0, batch = 1;
+  bool c_ext = false;            // gp.C <- RunArgs.out at run time
+  std::function<hipError_t(hipStream_t, const RunArgs&)> fn;
+  const char* tag = "";
+};
+
+struct Block {
+  void* p;
+  size_t bytes;
+};
+
+struct Plan {
+  std::vector<Op> ops;
+  std::vector<Block> owned;      // every hipMalloc'd block (freed with the plan)
+  std::vector<Block> freelist;   // build-time reuse
+  float* partial = nullptr;      // shared split-K scratch
+  size_t partial_bytes = 0;
+  double gemm_flops = 0, weight_bytes = 0;
+  ~Plan() {
+    for (auto& b : owned) (void)hipFree(b.p);
+    if (partial) (void)hipFree(partial);
+  }
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (int i = 0; i < (int)freelist.size(); ++i)
+      if (freelist[i].bytes >= bytes && freelist[i].bytes <= bytes + bytes / 2 + 4096 &&
+          (best < 0 || freelist[i].bytes < freelist[best].bytes))
+        best = i;
+    if (best >= 0) {
+      void* p = freelist[best].p;
+      freelist.erase(freelist.begin() + best);
+      return p;
+    }
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, bytes));
+    HIPCHK(hipMemset(p, 0, bytes));
+    owned.push_back({p, bytes});
+    return p;
+  }
+  void release(void* p) {
+    if (!p) return;
+    for (auto& b : owned)
+      if (b.p == p) {
+        freelist.push_back(b);
+        return;
+      }
+  }
+};
+
+struct F32 {  // fp32 NHWC activation view
+  float* p = nullptr;
+  int rows = 0, C = 0, ld = 0;
+};
+
+}  // namespace
+
+struct df_ctx {
+  int device = 0;
+  std::map<std::string, RawT> raw;
+  std::map<std::string, void*> packed;
+  std::vector<void*> packed_blocks;
+  bool has_unet = false, has_vae = false, has_cond = false, has_cls = false, finalized = false;
+  df_unet_config ucfg{}, ccfg{};
+  df_vae_config vcfg{};
+  df_cond_config kcfg{};
+  std::map<std::string, int> emb_off[2];   // resblock prefix -> column offset in the fused emb projection
+  int emb_total[2] = {0, 0};
+  std::map<std::string, std::unique_ptr<Plan>> plans;
+  Plan* last_unet = nullptr;
+  int ctx_N = 0, ctx_T = 0;
+  float* ctx_copy = nullptr;
+  size_t ctx_copy_bytes = 0;
+  bool autotune = false;
+  hipStream_t pack_stream = nullptr;
+
+  ~df_ctx() {
+    plans.clear();
+    for (auto& kv : raw) (void)hipFree(kv.second.d);
+    for (void* p : packed_blocks) (void)hipFree(p);
+  }
+
+  const RawT& rt(const std::string& name) const {
+    auto it = raw.find(name);
+    if (it == raw.end()) fail("missing tensor '%s'", name.c_str());
+    return it->second;
+  }
+  bool has(const std::string& name) const { return raw.count(name) != 0; }
+  const float* f32(const std::string& name) const { return rt(name).d; }
+
+  void* pmalloc(size_t bytes) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, (bytes + 255) & ~(size_t)255));
+    packed_blocks.push_back(p);
+    return p;
+  }
+  // Linear / 1x1-conv weight [O][I] -> bf16
+  const bf16_t* w_linear(const std::string& name) {
+    auto it = packed.find(name);
+    if (it != packed.end()) return (const bf16_t*)it->second;
+    const RawT& t = rt(name);
+    bf16_t* o = (bf16_t*)pmalloc(t.n * 2);
+    HIPCHK(launch_cast_bf16(t.d, o, (long)t.n, pack_stream));
+    packed[name] = o;
+    return o;
+  }
+  // rows of several [O_i][I] matrices stacked -> bf16 [sum O_i][I]
+  const bf16_t* w_stack(const std::string& key, const std::vector<std::string>& names) {
+    auto it = packed.find(key);
+    if (it != packed.end()) return (const bf16_t*)it->second;
+    size_t tot = 0;
+    for (auto& n : names) tot += rt(n).n;
+    bf16_t* o = (bf16_t*)pmalloc(tot * 2);
+    size_t off = 0;
+    for (auto& n : names) {
+      const RawT& t = rt(n);
+      HIPCHK(launch_cast_bf16(t.d, o + off, (long)t.n, pack_stream));
+      off += t.n;
+    }
+    packed[key] = o;
+    return o;
+  }
+  const float* b_stack(const std::string& key, const std::vector<std::string>& names) {
+    auto it = packed.find(key);
+    if (it != packed.end()) return (const float*)it->second;
+    size_t tot = 0;
+    for (auto& n : names) tot += rt(n).n;
+    float* o = (float*)pmalloc(tot * 4);
+    size_t off = 0;
+    for (auto& n : names) {
+      const RawT& t = rt(n);
+      HIPCHK(hipMemcpyAsync(o + off, t.d, t.n * 4, hipMemcpyDeviceToDevice, pack_stream));
+      off += t.n;
+    }
+    packed[key] = o;
+    return o;
+  }
+  // 3x3 conv weight OIHW -> bf16 [O][3][3][Ipad]
+  const bf16_t* w_conv3(const std::string& name, int ipad) {
+    const std::string key = name + "#c3";
+    auto it = packed.find(key);
+    if (it != packed.end()) return (const bf16_t*)it->second;
+    const RawT& t = rt(name);
+    if (t.shape.size() != 4 || t.shape[2] != 3 || t.shape[3] != 3) fail("'%s' is not a 3x3 conv weight", name.c_str());
+    const int O = (int)t.shape[0], I = (int)t.shape[1];
+    bf16_t* o = (bf16_t*)pmalloc((size_t)O * 9 * ipad * 2);
+    HIPCHK(launch_pack_conv_weight(t.d, o, O, I, 3, 3, ipad, pack_stream));
+    packed[key] = o;
+    return o;
+  }
+  void w_geglu(const std::string& prefix, const bf16_t** w, const float** b) {
+    const std::string kw = prefix + ".weight#geglu", kb = prefix + ".bias#geglu";
+    auto it = packed.find(kw);
+    if (it == packed.end()) {
+      const RawT& tw = rt(prefix + ".weight");
+      const RawT& tb = rt(prefix + ".bias");
+      const int rows = (int)tw.shape[0], K = (int)tw.shape[1];
+      bf16_t* wo = (bf16_t*)pmalloc((size_t)rows * K * 2);
+      float* bo = (float*)pmalloc((size_t)rows * 4);
+      HIPCHK(launch_pack_geglu(tw.d, tb.d, wo, bo, rows / 2, K, pack_stream));
+      packed[kw] = wo;
+      packed[kb] = bo;
+    }
+    *w = (const bf16_t*)packed[kw];
+    *b = (const float*)packed[kb];
+  }
+};
+
+namespace {
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int rup(int a, int b) { return cdiv(a, b) * b; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tile / split-K choice: a small cost model in MFMA cycles (256 CUs, one 32x32x16 MFMA per 8 cycles per CU).
+void choose_tile(int M, int N, int K, int batch, bool geglu, int* tile, int* splitk) {
+  static const double eff[TILE_COUNT] = {1.0, 0.85, 0.85, 0.62, 0.55};
+  double best = 1e30;
+  *tile = TILE_64x64;
+  *splitk = 1;
+  const int nk = K / 64;
+  for (int c = 0; c < TILE_COUNT; ++c) {
+    if (geglu && !(c == TILE_128x128 || c == TILE_64x128)) continue;
+    int bm, bn;
+    gemm_tile_dims(c, &bm, &bn);
+    if (bm > 64 && M <= bm / 2) continue;
+    const long tiles = (long)cdiv(M, bm) * cdiv(N, bn) * batch;
+    for (int sk = 1; sk <= 16; sk *= 2) {
+      if (sk > 1 && (batch > 1 || nk / sk < 4)) break;
+      const double work = (double)(bm / 32) * (bn / 32) * (double)cdiv(nk, sk) * 4.0 * 8.0 / eff[c] + 2500.0;
+      const double rounds = (double)((tiles * sk + 255) / 256);
+      double cost = rounds * work;
+      if (sk > 1) cost += 9000.0 + (double)M * N * 8.0 * sk / 2000.0;   // reduce launch + slab traffic
+      if (cost < best) {
+        best = cost;
+        *tile = c;
+        *splitk = sk;
+      }
+    }
+  }
+}
+
+struct Builder {
+  df_ctx* c;
+  Plan* pl;
+  std::string pre;     // state_dict prefix of the module being built
+  int which = 0;       // 0 = unet, 1 = classifier (emb offset table)
+
+  std::string nm(const std::string& s) const { return pre + s; }
+
+  template <class T>
+  T* buf(size_t n) {
+    return (T*)pl->alloc(n * sizeof(T));
+  }
+
+  void other(const char* tag, std::function<hipError_t(hipStream_t, const RunArgs&)> fn) {
+    Op o;
+    o.fn = std::move(fn);
+    o.tag = tag;
+    pl->ops.push_back(std::move(o));
+  }
+
+  Op& gemm(GemmParams gp, int batch, const char* tag) {
+    Op o;
+    o.is_gemm = true;
+    o.batch = batch;
+    o.tag = tag;
+    int sk = 1;
+    choose_tile(gp.M, gp.N, gp.K, batch, gp.geglu != 0, &o.tile, &sk);
+    gp.splitk = sk;
+    if (sk > 1) {
+      const size_t need = (size_t)sk * gp.M * gp.N * 4;
+      if (need > pl->partial_bytes) pl->partial_bytes = need;
+    }
+    o.gp = gp;
+    pl->gemm_flops += 2.0 * gp.M * (double)gp.N * gp.K * batch;
+    pl->weight_bytes += 2.0 * (double)gp.N * gp.K * (gp.w_bs ? batch : 1);
+    pl->ops.push_back(std::move(o));
+    return pl->ops.back();
+  }
+
+  static GemmParams gp_linear(const bf16_t* A, int M, int K, const bf16_t* W, int N) {
+    GemmParams g{};
+    g.A = A; g.lda = K; g.W = W; g.M = M; g.N = N; g.K = K;
+    g.taps = 1; g.Cin = K; g.alpha = 1.f; g.stride = 1;
+    return g;
+  }
+  static GemmParams gp_conv3(const bf16_t* A, int NB, int H, int Wd, int Cin, const bf16_t* W, int Cout, int stride,
+                             int ups) {
+    GemmParams g{};
+    g.A = A; g.lda = Cin; g.W = W;
+    g.H = H; g.Wd = Wd; g.stride = stride; g.ups = ups;
+    g.OH = ups ? 2 * H : (stride == 2 ? H / 2 : H);
+    g.OW = ups ? 2 * Wd : (stride == 2 ? Wd / 2 : Wd);
+    g.M = NB * g.OH * g.OW; g.N = Cout; g.K = 9 * Cin;
+    g.taps = 9; g.Cin = Cin; g.alpha = 1.f;
+    return g;
+  }
+  static void out_f32(GemmParams& g, float* C, int ldc) { g.C = C; g.ldc = ldc; g.out_bf16 = 0; }
+  static void out_b16(GemmParams& g, bf16_t* C, int ldc) { g.C = C; g.ldc = ldc; g.out_bf16 = 1; }
+
+  // GroupNorm(+SiLU) -> bf16 operand (and optionally the raw bf16 cast)
+  bf16_t* groupnorm(const F32& x, int NB, const std::string& p, float eps, int silu, bf16_t** raw) {
+    bf16_t* o = buf<bf16_t>((size_t)x.rows * x.C);
+    bf16_t* r = raw ? buf<bf16_t>((size_t)x.rows * x.C) : nullptr;
+    if (raw) *raw = r;
+    const float* g = c->f32(nm(p + ".weight"));
+    const float* b = c->f32(nm(p + ".bias"));
+    const float* xp = x.p;
+    const int ld = x.ld, HW = x.rows / NB, C = x.C;
+    other("groupnorm", [=](hipStream_t s, const RunArgs&) {
+      return launch_groupnorm(xp, ld, NB, HW, C, g, b, eps, silu, o, C, r, s);
+    });
+    return o;
+  }
+  void layernorm(const F32& x, const std::string& p, bf16_t* o) {
+    const float* g = c->f32(nm(p + ".weight"));
+    const float* b = c->f32(nm(p + ".bias"));
+    const float* xp = x.p;
+    const int ld = x.ld, rows = x.rows, C = x.C;
+    other("layernorm", [=](hipStream_t s, const RunArgs&) { return launch_layernorm(xp, ld, rows, C, g, b, 1e-5f, o, s); });
+  }
+  bf16_t* cast2d(const F32& x) {
+    bf16_t* o = buf<bf16_t>((size_t)x.rows * x.C);
+    const float* xp = x.p;
+    const int ld = x.ld, C = x.C;
+    const long rows = x.rows;
+    other("cast", [=](hipStream_t s, const RunArgs&) { return launch_cast_bf16_2d(xp, ld, o, rows, C, s); });
+    return o;
+  }
+
+  // ResBlock (openai_unetmodel.py:255-275) / VAE ResnetBlock (model.py:216-236, no emb).  `out` may be a slot of a
+  // concat buffer.  Names differ between the two families, so they are passed in.
+  void resblock(const F32& x, const F32& out, int NB, int H, int Wd, const std::string& n1, const std::string& c1,
+                const std::string& n2, const std::string& c2, const std::string& skip, float eps,
+                const float* emb, int emb_ld, int emb_col) {
+    const int cin = x.C, cout = out.C, M = x.rows;
+    const bool has_skip = c->has(nm(skip + ".weight"));
+    if (!has_skip && cin != cout) fail("resblock %s: channel change without skip conv", nm(c1).c_str());
+    bf16_t* xraw = nullptr;
+    bf16_t* a1 = groupnorm(x, NB, n1, eps, 1, has_skip ? &xraw : nullptr);
+    float* h1 = buf<float>((size_t)M * cout);
+    {
+      GemmParams g = gp_conv3(a1, NB, H, Wd, cin, c->w_conv3(nm(c1 + ".weight"), cin), cout, 1, 0);
+      out_f32(g, h1, cout);
+      g.bias = c->f32(nm(c1 + ".bias"));
+      if (emb) {
+        g.rowbias = emb + emb_col; g.ld_rowbias = emb_ld; g.rows_per_sample = H * Wd; g.rowbias_mode = 1;
+      }
+      gemm(g, 1, "res.conv1");
+    }
+    pl->release(a1);
+    F32 h1v{h1, M, cout, cout};
+    bf16_t* a2 = groupnorm(h1v, NB, n2, eps, 1, nullptr);
+    pl->release(h1);
+    if (has_skip) {
+      GemmParams g = gp_linear(xraw, M, cin, c->w_linear(nm(skip + ".weight")), cout);
+      out_f32(g, out.p, out.ld);
+      g.bias = c->f32(nm(skip + ".bias"));
+      gemm(g, 1, "res.skip");
+      pl->release(xraw);
+    }
+    {
+      GemmParams g = gp_conv3(a2, NB, H, Wd, cout, c->w_conv3(nm(c2 + ".weight"), cout), cout, 1, 0);
+      out_f32(g, out.p, out.ld);
+      g.bias = c->f32(nm(c2 + ".bias"));
+      if (has_skip) { g.res = out.p; g.ldr = out.ld; } else { g.res = x.p; g.ldr = x.ld; }
+      gemm(g, 1, "res.conv2");
+    }
+    pl->release(a2);
+  }
+
+  // SpatialTransformer (attention_openai.py:250-261) with one BasicTransformerBlock (:211-215).
+  // ctxK [NB*Tc][C] bf16 and ctxVt [NB][C][ldvt] bf16 are the hoisted cross-attention K / V^T.
+  void spatial_transformer(const F32& x, const F32& out, int NB, int T, const std::string& p, int heads,
+                           const bf16_t* ctxK, const bf16_t* ctxVt, int Tc, int ldvtc) {
+    const int C = x.C, M = x.rows, D = C / heads;
+    if (!attention_supported(D)) fail("unsupported attention head dim %d", D);
+    const std::string tb = p + ".transformer_blocks.0";
+    const float scale = 1.0f / sqrtf((float)D);
+    bf16_t* a = groupnorm(x, NB, p + ".norm", 1e-6f, 0, nullptr);
+    float* t0 = buf<float>((size_t)M * C);
+    F32 t0v{t0, M, C, C};
+    {
+      GemmParams g = gp_linear(a, M, C, c->w_linear(nm(p + ".proj_in.weight")), C);
+      out_f32(g, t0, C);
+      g.bias = c->f32(nm(p + ".proj_in.bias"));
+      gemm(g, 1, "st.proj_in");
+    }
+    // ---- self attention
+    layernorm(t0v, tb + ".norm1", a);
+    bf16_t* qk = buf<bf16_t>((size_t)M * 2 * C);
+    {
+      const bf16_t* w = c->w_stack(nm(tb + ".attn1.qk"), {nm(tb + ".attn1.to_q.weight"), nm(tb + ".attn1.to_k.weight")});
+      GemmParams g = gp_linear(a, M, C, w, 2 * C);
+      out_b16(g, qk, 2 * C);
+      gemm(g, 1, "st.qk");
+    }
+    const int ldvt = rup(T, 32);
+    bf16_t* vt = buf<bf16_t>((size_t)NB * C * ldvt);
+    {  // V^T[n] = Wv . a[n]^T  (batched: A = Wv shared, "W" operand = this sample's tokens)
+      GemmParams g = gp_linear(c->w_linear(nm(tb + ".attn1.to_v.weight")), C, C, a, T);
+      g.w_bs = (long)T * C;
+      out_b16(g, vt, ldvt);
+      g.c_bs = (long)C * ldvt;
+      gemm(g, NB, "st.vT");
+    }
+    bf16_t* o = buf<bf16_t>((size_t)M * C);
+    other("attn.self", [=](hipStream_t s, const RunArgs&) {
+      return launch_attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, o, C, NB, heads, D, T, T, scale, s);
+    });
+    {
+      GemmParams g = gp_linear(o, M, C, c->w_linear(nm(tb + ".attn1.to_out.0.weight")), C);
+      out_f32(g, t0, C);
+      g.bias = c->f32(nm(tb + ".attn1.to_out.0.bias"));
+      g.res = t0; g.ldr = C;
+      gemm(g, 1, "st.attn1.out");
+    }
+    // ---- cross attention (K / V^T of the context were computed by set_context)
+    layernorm(t0v, tb + ".norm2", a);
+    bf16_t* q2 = qk;
+    {
+      GemmParams g = gp_linear(a, M, C, c->w_linear(nm(tb + ".attn2.to_q.weight")), C);
+      out_b16(g, q2, C);
+      gemm(g, 1, "st.q2");
+    }
+    other("attn.cross", [=](hipStream_t s, const RunArgs&) {
+      return launch_attention(q2, C, ctxK, C, ctxVt, ldvtc, o, C, NB, heads, D, T, Tc, scale, s);
+    });
+    {
+      GemmParams g = gp_linear(o, M, C, c->w_linear(nm(tb + ".attn2.to_out.0.weight")), C);
+      out_f32(g, t0, C);
+      g.bias = c->f32(nm(tb + ".attn2.to_out.0.bias"));
+      g.res = t0; g.ldr = C;
+      gemm(g, 1, "st.attn2.out");
+    }
+    pl->release(qk);
+    pl->release(vt);
+    pl->release(o);
+    // ---- GEGLU feed-forward
+    layernorm(t0v, tb + ".norm3", a);
+    bf16_t* gl = buf<bf16_t>((size_t)M * 4 * C);
+    {
+      const bf16_t* w;
+      const float* b;
+      c->w_geglu(nm(tb + ".ff.net.0.proj"), &w, &b);
+      GemmParams g = gp_linear(a, M, C, w, 8 * C);
+      out_b16(g, gl, 4 * C);
+      g.bias = b;
+      g.geglu = 1;
+      gemm(g, 1, "st.ff1");
+    }
+    {
+      GemmParams g = gp_linear(gl, M, 4 * C, c->w_linear(nm(tb + ".ff.net.2.weight")), C);
+      out_b16(g, a, C);            // transformer output, consumed only by proj_out
+      g.bias = c->f32(nm(tb + ".ff.net.2.bias"));
+      g.res = t0; g.ldr = C;
+      gemm(g, 1, "st.ff2");
+    }
+    pl->release(gl);
+    {
+      GemmParams g = gp_linear(a, M, C, c->w_linear(nm(p + ".proj_out.weight")), C);
+      out_f32(g, out.p, out.ld);
+      g.bias = c->f32(nm(p + ".proj_out.bias"));
+      g.res = x.p; g.ldr = x.ld;
+      gemm(g, 1, "st.proj_out");
+    }
+    pl->release(a);
+    pl->release(t0);
+  }
+
+  // context -> per-ST K [NB*Tc][C] and V^T [NB][C][ldvt]
+  void context_kv(const bf16_t* ctx, int NB, int Tc, int Dc, const std::string& st_prefix, int C, bf16_t** K,
+                  bf16_t** Vt, int ldvt) {
+    const std::string a2 = st_prefix + ".transformer_blocks.0.attn2";
+    *K = buf<bf16_t>((size_t)NB * Tc * C);
+    *Vt = buf<bf16_t>((size_t)NB * C * ldvt);
+    {
+      GemmParams g = gp_linear(ctx, NB * Tc, Dc, c->w_linear(nm(a2 + ".to_k.weight")), C);
+      out_b16(g, *K, C);
+      gemm(g, 1, "ctx.k");
+    }
+    {
+      GemmParams g = gp_linear(c->w_linear(nm(a2 + ".to_v.weight")), C, Dc, ctx, Tc);
+      g.w_bs = (long)Tc * Dc;
+      out_b16(g, *Vt, ldvt);
+      g.c_bs = (long)C * ldvt;
+      gemm(g, NB, "ctx.vT");
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// UNet topology (openai_unetmodel.py:516-692), shared by the plan builder and the emb-offset table.
+struct BlockDesc {
+  enum Kind { CONV_IN, RES, ST, DOWN, UP } kind;
+  std::string prefix;
+  int cin, cout;
+};
+struct UNetTopo {
+  std::vector<std::vector<BlockDesc>> input, output;
+  std::vector<BlockDesc> middle;
+  std::vector<int> in_ch;      // output channels of every input block (the skip stack)
+  std::vector<int> in_ds;      // downsample factor (1,2,4,8) at the output of every input block
+  std::vector<int> out_ds;     // ds at which every output block's ResBlock runs
+  int final_ch = 0;
+};
+
+UNetTopo make_topo(const df_unet_config& u, bool encoder_only) {
+  UNetTopo t;
+  const int mc = u.model_channels;
+  auto in_attn = [&](int ds) {
+    for (int i = 0; i < u.n_attn; ++i)
+      if (u.attention_resolutions[i] == ds) return true;
+    return false;
+  };
+  t.input.push_back({{BlockDesc::CONV_IN, "input_blocks.0.0", u.in_channels, mc}});
+  t.in_ch.push_back(mc);
+  t.in_ds.push_back(1);
+  int ch = mc, ds = 1, idx = 1;
+  for (int level = 0; level < u.n_mult; ++level) {
+    for (int r = 0; r < u.num_res_blocks; ++r) {
+      std::vector<BlockDesc> b;
+      const int co = u.channel_mult[level] * mc;
+      b.push_back({BlockDesc::RES, "input_blocks." + std::to_string(idx) + ".0", ch, co});
+      ch = co;
+      if (in_attn(ds)) b.push_back({BlockDesc::ST, "input_blocks." + std::to_string(idx) + ".1", ch, ch});
+      t.input.push_back(b);
+      t.in_ch.push_back(ch);
+      t.in_ds.push_back(ds);
+      ++idx;
+    }
+    if (level != u.n_mult - 1) {
+      t.input.push_back({{BlockDesc::DOWN, "input_blocks." + std::to_string(idx) + ".0", ch, ch}});
+      ds *= 2;
+      t.in_ch.push_back(ch);
+      t.in_ds.push_back(ds);
+      ++idx;
+    }
+  }
+  t.middle = {{BlockDesc::RES, "middle_block.0", ch, ch},
+              {BlockDesc::ST, "middle_block.1", ch, ch},
+              {BlockDesc::RES, "middle_block.2", ch, ch}};
+  t.final_ch = ch;
+  if (encoder_only) return t;
+  std::vector<int> stack = t.in_ch;
+  idx = 0;
+  for (int level = u.n_mult - 1; level >= 0; --level) {
+    for (int i = 0; i <= u.num_res_blocks; ++i) {
+      const int ich = stack.back();
+      stack.pop_back();
+      std::vector<BlockDesc> b;
+      const int co = mc * u.channel_mult[level];
+      b.push_back({BlockDesc::RES, "output_blocks." + std::to_string(idx) + ".0", ch + ich, co});
+      ch = co;
+      int j = 1;
+      t.out_ds.push_back(ds);
+      if (in_attn(ds)) b.push_back({BlockDesc::ST, "output_blocks." + std::to_string(idx) + "." + std::to_string(j++), ch, ch});
+      if (level && i == u.num_res_blocks) {
+        b.push_back({BlockDesc::UP, "output_blocks." + std::to_string(idx) + "." + std::to_string(j), ch, ch});
+        ds /= 2;
+      }
+      t.output.push_back(b);
+      ++idx;
+    }
+  }
+  t.final_ch = ch;
+  return t;
+}
+
+std::vector<std::string> topo_resblocks(const UNetTopo& t) {
+  std::vector<std::string> r;
+  auto scan = [&](const std::vector<BlockDesc>& b) {
+    for (auto& d : b)
+      if (d.kind == BlockDesc::RES) r.push_back(d.prefix);
+  };
+  for (auto& b : t.input) scan(b);
+  scan(t.middle);
+  for (auto& b : t.output) scan(b);
+  return r;
+}
+std::vector<BlockDesc> topo_sts(const UNetTopo& t) {
+  std::vector<BlockDesc> r;
+  auto scan = [&](const std::vector<BlockDesc>& b) {
+    for (auto& d : b)
+      if (d.kind == BlockDesc::ST) r.push_back(d);
+  };
+  for (auto& b : t.input) scan(b);
+  scan(t.middle);
+  for (auto& b : t.output) scan(b);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// UNet / classifier plan.  which: 0 = denoiser UNet, 1 = alignment classifier backbone.
+//   cfg_mode (UNet only): external x/t hold B = N/2 rows, the batch is duplicated on the fly and the CFG combine
+//   is applied to the output.
+struct NetState {                 // context-dependent buffers shared between set_context and forward plans
+  std::vector<bf16_t*> K, Vt;
+  int ldvt = 0;
+};
+
+void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc, bool cfg_mode, bool ctx_inline) {
+  const df_unet_config& u = which ? c->ccfg : c->ucfg;
+  const std::string pre = which ? "classifier.model." : "model.diffusion_model.";
+  Builder b{c, pl, pre, which};
+  UNetTopo topo = make_topo(u, which == 1);
+  const int mc = u.model_channels, temb = 4 * mc, HW = H * W, heads = u.num_heads;
+  const int Dc = u.context_dim;
+
+  // ---- context K / V^T for every SpatialTransformer (part of this plan: run by set_context or inline)
+  std::vector<BlockDesc> sts = topo_sts(topo);
+  const int ldvtc = rup(Tc, 32);
+  bf16_t* ctxb = b.buf<bf16_t>((size_t)N * Tc * Dc);
+  std::map<std::string, std::pair<bf16_t*, bf16_t*>> kv;
+  const size_t ctx_ops_begin = pl->ops.size();
+  {
+    const long n = (long)N * Tc * Dc;
+    b.other("ctx.cast", [=](hipStream_t s, const RunArgs& a) { return launch_cast_bf16(a.aux, ctxb, n, s); });
+    for (auto& d : sts) {
+      bf16_t *K, *Vt;
+      b.context_kv(ctxb, N, Tc, Dc, d.prefix, d.cin, &K, &Vt, ldvtc);
+      kv[d.prefix] = {K, Vt};
+    }
+  }
+  const size_t ctx_ops_end = pl->ops.size();
+  if (!ctx_inline) {
+    // move the context ops into a separate plan entry "…#ctx" is handled by the caller: it splits [begin,end)
+  }
+  (void)ctx_ops_begin;
+  (void)ctx_ops_end;
+
+  // ---- time embedding MLP and the fused emb projection of every ResBlock
+  const int B_ext = cfg_mode ? N / 2 : N;
+  float* tbuf = b.buf<float>(N);
+  b.other("t.copy", [=](hipStream_t s, const RunArgs& a) {
+    hipError_t e = hipMemcpyAsync(tbuf, a.t, (size_t)B_ext * 4, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return e;
+    if (cfg_mode) e = hipMemcpyAsync(tbuf + B_ext, a.t, (size_t)B_ext * 4, hipMemcpyDeviceToDevice, s);
+    return e;
+  });
+  float* te = b.buf<float>((size_t)N * mc);
+  b.other("t.embed", [=](hipStream_t s, const RunArgs&) { return launch_timestep_embedding(tbuf, te, N, mc, s); });
+  float* e1 = b.buf<float>((size_t)N * temb);
+  float* semb = b.buf<float>((size_t)N * temb);
+  {
+    const bf16_t* w0 = c->w_linear(pre + "time_embed.0.weight");
+    const float* b0 = c->f32(pre + "time_embed.0.bias");
+    const bf16_t* w2 = c->w_linear(pre + "time_embed.2.weight");
+    const float* b2 = c->f32(pre + "time_embed.2.bias");
+    b.other("t.mlp0", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(te, mc, w0, b0, e1, temb, N, temb, mc, 1, s); });
+    // emb is only ever consumed through SiLU (emb_layers = SiLU -> Linear), so SiLU is applied here once
+    b.other("t.mlp2", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(e1, temb, w2, b2, semb, temb, N, temb, temb, 1, s); });
+  }
+  const int etot = c->emb_total[which];
+  float* E = b.buf<float>((size_t)N * etot);
+  {
+    std::vector<std::string> wn, bn;
+    for (auto& r : topo_resblocks(topo)) {
+      wn.push_back(pre + r + ".emb_layers.1.weight");
+      bn.push_back(pre + r + ".emb_layers.1.bias");
+    }
+    const bf16_t* w = c->w_stack(pre + "#embw", wn);
+    const float* bb = c->b_stack(pre + "#embb", bn);
+    b.other("t.embproj", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(semb, temb, w, bb, E, etot, N, etot, temb, 0, s); });
+    pl->weight_bytes += 2.0 * etot * temb + 2.0 * (temb * mc + temb * temb);
+  }
+
+  // ---- input packing: NCHW fp32 -> NHWC bf16 (channels padded to 64), CFG duplication folded in
+  const int cin = u.in_channels;
+  bf16_t* xin = b.buf<bf16_t>((size_t)N * HW * 64);
+  b.other("x.pack", [=](hipStream_t s, const RunArgs& a) {
+    return launch_pack_latent(a.x, xin, B_ext, cin, HW, 64, cfg_mode ? 2 : 1, 1.0f, nullptr, nullptr, s);
+  });
+
+  // ---- concat buffers of the decoder (skip tensors are produced straight into them)
+  const int nin = (int)topo.input.size();
+  struct Cat { float* p; int ch, ich, rows, h, w; };
+  std::vector<Cat> cats;
+  if (!which) {
+    // output block j pops input block (nin-1-j)
+    int ch = topo.middle.back().cout;
+    for (int j = 0; j < (int)topo.output.size(); ++j) {
+      const int k = nin - 1 - j;
+      const int ich = topo.in_ch[k], ds = topo.in_ds[k];
+      const int h = H / ds, w = W / ds, rows = N * h * w;
+      float* p = b.buf<float>((size_t)rows * (ch + ich));
+      cats.push_back({p, ch, ich, rows, h, w});
+      ch = topo.output[j][0].cout;
+    }
+  }
+  auto skip_slot = [&](int k) -> F32 {   // destination of input block k's output
+    if (which) return F32{};
+    const Cat& ct = cats[nin - 1 - k];
+    return F32{ct.p + ct.ch, ct.rows, ct.ich, ct.ch + ct.ich};
+  };
+
+  auto run_block = [&](const std::vector<BlockDesc>& blk, F32 h, int ds, F32 final_dst) -> F32 {
+    for (size_t li = 0; li < blk.size(); ++li) {
+      const BlockDesc& d = blk[li];
+      const bool last = (li + 1 == blk.size());
+      int hh = H / ds, ww = W / ds;
+      F32 dst;
+      auto mk = [&](int rows, int C) {
+        if (last && final_dst.p) return final_dst;
+        return F32{b.buf<float>((size_t)rows * C), rows, C, C};
+      };
+      if (d.kind == BlockDesc::CONV_IN) {
+        dst = mk(N * HW, d.cout);
+        GemmParams g = Builder::gp_conv3(xin, N, H, W, 64, c->w_conv3(pre + d.prefix + ".weight", 64), d.cout, 1, 0);
+        Builder::out_f32(g, dst.p, dst.ld);
+        g.bias = c->f32(pre + d.prefix + ".bias");
+        b.gemm(g, 1, "conv_in");
+      } else if (d.kind == BlockDesc::RES) {
+        dst = mk(h.rows, d.cout);
+        b.resblock(h, dst, N, hh, ww, d.prefix + ".in_layers.0", d.prefix + ".in_layers.2", d.prefix + ".out_layers.0",
+                   d.prefix + ".out_layers.3", d.prefix + ".skip_connection", 1e-5f, E, etot,
+                   c->emb_off[which].at(d.prefix));
+      } else if (d.kind == BlockDesc::ST) {
+        dst = mk(h.rows, d.cout);
+        b.spatial_transformer(h, dst, N, hh * ww, d.prefix, heads, kv[d.prefix].first, kv[d.prefix].second, Tc, ldvtc);
+      } else if (d.kind == BlockDesc::DOWN) {
+        dst = mk(h.rows / 4, d.cout);
+        bf16_t* hb = b.cast2d(h);
+        GemmParams g = Builder::gp_conv3(hb, N, hh, ww, d.cin, c->w_conv3(pre + d.prefix + ".op.weight", d.cin), d.cout, 2, 0);
+        Builder::out_f32(g, dst.p, dst.ld);
+        g.bias = c->f32(pre + d.prefix + ".op.bias");
+        b.gemm(g, 1, "down");
+        pl->release(hb);
+      } else {  // UP: nearest x2 then conv3x3 (openai_unetmodel.py:100-119)
+        dst = mk(h.rows * 4, d.cout);
+        bf16_t* hb = b.cast2d(h);
+        GemmParams g = Builder::gp_conv3(hb, N, hh, ww, d.cin, c->w_conv3(pre + d.prefix + ".conv.weight", d.cin), d.cout, 1, 1);
+        Builder::out_f32(g, dst.p, dst.ld);
+        g.bias = c->f32(pre + d.prefix + ".conv.bias");
+        b.gemm(g, 1, "up");
+        pl->release(hb);
+      }
+      // the previous intermediate is dead unless it lives in a concat buffer
+      bool in_cat = false;
+      for (auto& ct : cats)
+        if (h.p >= ct.p && h.p < ct.p + (size_t)ct.rows * (ct.ch + ct.ich)) in_cat = true;
+      if (h.p && !in_cat) pl->release(h.p);
+      h = dst;
+    }
+    return h;
+  };
+
+  F32 h{};
+  for (int k = 0; k < nin; ++k) {
+    const int ds_run = (topo.input[k][0].kind == BlockDesc::DOWN) ? topo.in_ds[k] / 2 : topo.in_ds[k];
+    h = run_block(topo.input[k], h, ds_run, skip_slot(k));
+  }
+  const int ds_mid = topo.in_ds.back();
+  if (which) {
+    h = run_block(topo.middle, h, ds_mid, F32{});
+    // classifier head: GN -> SiLU -> conv3x3 -> global avg-pool -> Linear -> sigmoid (alignment_backbone.py:630-638)
+    const int hh = H / ds_mid, ww = W / ds_mid, co = topo.final_ch / 2;
+    bf16_t* a = b.groupnorm(h, N, "out.0", 1e-5f, 1, nullptr);
+    float* ho = b.buf<float>((size_t)h.rows * co);
+    GemmParams g = Builder::gp_conv3(a, N, hh, ww, topo.final_ch, c->w_conv3(pre + "out.2.weight", topo.final_ch), co, 1, 0);
+    Builder::out_f32(g, ho, co);
+    g.bias = c->f32(pre + "out.2.bias");
+    b.gemm(g, 1, "cls.out");
+    float* pooled = b.buf<float>((size_t)N * rup(co, 8));
+    const int hw2 = hh * ww, oc = u.out_channels;
+    b.other("cls.pool", [=](hipStream_t s, const RunArgs&) { return launch_avgpool(ho, pooled, N, hw2, co, s); });
+    const bf16_t* wc = c->w_linear(pre + "classifier.weight");
+    const float* bc = c->f32(pre + "classifier.bias");
+    b.other("cls.head", [=](hipStream_t s, const RunArgs& ar) { return launch_linear_rows(pooled, co, wc, bc, ar.out, oc, N, oc, co, 2, s); });
+    return;
+  }
+  // middle block output goes into the first concat buffer's leading columns
+  h = run_block(topo.middle, h, ds_mid, F32{cats[0].p, cats[0].rows, cats[0].ch, cats[0].ch + cats[0].ich});
+  const int nout = (int)topo.output.size();
+  for (int j = 0; j < nout; ++j) {
+    F32 cat{cats[j].p, cats[j].rows, cats[j].ch + cats[j].ich, cats[j].ch + cats[j].ich};
+    F32 dst{};
+    if (j + 1 < nout) dst = F32{cats[j + 1].p, cats[j + 1].rows, cats[j + 1].ch, cats[j + 1].ch + cats[j + 1].ich};
+    h = run_block(topo.output[j], cat, topo.out_ds[j], dst);
+  }
+  // ---- out: GN -> SiLU -> conv3x3 -> NCHW fp32 (openai_unetmodel.py:682-686)
+  bf16_t* a = b.groupnorm(h, N, "out.0", 1e-5f, 1, nullptr);
+  GemmParams g = Builder::gp_conv3(a, N, H, W, mc, c->w_conv3(pre + "out.2.weight", mc), u.out_channels, 1, 0);
+  g.bias = c->f32(pre + "out.2.bias");
+  g.store_nchw = 1;
+  g.hw_out = HW;
+  if (cfg_mode) {
+    float* e2 = b.buf<float>((size_t)N * u.out_channels * HW);
+    Builder::out_f32(g, e2, u.out_channels);
+    b.gemm(g, 1, "out.conv");
+    const long n = (long)(N / 2) * u.out_channels * HW;
+    b.other("cfg.combine", [=](hipStream_t s, const RunArgs& ar) { return launch_cfg_combine(e2, ar.out, n, ar.scale, s); });
+  } else {
+    Builder::out_f32(g, nullptr, u.out_channels);
+    Op& o = b.gemm(g, 1, "out.conv");
+    o.c_ext = true;
+  }
+}
+
+// VAE decoder plan (autoencoder.py:330-333, stage1_autoencoder/model.py:630-663)
+void build_vae(df_ctx* c, Plan* pl, int B, int H, int W) {
+  const df_vae_config& v = c->vcfg;
+  const std::string pre = "first_stage_model.";
+  Builder b{c, pl, pre, 0};
+  const int zc = v.z_channels;
+  int hh = H, ww = W;
+  int ch = v.ch * v.ch_mult[v.n_mult - 1];
+  bf16_t* zin = b.buf<bf16_t>((size_t)B * hh * ww * 64);
+  {
+    const float* wpq = c->f32(pre + "post_quant_conv.weight");
+    const float* bpq = c->f32(pre + "post_quant_conv.bias");
+    const float inv = 1.0f / v.scale_factor;
+    const int HW = hh * ww;
+    b.other("z.pack", [=](hipStream_t s, const RunArgs& a) { return launch_pack_latent(a.x, zin, B, zc, HW, 64, 1, inv, wpq, bpq, s); });
+  }
+  F32 h{b.buf<float>((size_t)B * hh * ww * ch), B * hh * ww, ch, ch};
+  {
+    GemmParams g = Builder::gp_conv3(zin, B, hh, ww, 64, c->w_conv3(pre + "decoder.conv_in.weight", 64), ch, 1, 0);
+    Builder::out_f32(g, h.p, ch);
+    g.bias = c->f32(pre + "decoder.conv_in.bias");
+    b.gemm(g, 1, "vae.conv_in");
+  }
+  auto res = [&](const std::string& p, F32 x, int cout) {
+    F32 o{b.buf<float>((size_t)x.rows * cout), x.rows, cout, cout};
+    b.resblock(x, o, B, hh, ww, p + ".norm1", p + ".conv1", p + ".norm2", p + ".conv2", p + ".nin_shortcut", 1e-6f,
+               nullptr, 0, 0);
+    pl->release(x.p);
+    return o;
+  };
+  h = res("decoder.mid.block_1", h, ch);
+  {  // AttnBlock (model.py:273-297): single head over hh*ww tokens, head dim = ch -> GEMM + row-softmax + GEMM
+    const std::string p = "decoder.mid.attn_1";
+    const int T = hh * ww, M = B * T;
+    bf16_t* a = b.groupnorm(h, B, p + ".norm", 1e-6f, 0, nullptr);
+    bf16_t* q = b.buf<bf16_t>((size_t)M * ch);
+    bf16_t* k = b.buf<bf16_t>((size_t)M * ch);
+    bf16_t* vt = b.buf<bf16_t>((size_t)B * ch * T);
+    {
+      GemmParams g = Builder::gp_linear(a, M, ch, c->w_linear(pre + p + ".q.weight"), ch);
+      Builder::out_b16(g, q, ch);
+      g.bias = c->f32(pre + p + ".q.bias");
+      b.gemm(g, 1, "vae.q");
+    }
+    {
+      GemmParams g = Builder::gp_linear(a, M, ch, c->w_linear(pre + p + ".k.weight"), ch);
+      Builder::out_b16(g, k, ch);
+      g.bias = c->f32(pre + p + ".k.bias");
+      b.gemm(g, 1, "vae.k");
+    }
+    {  // V^T without its bias: softmax rows sum to 1, so P(V + 1 b^T) = P V + b^T -> bias added after P V
+      GemmParams g = Builder::gp_linear(c->w_linear(pre + p + ".v.weight"), ch, ch, a, T);
+      g.w_bs = (long)T * ch;
+      Builder::out_b16(g, vt, T);
+      g.c_bs = (long)ch * T;
+      b.gemm(g, B, "vae.vT");
+    }
+    float* sc = b.buf<float>((size_t)B * T * T);
+    {
+      GemmParams g = Builder::gp_linear(q, T, ch, k, T);
+      g.a_bs = (long)T * ch;
+      g.w_bs = (long)T * ch;
+      Builder::out_f32(g, sc, T);
+      g.c_bs = (long)T * T;
+      g.alpha = 1.0f / sqrtf((float)ch);
+      b.gemm(g, B, "vae.qk");
+    }
+    bf16_t* pr = b.buf<bf16_t>((size_t)B * T * T);
+    b.other("vae.softmax", [=](hipStream_t s, const RunArgs&) { return launch_softmax_rows(sc, pr, B * T, T, s); });
+    bf16_t* o = q;
+    {
+      GemmParams g = Builder::gp_linear(pr, T, T, vt, ch);
+      g.a_bs = (long)T * T;
+      g.w_bs = (long)ch * T;
+      Builder::out_b16(g, o, ch);
+      g.c_bs = (long)T * ch;
+      g.bias = c->f32(pre + p + ".v.bias");
+      b.gemm(g, B, "vae.pv");
+    }
+    F32 ho{b.buf<float>((size_t)M * ch), M, ch, ch};
+    {
+      GemmParams g = Builder::gp_linear(o, M, ch, c->w_linear(pre + p + ".proj_out.weight"), ch);
+      Builder::out_f32(g, ho.p, ch);
+      g.bias = c->f32(pre + p + ".proj_out.bias");
+      g.res = h.p; g.ldr = h.ld;
+      b.gemm(g, 1, "vae.proj_out");
+    }
+    for (void* p_ : {(void*)a, (void*)q, (void*)k, (void*)vt, (void*)sc, (void*)pr, (void*)h.p}) pl->release(p_);
+    h = ho;
+  }
+  h = res("decoder.mid.block_2", h, ch);
+  for (int lvl = v.n_mult - 1; lvl >= 0; --lvl) {
+    const int co = v.ch * v.ch_mult[lvl];
+    for (int ib = 0; ib <= v.num_res_blocks; ++ib)
+      h = res("decoder.up." + std::to_string(lvl) + ".block." + std::to_string(ib), h, co);
+    if (lvl != 0) {
+      bf16_t* hb = b.cast2d(h);
+      F32 o{b.buf<float>((size_t)h.rows * 4 * co), h.rows * 4, co, co};
+      const std::string p = pre + "decoder.up." + std::to_string(lvl) + ".upsample.conv";
+      GemmParams g = Builder::gp_conv3(hb, B, hh, ww, co, c->w_conv3(p + ".weight", co), co, 1, 1);
+      Builder::out_f32(g, o.p, co);
+      g.bias = c->f32(p + ".bias");
+      b.gemm(g, 1, "vae.up");
+      pl->release(hb);
+      pl->release(h.p);
+      h = o;
+      hh *= 2;
+      ww *= 2;
+    }
+  }
+  bf16_t* a = b.groupnorm(h, B, "decoder.norm_out", 1e-6f, 1, nullptr);
+  GemmParams g = Builder::gp_conv3(a, B, hh, ww, h.C, c->w_conv3(pre + "decoder.conv_out.weight", h.C), v.out_ch, 1, 0);
+  Builder::out_f32(g, nullptr, v.out_ch);
+  g.bias = c->f32(pre + "decoder.conv_out.bias");
+  g.store_nchw = 1;
+  g.hw_out = hh * ww;
+  Op& o = b.gemm(g, 1, "vae.conv_out");
+  o.c_ext = true;
+}
+
+// cond stage: Linear(origin->embed) + pos_emb[:T]  (video_feat_encoder.py:12-18)
+void build_cond(df_ctx* c, Plan* pl, int B, int T) {
+  const df_cond_config& k = c->kcfg;
+  const std::string pre = "cond_stage_model.";
+  Builder b{c, pl, pre, 0};
+  if (T > k.seq_len) fail("cond stage: %d frames > pos_emb length %d", T, k.seq_len);
+  const long n = (long)B * T * k.origin_dim;
+  bf16_t* xb = b.buf<bf16_t>((size_t)n);
+  b.other("cond.cast", [=](hipStream_t s, const RunArgs& a) { return launch_cast_bf16(a.x, xb, n, s); });
+  GemmParams g = Builder::gp_linear(xb, B * T, k.origin_dim, c->w_linear(pre + "embedder.0.weight"), k.embed_dim);
+  Builder::out_f32(g, nullptr, k.embed_dim);
+  g.bias = c->f32(pre + "embedder.0.bias");
+  g.rowbias = c->f32(pre + "pos_emb.weight");
+  g.ld_rowbias = k.embed_dim;
+  g.rows_per_sample = T;
+  g.rowbias_mode = 2;
+  Op& o = b.gemm(g, 1, "cond.embed");
+  o.c_ext = true;
+}
+
+void finish_plan(df_ctx* c, Plan* pl) {
+  if (pl->partial_bytes) {
+    HIPCHK(hipMalloc((void**)&pl->partial, pl->partial_bytes));
+    for (auto& o : pl->ops)
+      if (o.is_gemm && o.gp.splitk > 1) o.gp.partial = pl->partial;
+  }
+  HIPCHK(hipStreamSynchronize(c->pack_stream));   // weight packing done before first use
+}
+
+void run_ops(Plan* pl, size_t begin, size_t end, hipStream_t s, const RunArgs& a) {
+  for (size_t i = begin; i < end; ++i) {
+    Op& o = pl->ops[i];
+    hipError_t e;
+    if (o.is_gemm) {
+      GemmParams g = o.gp;
+      if (o.c_ext) g.C = a.out;
+      e = launch_gemm(g, o.tile, o.batch, s);
+    } else {
+      e = o.fn(s, a);
+    }
+    if (e != hipSuccess) fail("op %zu (%s) failed: %s", i, o.tag, hipGetErrorString(e));
+  }
+}
+
+// Time every tile candidate of every GEMM in the plan and keep the fastest ("measure, don't guess").
+void autotune_plan(Plan* pl, hipStream_t s) {
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  std::map<std::string, std::pair<int, int>> memo;
+  for (auto& o : pl->ops) {
+    if (!o.is_gemm || o.c_ext) continue;
+    GemmParams g = o.gp;
+    char key[160];
+    snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d_%d", g.M, g.N, g.K, g.taps, g.stride, g.ups, o.batch, g.geglu);
+    auto it = memo.find(key);
+    if (it != memo.end()) {
+      o.tile = it->second.first;
+      o.gp.splitk = it->second.second;
+      o.gp.partial = pl->partial;
+      continue;
+    }
+    float best = 1e30f;
+    int bt = o.tile, bs = g.splitk;
+    const int nk = g.K / 64;
+    for (int t = 0; t < TILE_COUNT; ++t) {
+      if (g.geglu && !(t == TILE_128x128 || t == TILE_64x128)) continue;
+      for (int sk = 1; sk <= 16; sk *= 2) {
+        if (sk > 1 && (o.batch > 1 || nk / sk < 2)) break;
+        const size_t need = (size_t)sk * g.M * g.N * 4;
+        if (sk > 1 && need > pl->partial_bytes) break;
+        GemmParams q = g;
+        q.splitk = sk;
+        q.partial = pl->partial;
+        // res may alias C: results are garbage during tuning but are recomputed by the next real run
+        if (launch_gemm(q, t, o.batch, s) != hipSuccess) continue;
+        HIPCHK(hipEventRecord(e0, s));
+        for (int r = 0; r < 3; ++r) (void)launch_gemm(q, t, o.batch, s);
+        HIPCHK(hipEventRecord(e1, s));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) {
+          best = ms;
+          bt = t;
+          bs = sk;
+        }
+      }
+    }
+    o.tile = bt;
+    o.gp.splitk = bs;
+    o.gp.partial = pl->partial;
+    memo[key] = {bt, bs};
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+}
+
+Plan* get_plan(df_ctx* c, const std::string& key, const std::function<void(Plan*)>& build) {
+  auto it = c->plans.find(key);
+  if (it != c->plans.end()) return it->second.get();
+  if (!c->finalized) fail("df_finalize() has not been called");
+  std::unique_ptr<Plan> p(new Plan());
+  build(p.get());
+  if (c->autotune) {
+    // tuning may try larger split-K factors than the cost model picked: give the scratch some head-room
+    size_t want = 0;
+    for (auto& o : p->ops)
+      if (o.is_gemm && o.batch == 1) want = std::max(want, (size_t)16 * o.gp.M * o.gp.N * 4);
+    if (want > ((size_t)512 << 20)) want = (size_t)512 << 20;
+    if (want > p->partial_bytes) p->partial_bytes = want;
+  }
+  finish_plan(c, p.get());
+  if (c->autotune) {
+    autotune_plan(p.get(), c->pack_stream);
+    HIPCHK(hipStreamSynchronize(c->pack_stream));
+  }
+  Plan* r = p.get();
+  c->plans[key] = std::move(p);
+  return r;
+}
+
+std::string keyf(const char* fmt, ...) {
+  char buf[128];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  return buf;
+}
+
+void build_emb_table(df_ctx* c, int which) {
+  const df_unet_config& u = which ? c->ccfg : c->ucfg;
+  UNetTopo t = make_topo(u, which == 1);
+  int off = 0;
+  const std::string pre = which ? "classifier.model." : "model.diffusion_model.";
+  for (auto& r : topo_resblocks(t)) {
+    c->emb_off[which][r] = off;
+    off += (int)c->rt(pre + r + ".emb_layers.1.weight").shape[0];
+  }
+  c->emb_total[which] = off;
+}
+
+template <class F>
+int guard(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
+}  // namespace
+
+// ================================================================================================== C ABI
+extern "C" {
+
+int df_abi_version(void) { return 1; }
+const char* df_last_error(void) { return g_err.c_str(); }
+
+int df_create(int device, df_ctx** out) {
+  return guard([&] {
+    HIPCHK(hipSetDevice(device));
+    df_ctx* c = new df_ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->pack_stream, hipStreamNonBlocking));
+    *out = c;
+  });
+}
+
+void df_destroy(df_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  if (ctx->pack_stream) (void)hipStreamDestroy(ctx->pack_stream);
+  delete ctx;
+}
+
+int df_config_unet(df_ctx* c, const df_unet_config* cfg) { return guard([&] { c->ucfg = *cfg; c->has_unet = true; }); }
+int df_config_vae(df_ctx* c, const df_vae_config* cfg) { return guard([&] { c->vcfg = *cfg; c->has_vae = true; }); }
+int df_config_cond(df_ctx* c, const df_cond_config* cfg) { return guard([&] { c->kcfg = *cfg; c->has_cond = true; }); }
+int df_config_classifier(df_ctx* c, const df_unet_config* cfg) { return guard([&] { c->ccfg = *cfg; c->has_cls = true; }); }
+
+static void load_common(df_ctx* c, const char* name, const float* src, const int64_t* shape, int ndim, hipMemcpyKind kind) {
+  HIPCHK(hipSetDevice(c->device));
+  RawT t;
+  t.n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    t.shape.push_back(shape[i]);
+    t.n *= (size_t)shape[i];
+  }
+  auto it = c->raw.find(name);
+  if (it != c->raw.end()) {
+    (void)hipFree(it->second.d);
+    c->raw.erase(it);
+  }
+  HIPCHK(hipMalloc((void**)&t.d, ((t.n * 4) + 255) & ~(size_t)255));
+  HIPCHK(hipMemcpy(t.d, src, t.n * 4, kind));
+  c->raw[name] = t;
+}
+
+int df_load_tensor(df_ctx* c, const char* name, const float* host, const int64_t* shape, int ndim) {
+  return guard([&] { load_common(c, name, host, shape, ndim, hipMemcpyHostToDevice); });
+}
+int df_load_tensor_dev(df_ctx* c, const char* name, const float* dev, const int64_t* shape, int ndim) {
+  return guard([&] { load_common(c, name, dev, shape, ndim, hipMemcpyDeviceToDevice); });
+}
+
+int df_finalize(df_ctx* c) {
+  return guard([&] {
+    HIPCHK(hipSetDevice(c->device));
+    if (c->has_unet) build_emb_table(c, 0);
+    if (c->has_cls) build_emb_table(c, 1);
+    c->plans.clear();
+    c->last_unet = nullptr;
+    c->finalized = true;
+  });
+}
+
+int df_autotune(df_ctx* c, int enable) { return guard([&] { c->autotune = enable != 0; }); }
+
+int df_cond_encode(df_ctx* c, const float* feats, float* out, int B, int T, void* stream) {
+  return guard([&] {
+    if (!c->has_cond) fail("cond stage not configured");
+    Plan* p = get_plan(c, keyf("cond_%d_%d", B, T), [&](Plan* pl) { build_cond(c, pl, B, T); });
+    RunArgs a;
+    a.x = feats;
+    a.out = out;
+    run_ops(p, 0, p->ops.size(), (hipStream_t)stream, a);
+  });
+}
+
+// UNet plans keep their context ops at the front of the op list: [0, n_ctx) = context, rest = forward.
+static size_t n_ctx_ops(df_ctx* c, int which) {
+  const df_unet_config& u = which ? c->ccfg : c->ucfg;
+  UNetTopo t = make_topo(u, which == 1);
+  return 1 + 2 * topo_sts(t).size();
+}
+
+static Plan* unet_plan(df_ctx* c, int N, int H, int W, int T, bool cfg) {
+  if (!c->has_unet) fail("unet not configured");
+  if (H % (1 << (c->ucfg.n_mult - 1)) || W % (1 << (c->ucfg.n_mult - 1))) fail("latent %dx%d not divisible by the UNet downsampling", H, W);
+  return get_plan(c, keyf("unet_%d_%d_%d_%d_%d", N, H, W, T, (int)cfg),
+                  [&](Plan* pl) { build_unet_like(c, pl, 0, N, H, W, T, cfg, false); });
+}
+
+int df_unet_set_context(df_ctx* c, const float* context, int N, int T, void* stream) {
+  return guard([&] {
+    c->ctx_N = N;
+    c->ctx_T = T;
+    // the context K/V live inside each forward plan; remember the pointer and (re)run the context ops lazily
+    // for every plan that is used with this context.  Simple and exact: stash the pointer, mark plans stale.
+    RunArgs a;
+    a.aux = context;
+    const size_t nctx = n_ctx_ops(c, 0);
+    for (auto& kv : c->plans) {
+      if (kv.first.rfind("unet_", 0) != 0) continue;
+      int n, h, w, t, g;
+      if (sscanf(kv.first.c_str(), "unet_%d_%d_%d_%d_%d", &n, &h, &w, &t, &g) == 5 && n == N && t == T)
+        run_ops(kv.second.get(), 0, nctx, (hipStream_t)stream, a);
+    }
+    // keep a device copy so plans created later can still be primed
+    const size_t bytes = (size_t)N * T * c->ucfg.context_dim * 4;
+    if (bytes > c->ctx_copy_bytes) {
+      c->ctx_copy = (float*)c->pmalloc(bytes);
+      c->ctx_copy_bytes = bytes;
+    }
+    HIPCHK(hipMemcpyAsync(c->ctx_copy, context, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  });
+}
+
+static void unet_run(df_ctx* c, const float* x, const float* t, float* out, int N, int H, int W, bool cfg, float scale,
+                     hipStream_t s) {
+  if (c->ctx_N != N) fail("context has %d rows but the UNet batch is %d (call df_unet_set_context first)", c->ctx_N, N);
+  const std::string key = keyf("unet_%d_%d_%d_%d_%d", N, H, W, c->ctx_T, (int)cfg);
+  const bool fresh = c->plans.count(key) == 0;
+  Plan* p = unet_plan(c, N, H, W, c->ctx_T, cfg);
+  const size_t nctx = n_ctx_ops(c, 0);
+  RunArgs a;
+  a.x = x;
+  a.t = t;
+  a.out = out;
+  a.scale = scale;
+  if (fresh) {  // plan created after set_context: prime its K/V from the saved context copy
+    a.aux = c->ctx_copy;
+    run_ops(p, 0, nctx, s, a);
+  }
+  run_ops(p, nctx, p->ops.size(), s, a);
+  c->last_unet = p;
+}
+
+int df_unet_forward(df_ctx* c, const float* x, const float* t, float* out, int N, int H, int W, void* stream) {
+  return guard([&] { unet_run(c, x, t, out, N, H, W, false, 1.f, (hipStream_t)stream); });
+}
+
+int df_unet_forward_cfg(df_ctx* c, const float* x, const float* t, float* out, int B, int H, int W, float scale,
+                        void* stream) {
+  return guard([&] { unet_run(c, x, t, out, 2 * B, H, W, true, scale, (hipStream_t)stream); });
+}
+
+int df_vae_decode(df_ctx* c, const float* z, float* out, int B, int H, int W, void* stream) {
+  return guard([&] {
+    if (!c->has_vae) fail("vae not configured");
+    Plan* p = get_plan(c, keyf("vae_%d_%d_%d", B, H, W), [&](Plan* pl) { build_vae(c, pl, B, H, W); });
+    RunArgs a;
+    a.x = z;
+    a.out = out;
+    run_ops(p, 0, p->ops.size(), (hipStream_t)stream, a);
+  });
+}
+
+int df_classifier_forward(df_ctx* c, const float* x, const float* t, const float* feat, float* prob, int B, int H,
+                          int W, int T, void* stream) {
+  return guard([&] {
+    if (!c->has_cls) fail("classifier not configured");
+    Plan* p = get_plan(c, keyf("cls_%d_%d_%d_%d", B, H, W, T),
+                       [&](Plan* pl) { build_unet_like(c, pl, 1, B, H, W, T, false, true); });
+    RunArgs a;
+    a.x = x;
+    a.t = t;
+    a.aux = feat;
+    a.out = prob;
+    run_ops(p, 0, p->ops.size(), (hipStream_t)stream, a);
+  });
+}
+
+int df_cfg_combine(const float* e2, float* e, int64_t n, float scale, void* stream) {
+  return guard([&] { HIPCHK(launch_cfg_combine(e2, e, (long)n, scale, (hipStream_t)stream)); });
+}
+int df_lincomb(float* out, const float* const* in, const float* coef, int nterms, int64_t n, void* stream) {
+  return guard([&] { HIPCHK(launch_lincomb(out, in, coef, nterms, (long)n, (hipStream_t)stream)); });
+}
+int df_ddim_update(const float* x, const float* e, const float* noise, float* x_prev, float* pred_x0, int64_t n,
+                   float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, void* stream) {
+  return guard([&] {
+    const float dir = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
+    HIPCHK(launch_ddim_update(x, e, noise, x_prev, pred_x0, (long)n, sqrtf(a_t), sqrt_one_minus_at, sqrtf(a_prev), dir,
+                              sigma_t, (hipStream_t)stream));
+  });
+}
+
+int df_unet_plan_stats(df_ctx* c, int64_t* n_launches, double* gemm_flops, double* weight_bytes) {
+  return guard([&] {
+    if (!c->last_unet) fail("no UNet plan has been executed yet");
+    const size_t nctx = n_ctx_ops(c, 0);
+    int64_t n = 0;
+    for (size_t i = nctx; i < c->last_unet->ops.size(); ++i) n += 1 + (c->last_unet->ops[i].is_gemm && c->last_unet->ops[i].gp.splitk > 1);
+    *n_launches = n;
+    *gemm_flops = c->last_unet->gemm_flops;
+    *weight_bytes = c->last_unet->weight_bytes;
+  });
+}
+
+// ---- single-kernel entry points for unit tests
+int df_test_gemm(const uint16_t* A, const uint16_t* W, float* C, int M, int N, int K, int tile, int splitk, void* stream) {
+  return guard([&] {
+    GemmParams g = Builder::gp_linear(A, M, K, W, N);
+    Builder::out_f32(g, C, N);
+    g.splitk = splitk;
+    float* part = nullptr;
+    if (splitk > 1) {
+      HIPCHK(hipMalloc((void**)&part, (size_t)splitk * M * N * 4));
+      g.partial = part;
+    }
+    HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
+    if (part) {
+      HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+      (void)hipFree(part);
+    }
+  });
+}
+
+int df_test_conv3x3(const uint16_t* A, const uint16_t* W, const float* bias, float* C, int NB, int H, int Wd, int Cin,
+                    int Cout, int stride, int ups, int tile, int splitk, void* stream) {
+  return guard([&] {
+    GemmParams g = Builder::gp_conv3(A, NB, H, Wd, Cin, W, Cout, stride, ups);
+    Builder::out_f32(g, C, Cout);
+    g.bias = bias;
+    g.splitk = splitk;
+    float* part = nullptr;
+    if (splitk > 1) {
+      HIPCHK(hipMalloc((void**)&part, (size_t)splitk * g.M * g.N * 4));
+      g.partial = part;
+    }
+    HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
+    if (part) {
+      HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+      (void)hipFree(part);
+    }
+  });
+}
+
+int df_test_groupnorm(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,
+                      int silu, uint16_t* out, void* stream) {
+  return guard([&] { HIPCHK(launch_groupnorm(x, ld, N, HW, C, gamma, beta, eps, silu, out, C, nullptr, (hipStream_t)stream)); });
+}
+int df_test_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, uint16_t* out, void* stream) {
+  return guard([&] { HIPCHK(launch_layernorm(x, C, rows, C, gamma, beta, 1e-5f, out, (hipStream_t)stream)); });
+}
+int df_test_attention(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt, uint16_t* O,
+                      int ldo, int N, int heads, int D, int Tq, int Tk, float scale, void* stream) {
+  return guard([&] { HIPCHK(launch_attention(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, D, Tq, Tk, scale, (hipStream_t)stream)); });
+}
+
+}  // extern "C"

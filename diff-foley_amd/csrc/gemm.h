@@ -1,0 +1,47 @@
+// Implicit-GEMM descriptor shared by host launcher and device kernels.
+//
+//   C[m, n] = epilogue( alpha * sum_k A(m, k) * W[n, k] )
+//
+// A is a bf16 NHWC activation tensor [rows][lda]; for taps == 9 the k index runs over
+// (ky, kx, cin) of a 3x3 window (zero padding 1, stride 1|2, optional nearest x2 upsample of
+// the input), i.e. the convolution is evaluated as a GEMM without materialising im2col.
+// W is bf16 [N][K] (K contiguous) -- PyTorch Linear layout, conv weights re-packed to
+// [Cout][ky][kx][Cin] at load time.  Accumulation is fp32 on the MFMA units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct GemmParams {
+  // operands
+  const uint16_t* A; long a_bs; int lda;
+  const uint16_t* W; long w_bs;
+  int M, N, K;
+  // implicit-conv geometry
+  int taps;    // 1 (linear / 1x1) or 9 (3x3, pad 1)
+  int Cin;     // channels per tap, K = taps * Cin, Cin % 64 == 0
+  int H, Wd;   // stored input spatial size
+  int OH, OW;  // output spatial size (M = batch * OH * OW)
+  int stride;  // 1 | 2
+  int ups;     // 1: conv runs on the nearest-x2 upsampled input
+  // epilogue
+  void* C; long c_bs; int ldc; int out_bf16;
+  float alpha;
+  const float* bias;                 // [N]
+  const float* rowbias; int ld_rowbias; int rows_per_sample; int rowbias_mode;  // 1: by sample, 2: by position
+  const float* res; long res_bs; int ldr;   // fp32 residual, may alias C
+  int geglu;                         // columns come in (x:32 | gate:32) groups, output width N/2
+  int store_nchw; int hw_out;        // write C as [batch][N][hw_out] instead of [rows][ldc]
+  // split-K
+  int splitk; float* partial;
+};
+
+enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_COUNT = 5 };
+
+static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
+  static const int d[TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}};
+  *bm = d[cfg][0];
+  *bn = d[cfg][1];
+}
+
+// batch > 1 and splitk > 1 are mutually exclusive.
+hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t stream);

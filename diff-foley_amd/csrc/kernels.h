@@ -1,0 +1,63 @@
+// Host-side launchers of the non-GEMM kernels (norms, attention, small linears, sampler updates).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// GroupNorm(32 groups) [+ SiLU] over an fp32 NHWC tensor [N][HW][ld] -> bf16 [N][HW][ldo].
+// raw_out (optional) receives the un-normalised input cast to bf16 (operand of a 1x1 skip conv).
+hipError_t launch_groupnorm(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
+                            float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, hipStream_t s);
+
+// LayerNorm over the last dim of fp32 [rows][ld] -> bf16 [rows][C]   (eps 1e-5, affine)
+hipError_t launch_layernorm(const float* x, int ld, int rows, int C, const float* gamma, const float* beta,
+                            float eps, uint16_t* out, hipStream_t s);
+
+// Fused attention  O = softmax(scale * Q K^T) V  per (batch, head).
+//   Q  bf16 [N*Tq][ldq]  head h at columns [h*D, (h+1)*D)
+//   K  bf16 [N*Tk][ldk]  same head layout
+//   Vt bf16 [N][heads*D][ldvt]  (V transposed: keys contiguous), ldvt >= round_up(Tk, 32) and zero padded
+//   O  bf16 [N*Tq][ldo]
+hipError_t launch_attention(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt,
+                            uint16_t* O, int ldo, int N, int heads, int D, int Tq, int Tk, float scale,
+                            hipStream_t s);
+bool attention_supported(int D);
+
+// Row softmax: fp32 scores [rows][T] -> bf16 probabilities [rows][T]  (VAE single-head attention)
+hipError_t launch_softmax_rows(const float* s, uint16_t* p, int rows, int T, hipStream_t st);
+
+// out[m][n] = act_out( sum_k a[m][k] * W[n][k] + bias[n] ),  M <= 16, fp32 activations, bf16 weights.
+hipError_t launch_linear_rows(const float* a, int lda, const uint16_t* W, const float* bias, float* out, int ldo,
+                              int M, int N, int K, int act_out /*0 none, 1 silu, 2 sigmoid*/, hipStream_t s);
+
+// Sinusoidal timestep embedding [cos | sin] (util.py:151-171), t fp32 (may be fractional) -> [N][dim] fp32
+hipError_t launch_timestep_embedding(const float* t, float* out, int N, int dim, hipStream_t s);
+
+// NCHW fp32 latent -> NHWC bf16 padded to cpad channels.  `rep` copies of the batch are written back to
+// back (rep=2 builds the CFG batch cat([x, x])).  Optional affine pre-1x1 conv (VAE post_quant_conv):
+// y = Wpq * (x * in_scale) + bpq.
+hipError_t launch_pack_latent(const float* x, uint16_t* out, int B, int C, int HW, int cpad, int rep, float in_scale,
+                              const float* wpq, const float* bpq, hipStream_t s);
+
+// fp32 -> bf16 cast of a contiguous buffer (n elements, n % 2 == 0 not required)
+hipError_t launch_cast_bf16(const float* x, uint16_t* out, long n, hipStream_t s);
+
+// fp32 [rows][ld] (first C columns) -> bf16 [rows][C]
+hipError_t launch_cast_bf16_2d(const float* x, int ld, uint16_t* out, long rows, int C, hipStream_t s);
+
+// Weight re-pack on device: conv OIHW fp32 -> [O][kh][kw][Ipad] bf16 ; (Ipad >= I, zero filled)
+hipError_t launch_pack_conv_weight(const float* w, uint16_t* out, int O, int I, int KH, int KW, int Ipad, hipStream_t s);
+// GEGLU weight/bias interleave: rows [x(4C) ; gate(4C)] -> blocks of (32 x-rows | 32 gate-rows)
+hipError_t launch_pack_geglu(const float* w, const float* b, uint16_t* wout, float* bout, int half_rows, int K,
+                             hipStream_t s);
+
+// ---- sampler elementwise ops on fp32 latents -------------------------------------------------
+// e = e_u + scale * (e_c - e_u) for e2 = [e_u ; e_c] (each n elements)
+hipError_t launch_cfg_combine(const float* e2, float* e, long n, float scale, hipStream_t s);
+// out = sum_i coef[i] * in[i]   (up to 4 terms; out may alias any input)
+hipError_t launch_lincomb(float* out, const float* const* in, const float* coef, int nterms, long n, hipStream_t s);
+// DDIM update (ddim.py:258-272): pred_x0 = (x - s1m*e)/sqrt(a_t); x_prev = sqrt(a_prev)*pred_x0 + dir*e + sigma*noise
+hipError_t launch_ddim_update(const float* x, const float* e, const float* noise, float* x_prev, float* pred_x0,
+                              long n, float sqrt_at, float s1m, float sqrt_aprev, float dir_coef, float sigma,
+                              hipStream_t s);
+// mean over HW of NHWC fp32 [N][HW][C] -> [N][C]   (classifier head avg-pool)
+hipError_t launch_avgpool(const float* x, float* out, int N, int HW, int C, hipStream_t s);

@@ -1,0 +1,268 @@
+"""ctypes binding of libdfengine.so (C ABI: include/df_engine.h).
+
+PyTorch is used only as plumbing here: device memory (``tensor.data_ptr()``), the current HIP stream
+and dtype/shape bookkeeping.  There is NO fallback: if the shared library is missing or a call fails,
+a RuntimeError is raised -- results never come from a torch/CPU path.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfengine.so")
+
+
+class UNetConfig(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("model_channels", C.c_int),
+                ("num_res_blocks", C.c_int), ("channel_mult", C.c_int * 8), ("n_mult", C.c_int),
+                ("attention_resolutions", C.c_int * 8), ("n_attn", C.c_int), ("num_heads", C.c_int),
+                ("context_dim", C.c_int)]
+
+
+class VaeConfig(C.Structure):
+    _fields_ = [("z_channels", C.c_int), ("embed_dim", C.c_int), ("ch", C.c_int), ("num_res_blocks", C.c_int),
+                ("out_ch", C.c_int), ("ch_mult", C.c_int * 8), ("n_mult", C.c_int), ("scale_factor", C.c_float)]
+
+
+class CondConfig(C.Structure):
+    _fields_ = [("origin_dim", C.c_int), ("embed_dim", C.c_int), ("seq_len", C.c_int)]
+
+
+_lib = None
+
+_SIGS = {
+    "df_create": [C.c_int, C.POINTER(C.c_void_p)],
+    "df_config_unet": [C.c_void_p, C.POINTER(UNetConfig)],
+    "df_config_vae": [C.c_void_p, C.POINTER(VaeConfig)],
+    "df_config_cond": [C.c_void_p, C.POINTER(CondConfig)],
+    "df_config_classifier": [C.c_void_p, C.POINTER(UNetConfig)],
+    "df_load_tensor": [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int],
+    "df_load_tensor_dev": [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int],
+    "df_finalize": [C.c_void_p],
+    "df_autotune": [C.c_void_p, C.c_int],
+    "df_cond_encode": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "df_unet_set_context": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "df_unet_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "df_unet_forward_cfg": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                            C.c_void_p],
+    "df_vae_decode": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "df_classifier_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                              C.c_int, C.c_void_p],
+    "df_cfg_combine": [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p],
+    "df_lincomb": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_void_p],
+    "df_ddim_update": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                       C.c_float, C.c_float, C.c_void_p],
+    "df_unet_plan_stats": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "df_test_gemm": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "df_test_conv3x3": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p],
+    "df_test_groupnorm": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
+                          C.c_void_p, C.c_void_p],
+    "df_test_layernorm": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "df_test_attention": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
+}
+
+
+def lib():
+    """Load libdfengine.so (built in-tree by __graft_entry__.build / csrc/build.sh).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with diff-foley_amd/csrc/build.sh "
+                               "(there is no CPU/torch fallback for the sampling path)")
+        L = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        L.df_last_error.restype = C.c_char_p
+        L.df_destroy.argtypes = [C.c_void_p]
+        L.df_destroy.restype = None
+        L.df_abi_version.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGS.keys()) + ["df_last_error", "df_destroy", "df_abi_version"]
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RuntimeError("libdfengine: " + lib().df_last_error().decode())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t, device):
+    if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+    return t
+
+
+def _ilist(cls, n, vals):
+    a = (C.c_int * n)()
+    for i, v in enumerate(vals):
+        a[i] = int(v)
+    return a
+
+
+def unet_config(cfg):
+    u = UNetConfig()
+    u.in_channels, u.out_channels = cfg["in_channels"], cfg["out_channels"]
+    u.model_channels, u.num_res_blocks = cfg["model_channels"], cfg["num_res_blocks"]
+    u.channel_mult = _ilist(C.c_int, 8, cfg["channel_mult"])
+    u.n_mult = len(cfg["channel_mult"])
+    u.attention_resolutions = _ilist(C.c_int, 8, cfg["attention_resolutions"])
+    u.n_attn = len(cfg["attention_resolutions"])
+    u.num_heads, u.context_dim = cfg["num_heads"], cfg["context_dim"]
+    return u
+
+
+class Engine:
+    """One engine context per device per process (owns packed weights and plan workspaces)."""
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("diff_foley_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        h = C.c_void_p()
+        _chk(lib().df_create(self.device.index or 0, C.byref(h)))
+        self._h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().df_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- model definition
+    def config_unet(self, cfg):
+        _chk(lib().df_config_unet(self._h, C.byref(unet_config(cfg))))
+
+    def config_classifier(self, cfg):
+        _chk(lib().df_config_classifier(self._h, C.byref(unet_config(cfg))))
+
+    def config_vae(self, cfg, scale_factor):
+        v = VaeConfig()
+        v.z_channels, v.embed_dim, v.ch = cfg["z_channels"], cfg["embed_dim"], cfg["ch"]
+        v.num_res_blocks, v.out_ch = cfg["num_res_blocks"], cfg["out_ch"]
+        v.ch_mult = _ilist(C.c_int, 8, cfg["ch_mult"])
+        v.n_mult = len(cfg["ch_mult"])
+        v.scale_factor = float(scale_factor)
+        _chk(lib().df_config_vae(self._h, C.byref(v)))
+
+    def config_cond(self, cfg):
+        k = CondConfig(cfg["origin_dim"], cfg["embed_dim"], cfg["seq_len"])
+        _chk(lib().df_config_cond(self._h, C.byref(k)))
+
+    def load_tensor(self, name, t):
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        if t.is_cuda:
+            t = t.detach().to(torch.float32).contiguous()
+            _chk(lib().df_load_tensor_dev(self._h, name.encode(), _ptr(t), shape, t.dim()))
+        else:
+            t = t.detach().to(torch.float32).contiguous()
+            _chk(lib().df_load_tensor(self._h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()))
+
+    def finalize(self):
+        _chk(lib().df_finalize(self._h))
+
+    def autotune(self, enable=True):
+        _chk(lib().df_autotune(self._h, int(enable)))
+
+    # ---- network calls (all asynchronous on the current torch stream)
+    def cond_encode(self, feats):
+        feats = _dev_f32(feats, self.device)
+        B, T, _ = feats.shape
+        out = torch.empty(B, T, self.cond_embed_dim, device=self.device, dtype=torch.float32)
+        _chk(lib().df_cond_encode(self._h, _ptr(feats), _ptr(out), B, T, _stream()))
+        return out
+
+    def set_context(self, ctx):
+        ctx = _dev_f32(ctx, self.device)
+        N, T, _ = ctx.shape
+        _chk(lib().df_unet_set_context(self._h, _ptr(ctx), N, T, _stream()))
+
+    def unet_forward(self, x, t, out=None):
+        x = _dev_f32(x, self.device)
+        t = _dev_f32(t, self.device)
+        N, Cc, H, W = x.shape
+        if out is None:
+            out = torch.empty(N, self.unet_out_channels, H, W, device=self.device, dtype=torch.float32)
+        _chk(lib().df_unet_forward(self._h, _ptr(x), _ptr(t), _ptr(out), N, H, W, _stream()))
+        return out
+
+    def unet_forward_cfg(self, x, t, scale, out=None):
+        x = _dev_f32(x, self.device)
+        t = _dev_f32(t, self.device)
+        B, Cc, H, W = x.shape
+        if out is None:
+            out = torch.empty(B, self.unet_out_channels, H, W, device=self.device, dtype=torch.float32)
+        _chk(lib().df_unet_forward_cfg(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, float(scale), _stream()))
+        return out
+
+    def vae_decode(self, z):
+        z = _dev_f32(z, self.device)
+        B, Cc, H, W = z.shape
+        up = 2 ** (self.vae_n_mult - 1)
+        out = torch.empty(B, self.vae_out_ch, H * up, W * up, device=self.device, dtype=torch.float32)
+        _chk(lib().df_vae_decode(self._h, _ptr(z), _ptr(out), B, H, W, _stream()))
+        return out
+
+    def classifier_forward(self, x, t, feat):
+        x = _dev_f32(x, self.device)
+        t = _dev_f32(t, self.device)
+        feat = _dev_f32(feat, self.device)
+        B, Cc, H, W = x.shape
+        out = torch.empty(B, self.cls_out_channels, device=self.device, dtype=torch.float32)
+        _chk(lib().df_classifier_forward(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(out), B, H, W, feat.shape[1],
+                                         _stream()))
+        return out
+
+    def plan_stats(self):
+        n, f, w = C.c_int64(), C.c_double(), C.c_double()
+        _chk(lib().df_unet_plan_stats(self._h, C.byref(n), C.byref(f), C.byref(w)))
+        return dict(launches=n.value, gemm_flops=f.value, weight_bytes=w.value)
+
+
+# ---- sampler arithmetic (module-level: no ctx needed) --------------------------------------------------------
+def cfg_combine(e2, scale):
+    B = e2.shape[0] // 2
+    e = torch.empty((B,) + tuple(e2.shape[1:]), device=e2.device, dtype=torch.float32)
+    _chk(lib().df_cfg_combine(_ptr(e2), _ptr(e), e.numel(), float(scale), _stream()))
+    return e
+
+
+def lincomb(terms, out=None):
+    """out = sum(coef * tensor) over up to 4 (coef, tensor) pairs of identical shape (fp32, contiguous)."""
+    n = len(terms)
+    ts = [t.contiguous() for _, t in terms]
+    if out is None:
+        out = torch.empty_like(ts[0])
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    coefs = (C.c_float * n)(*[float(c) for c, _ in terms])
+    _chk(lib().df_lincomb(_ptr(out), ptrs, coefs, n, out.numel(), _stream()))
+    return out
+
+
+def ddim_update(x, e, a_t, a_prev, sigma_t, sqrt_one_minus_at, noise=None):
+    x_prev = torch.empty_like(x)
+    pred_x0 = torch.empty_like(x)
+    _chk(lib().df_ddim_update(_ptr(x), _ptr(e), _ptr(noise) if noise is not None else None, _ptr(x_prev),
+                              _ptr(pred_x0), x.numel(), float(a_t), float(a_prev), float(sigma_t),
+                              float(sqrt_one_minus_at), _stream()))
+    return x_prev, pred_x0

@@ -1,0 +1,278 @@
+"""Drop-in for the reference's ``LatentDiffusion`` on MI355X (sampling API only).
+
+``instantiate_from_config(config.model)`` of the reference notebook (inference/diff_foley_inference.ipynb:80-95,
+diff_foley/util.py:176-191) resolves ``target: diff_foley.models.diffusion.ddpm.LatentDiffusion``; pointing that
+target at :class:`LatentDiffusion` here keeps the rest of the notebook unchanged:
+
+    model = instantiate_from_config(cfg.model); model.load_state_dict(sd, strict=False); model.cuda(); model.eval()
+    c  = model.get_learned_conditioning(video_feat[:, :32])
+    z, _ = model.sample_log_diff_sampler(c, batch_size=4, sampler_name="DDIM", ddim_steps=25,
+                                         unconditional_guidance_scale=4.5, unconditional_conditioning=zeros_like(c))
+    mel = model.decode_first_stage(z)[:, 0]
+
+Method names, kwargs, return shapes/dtypes follow ddpm.py:568 (get_learned_conditioning), :739 (decode_first_stage),
+:925 (apply_model), :1252 (sample), :1270-1356 (sample_log*).  All compute runs in libdfengine.so (HIP); a missing
+library or a CPU-only host raises -- there is no fallback path.
+"""
+import importlib
+
+import torch
+
+from . import engine as E
+from . import samplers as S
+from .schedule import BUFFER_NAMES, register_schedule
+
+_UNET_KEYS = ("in_channels", "out_channels", "model_channels", "attention_resolutions", "num_res_blocks",
+              "channel_mult", "num_heads", "context_dim")
+
+
+def _params(cfg):
+    """Accept {'target':..., 'params': {...}} (YAML form) or the params dict itself."""
+    if cfg is None:
+        return None
+    cfg = dict(cfg)
+    return dict(cfg["params"]) if "params" in cfg else cfg
+
+
+def instantiate_from_config(config):
+    """diff_foley/util.py:176-191 semantics; reference ``target`` paths of the hot-path classes map to this package."""
+    target = config["target"]
+    alias = {
+        "diff_foley.models.diffusion.ddpm.LatentDiffusion": LatentDiffusion,
+        "diff_foley.modules.double_guidance.alignment_classifier.Alignment_Classifier_Double_Guidance": AlignmentClassifier,
+    }
+    if target in alias:
+        return alias[target](**dict(config.get("params", dict())))
+    module, cls = target.rsplit(".", 1)
+    return getattr(importlib.import_module(module), cls)(**dict(config.get("params", dict())))
+
+
+class _Unsupported:
+    def __init__(self, what):
+        self.what = what
+
+    def __getattr__(self, name):
+        raise AttributeError(f"{self.what}.{name}: module tree is not materialised in diff_foley_amd "
+                             "(weights live in packed HBM buffers owned by libdfengine.so)")
+
+
+class LatentDiffusion:
+    def __init__(self, first_stage_config=None, cond_stage_config=None, unet_config=None, linear_start=1e-4,
+                 linear_end=2e-2, timesteps=1000, beta_schedule="linear", channels=3, image_size=256,
+                 scale_factor=1.0, conditioning_key=None, parameterization="eps", log_every_t=100,
+                 v_posterior=0.0, use_ema=True, clip_denoised=True, **ignored):
+        if parameterization != "eps":
+            raise NotImplementedError("only eps-parameterisation is on the path")
+        if conditioning_key not in (None, "crossattn"):
+            raise NotImplementedError("only conditioning_key='crossattn' is on the path (Stage2_LDM.yaml:15)")
+        self.unet_cfg = {k: _params(unet_config)[k] for k in _UNET_KEYS}
+        for k in ("attention_resolutions", "channel_mult"):
+            self.unet_cfg[k] = [int(v) for v in self.unet_cfg[k]]
+        fs = _params(first_stage_config)
+        dd = dict(fs["ddconfig"])
+        self.vae_cfg = dict(z_channels=dd["z_channels"], embed_dim=fs["embed_dim"], ch=dd["ch"],
+                            ch_mult=[int(v) for v in dd["ch_mult"]], num_res_blocks=dd["num_res_blocks"],
+                            out_ch=dd["out_ch"])
+        self.cond_cfg = {k: _params(cond_stage_config)[k] for k in ("origin_dim", "embed_dim", "seq_len")}
+        self.channels = channels
+        self.image_size = image_size
+        self.scale_factor = scale_factor
+        self.parameterization = parameterization
+        self.log_every_t = log_every_t
+        self.clip_denoised = False            # LatentDiffusion overrides DDPM's default (ddpm.py:475)
+        self.conditioning_key = "crossattn"
+        self.num_timesteps = int(timesteps)
+        self.linear_start, self.linear_end = linear_start, linear_end
+        self._buffers = register_schedule(linear_start, linear_end, timesteps, v_posterior, beta_schedule)
+        for k, v in self._buffers.items():
+            setattr(self, k, v)
+        self.device = torch.device("cpu")
+        self.engine = None
+        self._state = None
+        self._ctx_owner = None
+        self.training = False
+        self.first_stage_model = _Unsupported("first_stage_model")
+        self.cond_stage_model = _Unsupported("cond_stage_model")
+        self.model = _Unsupported("model")
+
+    # ------------------------------------------------------------------ nn.Module-like plumbing
+    def load_state_dict(self, state_dict, strict=False):
+        need = ("model.diffusion_model.", "first_stage_model.post_quant_conv.", "first_stage_model.decoder.",
+                "cond_stage_model.")
+        self._state = {k: v for k, v in state_dict.items() if k.startswith(need)}
+        for k in BUFFER_NAMES:            # checkpoints carry the schedule buffers too
+            if k in state_dict:
+                setattr(self, k, state_dict[k].detach().float().cpu())
+        unexpected = [k for k in state_dict if not k.startswith(need) and k not in BUFFER_NAMES]
+        if strict and unexpected:
+            raise RuntimeError(f"unexpected keys: {unexpected[:5]} ...")
+        if self.engine is not None:
+            self._upload()
+        return [], unexpected
+
+    def _upload(self):
+        eng = self.engine
+        eng.config_unet(self.unet_cfg)
+        eng.config_vae(self.vae_cfg, self.scale_factor)
+        eng.config_cond(self.cond_cfg)
+        eng.cond_embed_dim = self.cond_cfg["embed_dim"]
+        eng.unet_out_channels = self.unet_cfg["out_channels"]
+        eng.vae_out_ch = self.vae_cfg["out_ch"]
+        eng.vae_n_mult = len(self.vae_cfg["ch_mult"])
+        for k, v in self._state.items():
+            eng.load_tensor(k, v)
+        eng.finalize()
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("diff_foley_amd.LatentDiffusion runs on a ROCm GPU only (no CPU path)")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(device)
+        self.device = device
+        self.engine = E.Engine(device)
+        for k in BUFFER_NAMES:
+            setattr(self, k, getattr(self, k).to(device))
+        if self._state is not None:
+            self._upload()
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def eval(self):
+        return self
+
+    def autotune(self, enable=True):
+        self._require().autotune(enable)
+        return self
+
+    def _require(self):
+        if self.engine is None or self._state is None:
+            raise RuntimeError("call load_state_dict(...) and .cuda() first")
+        return self.engine
+
+    def _cond_tensor(self, cond):
+        if isinstance(cond, dict):
+            cond = cond["c_crossattn"]
+        if isinstance(cond, (list, tuple)):
+            cond = torch.cat(list(cond), 1)
+        return cond
+
+    # ------------------------------------------------------------------ the path
+    @torch.no_grad()
+    def get_learned_conditioning(self, c):
+        return self._require().cond_encode(c)
+
+    @torch.no_grad()
+    def apply_model(self, x_noisy, t, cond, return_ids=False):
+        eng = self._require()
+        c = self._cond_tensor(cond)
+        if self._ctx_owner is not c:
+            eng.set_context(c)
+            self._ctx_owner = c
+        return eng.unet_forward(x_noisy, t)
+
+    @torch.no_grad()
+    def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):
+        if predict_cids:
+            raise NotImplementedError("VQ code-book decoding is not on the path (AutoencoderKL first stage)")
+        return self._require().vae_decode(z)
+
+    @torch.no_grad()
+    def sample(self, cond, batch_size=16, return_intermediates=False, x_T=None, verbose=True, timesteps=None,
+               quantize_denoised=False, mask=None, x0=None, shape=None, **kwargs):
+        self._require()
+        if shape is None:
+            shape = (batch_size, self.channels, self.image_size, self.image_size)
+        if cond is not None:
+            cond = self._cond_tensor(cond)[:batch_size]
+        return S.ancestral_sample(self, cond, tuple(shape), x_T=x_T, timesteps=timesteps,
+                                  return_intermediates=return_intermediates, noise_fn=kwargs.get("noise_fn"))
+
+    def _sampler(self, name):
+        return {"DDIM": S.DDIMSampler, "DPM_Solver": S.DPMSolverSampler, "PLMS": S.PLMSSampler}[name](self)
+
+    @torch.no_grad()
+    def sample_log(self, cond, batch_size, ddim, ddim_steps, size_len=64, unconditional_guidance_scale=1.0,
+                   unconditional_conditioning=None, **kwargs):
+        return self.sample_log_diff_sampler(cond, batch_size, "DDIM" if ddim else "DDPM", ddim_steps, size_len,
+                                            unconditional_guidance_scale, unconditional_conditioning, **kwargs)
+
+    @torch.no_grad()
+    def sample_log_diff_sampler(self, cond, batch_size, sampler_name, ddim_steps, size_len=64,
+                                unconditional_guidance_scale=1.0, unconditional_conditioning=None, **kwargs):
+        self._require()
+        if sampler_name in ("DDIM", "DPM_Solver", "PLMS"):
+            shape = (self.channels, 16, size_len)          # hard-coded latent height (ddpm.py:1293)
+            return self._sampler(sampler_name).sample(
+                ddim_steps, batch_size, shape, cond, verbose=False,
+                unconditional_guidance_scale=unconditional_guidance_scale,
+                unconditional_conditioning=unconditional_conditioning, **kwargs)
+        return self.sample(cond=cond, batch_size=batch_size, return_intermediates=True, **kwargs)
+
+    @torch.no_grad()
+    def sample_log_with_classifier(self, embed_cond, origin_cond, batch_size, ddim, ddim_steps, size_len=64,
+                                   unconditional_guidance_scale=1.0, unconditional_conditioning=None, classifier=None,
+                                   classifier_guide_scale=0.0, **kwargs):
+        return self.sample_log_with_classifier_diff_sampler(
+            embed_cond, origin_cond, batch_size, "DDIM" if ddim else "DDPM", ddim_steps, size_len,
+            unconditional_guidance_scale, unconditional_conditioning, classifier, classifier_guide_scale, **kwargs)
+
+    @torch.no_grad()
+    def sample_log_with_classifier_diff_sampler(self, embed_cond, origin_cond, batch_size, sampler_name="DDIM",
+                                                ddim_steps=250, size_len=64, unconditional_guidance_scale=1.0,
+                                                unconditional_conditioning=None, classifier=None,
+                                                classifier_guide_scale=0.0, **kwargs):
+        self._require()
+        if sampler_name in ("DDIM", "DPM_Solver"):
+            shape = (self.channels, 16, size_len)
+            return self._sampler(sampler_name).sample_with_classifier(
+                ddim_steps, batch_size, shape, embed_cond, origin_cond=origin_cond, verbose=False,
+                unconditional_guidance_scale=unconditional_guidance_scale,
+                unconditional_conditioning=unconditional_conditioning, classifier=classifier,
+                classifier_guide_scale=classifier_guide_scale, **kwargs)
+        return self.sample(cond=embed_cond, batch_size=batch_size, return_intermediates=True, **kwargs)
+
+
+class AlignmentClassifier:
+    """Alignment_Classifier_Double_Guidance.forward (alignment_classifier.py:269-271): prob = sigmoid(head(backbone)).
+
+    Shares the engine of the LatentDiffusion it guides (``attach``).  ``log_prob_grad`` (the input gradient that
+    double guidance needs, ddim.py:333-341) is not implemented natively yet -- see DESIGN.md 'next'."""
+
+    def __init__(self, classifier_config=None, **ignored):
+        cfg = _params(classifier_config)
+        self.cfg = {k: cfg[k] for k in _UNET_KEYS}
+        for k in ("attention_resolutions", "channel_mult"):
+            self.cfg[k] = [int(v) for v in self.cfg[k]]
+        self._state = None
+        self.engine = None
+
+    def load_state_dict(self, state_dict, strict=False):
+        self._state = {k: v for k, v in state_dict.items() if k.startswith("model.")}
+        return [], []
+
+    def attach(self, ldm):
+        self.engine = ldm._require()
+        self.engine.config_classifier(self.cfg)
+        self.engine.cls_out_channels = self.cfg["out_channels"]
+        for k, v in self._state.items():
+            self.engine.load_tensor("classifier." + k, v)
+        self.engine.finalize()
+        return self
+
+    def cuda(self):
+        return self
+
+    def eval(self):
+        return self
+
+    @torch.no_grad()
+    def __call__(self, x, t, video_feat):
+        if self.engine is None:
+            raise RuntimeError("AlignmentClassifier.attach(ldm) first")
+        return self.engine.classifier_forward(x, t, video_feat)
+
+    forward = __call__

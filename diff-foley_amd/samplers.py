@@ -1,0 +1,265 @@
+"""Sampler host loops of the MI355X path: DDIM, DPM-Solver++(2M), PLMS, ancestral DDPM.
+
+Same call surface as the reference sampler classes (``DDIMSampler(model).sample(S, batch_size, shape,
+conditioning, ...) -> (samples, intermediates)``), but every tensor operation in the loop is a HIP
+kernel behind the C ABI: the CFG UNet evaluation (``df_unet_forward_cfg``: batch duplication, UNet,
+guidance combine) and the solver updates (``df_ddim_update`` / ``df_lincomb``).  The cross-attention
+context is handed to the engine once per ``sample()`` (it is step-invariant), so the K/V projections
+of the 16 SpatialTransformers leave the step loop.  torch is used for RNG (x_T, eta noise) only.
+
+Reference: diff_foley/models/diffusion/ddim.py:58-273, plms.py:60-236,
+dpm_solver/sampler.py:24-156 + dpm_solver/dpm_solver.py:504-549,755-810,1071-1105, ddpm.py:1083-1268.
+"""
+import numpy as np
+import torch
+
+from . import engine as E
+from .schedule import DDIMTables, DPMTables
+
+
+def _warn_batch(conditioning, batch_size):
+    if conditioning is not None:
+        c = conditioning[list(conditioning.keys())[0]] if isinstance(conditioning, dict) else conditioning
+        if isinstance(c, (list, tuple)):
+            c = c[0]
+        if c.shape[0] != batch_size:
+            print(f"Warning: Got {c.shape[0]} conditionings but batch-size is {batch_size}")
+
+
+class _Guided:
+    """eps(x, t) with classifier-free guidance; owns the engine context for the duration of a sample()."""
+
+    def __init__(self, model, cond, scale, uc):
+        self.m = model
+        self.eng = model.engine
+        self.cfg = not (uc is None or scale == 1.0)
+        self.scale = float(scale)
+        cond = model._cond_tensor(cond)
+        if self.cfg:
+            self.eng.set_context(torch.cat([model._cond_tensor(uc), cond]))
+        else:
+            self.eng.set_context(cond)
+        model._ctx_owner = None          # invalidate apply_model's cached context
+
+    def __call__(self, x, t):
+        if self.cfg:
+            return self.eng.unet_forward_cfg(x, t, self.scale)
+        return self.eng.unet_forward(x, t)
+
+
+def _classifier_grad(model, classifier, x, t, origin_cond):
+    if not hasattr(classifier, "log_prob_grad"):
+        raise RuntimeError("classifier guidance needs a diff_foley_amd AlignmentClassifier (log_prob_grad)")
+    return classifier.log_prob_grad(x, t, origin_cond)
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0.0, verbose=True):
+        if ddim_discretize != "uniform":
+            raise NotImplementedError("only the 'uniform' DDIM discretisation is on the path")
+        self.tables = DDIMTables(self.model.alphas_cumprod, ddim_num_steps, ddim_eta)
+        self.ddim_timesteps = self.tables.timesteps
+        self.ddim_alphas = self.tables.alphas
+        self.ddim_alphas_prev = self.tables.alphas_prev
+        self.ddim_sigmas = self.tables.sigmas
+        self.ddim_sqrt_one_minus_alphas = self.tables.sqrt_one_minus_alphas
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, eta=0.0, x_T=None, log_every_t=100,
+               unconditional_guidance_scale=1.0, unconditional_conditioning=None, temperature=1.0,
+               verbose=True, callback=None, img_callback=None, classifier=None, origin_cond=None,
+               classifier_guide_scale=0.0, **kwargs):
+        _warn_batch(conditioning, batch_size)
+        self.make_schedule(S, ddim_eta=eta, verbose=verbose)
+        dev = self.model.device
+        C, H, W = shape
+        size = (batch_size, C, H, W)
+        img = torch.randn(size, device=dev) if x_T is None else x_T.to(dev, torch.float32).contiguous()
+        eps_fn = _Guided(self.model, conditioning, unconditional_guidance_scale, unconditional_conditioning)
+        tb = self.tables
+        steps = np.flip(tb.timesteps)
+        total = steps.shape[0]
+        t_all = torch.tensor(steps.copy(), dtype=torch.float32, device=dev)[:, None].expand(total, batch_size).contiguous()
+        inter = {"x_inter": [img], "pred_x0": [img]}
+        for i in range(total):
+            index = total - i - 1
+            e_t = eps_fn(img, t_all[i])
+            a_t, a_prev = tb.alphas[index], tb.alphas_prev[index]
+            if classifier is not None:       # ddim.py:374-380
+                g = _classifier_grad(self.model, classifier, img, t_all[i], origin_cond)
+                e_t = E.lincomb([(1.0, e_t), (-np.sqrt(np.float32(1.0) - a_t) * classifier_guide_scale, g)])
+            sigma = tb.sigmas[index]
+            noise = None
+            if sigma != 0.0:
+                noise = torch.randn(size, device=dev) * temperature
+            img, pred_x0 = E.ddim_update(img, e_t, a_t, a_prev, sigma, tb.sqrt_one_minus_alphas[index], noise)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total - 1:
+                inter["x_inter"].append(img)
+                inter["pred_x0"].append(pred_x0)
+        return img, inter
+
+    def sample_with_classifier(self, S, batch_size, shape, conditioning=None, origin_cond=None, classifier=None,
+                               classifier_guide_scale=0.0, **kwargs):
+        return self.sample(S, batch_size, shape, conditioning, origin_cond=origin_cond, classifier=classifier,
+                           classifier_guide_scale=classifier_guide_scale, **kwargs)
+
+
+class PLMSSampler(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, eta=0.0, x_T=None, log_every_t=100,
+               unconditional_guidance_scale=1.0, unconditional_conditioning=None, verbose=True, callback=None,
+               img_callback=None, **kwargs):
+        if eta != 0:
+            raise ValueError("ddim_eta must be 0 for PLMS")
+        _warn_batch(conditioning, batch_size)
+        tb = DDIMTables(self.model.alphas_cumprod, S, 0.0)
+        dev = self.model.device
+        C, H, W = shape
+        size = (batch_size, C, H, W)
+        img = torch.randn(size, device=dev) if x_T is None else x_T.to(dev, torch.float32).contiguous()
+        eps_fn = _Guided(self.model, conditioning, unconditional_guidance_scale, unconditional_conditioning)
+        steps = np.flip(tb.timesteps)
+        total = steps.shape[0]
+        t_all = torch.tensor(steps.copy(), dtype=torch.float32, device=dev)[:, None].expand(total, batch_size).contiguous()
+        inter = {"x_inter": [img], "pred_x0": [img]}
+        old_eps = []
+        for i in range(total):
+            index = total - i - 1
+            upd = lambda x, e: E.ddim_update(x, e, tb.alphas[index], tb.alphas_prev[index], 0.0,
+                                             tb.sqrt_one_minus_alphas[index], None)
+            e_t = eps_fn(img, t_all[i])
+            if len(old_eps) == 0:          # pseudo improved Euler (plms.py:219-223)
+                x_prev, _ = upd(img, e_t)
+                e_next = eps_fn(x_prev, t_all[min(i + 1, total - 1)])
+                e_p = E.lincomb([(0.5, e_t), (0.5, e_next)])
+            elif len(old_eps) == 1:
+                e_p = E.lincomb([(1.5, e_t), (-0.5, old_eps[-1])])
+            elif len(old_eps) == 2:
+                e_p = E.lincomb([(23 / 12, e_t), (-16 / 12, old_eps[-1]), (5 / 12, old_eps[-2])])
+            else:
+                e_p = E.lincomb([(55 / 24, e_t), (-59 / 24, old_eps[-1]), (37 / 24, old_eps[-2]), (-9 / 24, old_eps[-3])])
+            img, pred_x0 = upd(img, e_p)
+            old_eps.append(e_t)
+            if len(old_eps) >= 4:
+                old_eps.pop(0)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total - 1:
+                inter["x_inter"].append(img)
+                inter["pred_x0"].append(pred_x0)
+        return img, inter
+
+
+class DPMSolverSampler(object):
+    """DPM-Solver++(2M): multistep, order 2, time_uniform, predict_x0, lower_order_final (only if S < 15)."""
+
+    def __init__(self, model, **kwargs):
+        self.model = model
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, x_T=None, unconditional_guidance_scale=1.0,
+               unconditional_conditioning=None, classifier=None, origin_cond=None, classifier_guide_scale=0.0,
+               **kwargs):
+        _warn_batch(conditioning, batch_size)
+        dev = self.model.device
+        C, H, W = shape
+        size = (batch_size, C, H, W)
+        x = torch.randn(size, device=dev) if x_T is None else x_T.to(dev, torch.float32).contiguous()
+        ns = DPMTables(self.model.alphas_cumprod)
+        eps_fn = _Guided(self.model, conditioning, unconditional_guidance_scale, unconditional_conditioning)
+        ts = ns.time_steps(S)
+        t_in_all = torch.tensor([ns.model_time(t) for t in ts], dtype=torch.float32, device=dev)[:, None] \
+            .expand(S + 1, batch_size).contiguous()
+
+        def model_fn(x, k):          # data prediction x0 = (x - sigma*eps)/alpha   (dpm_solver.py:386-393)
+            t = ts[k]
+            noise = eps_fn(x, t_in_all[k])
+            if classifier is not None and eps_fn.cfg:      # double guidance (dpm_solver.py:1377-1393)
+                g = _classifier_grad(self.model, classifier, x, t_in_all[k], origin_cond)
+                noise = E.lincomb([(1.0, noise), (-classifier_guide_scale * ns.sigma(t), g)])
+            a, s = ns.alpha(t), ns.sigma(t)
+            return E.lincomb([(1.0 / a, x), (-s / a, noise)])
+
+        def first_update(x, s, t, m_s):
+            h = ns.lam(t) - ns.lam(s)
+            return E.lincomb([(ns.sigma(t) / ns.sigma(s), x), (-ns.alpha(t) * np.expm1(-h), m_s)])
+
+        def second_update(x, m1, m0, t1, t0, t):
+            l1, l0, lt = ns.lam(t1), ns.lam(t0), ns.lam(t)
+            h0, h = l0 - l1, lt - l0
+            r0 = h0 / h
+            k = ns.alpha(t) * (np.exp(-h) - np.float32(1.0))
+            # x_t = sig_t/sig_0 x - k m0 - 0.5 k (m0 - m1)/r0
+            return E.lincomb([(ns.sigma(t) / ns.sigma(t0), x), (-k - 0.5 * k / r0, m0), (0.5 * k / r0, m1)])
+
+        m_prev = [model_fn(x, 0)]
+        t_prev = [ts[0]]
+        x = first_update(x, ts[0], ts[1], m_prev[-1])
+        m_prev.append(model_fn(x, 1))
+        t_prev.append(ts[1])
+        for step in range(2, S + 1):
+            order = min(2, S + 1 - step) if S < 15 else 2
+            if order == 1:
+                x = first_update(x, t_prev[-1], ts[step], m_prev[-1])
+            else:
+                x = second_update(x, m_prev[0], m_prev[1], t_prev[0], t_prev[1], ts[step])
+            t_prev[0], m_prev[0] = t_prev[1], m_prev[1]
+            t_prev[1] = ts[step]
+            if step < S:
+                m_prev[1] = model_fn(x, step)
+        return x, None
+
+    def sample_with_classifier(self, S, batch_size, shape, conditioning=None, origin_cond=None, classifier=None,
+                               classifier_guide_scale=0.0, **kwargs):
+        return self.sample(S, batch_size, shape, conditioning, origin_cond=origin_cond, classifier=classifier,
+                           classifier_guide_scale=classifier_guide_scale, **kwargs)
+
+
+@torch.no_grad()
+def ancestral_sample(model, cond, shape, x_T=None, timesteps=None, log_every_t=None, return_intermediates=False,
+                     noise_fn=None, callback=None, img_callback=None):
+    """LatentDiffusion.p_sample_loop (ddpm.py:1201-1250): 1000-step ancestral sampling, no CFG, clip_denoised False."""
+    dev = model.device
+    img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32).contiguous()
+    b = shape[0]
+    T = model.num_timesteps if timesteps is None else timesteps
+    log_every_t = log_every_t or model.log_every_t
+    eps_fn = _Guided(model, cond, 1.0, None)
+    tab = {k: getattr(model, k).cpu().numpy() for k in ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                                                        "posterior_mean_coef1", "posterior_mean_coef2",
+                                                        "posterior_log_variance_clipped")}
+    inter = [img]
+    for i in reversed(range(0, T)):
+        ts = torch.full((b,), float(i), device=dev, dtype=torch.float32)
+        eps = eps_fn(img, ts)
+        # x_recon = c_r x - c_m eps ; mean = c1 x_recon + c2 x   (ddpm.py:221-234)
+        cr, cm = tab["sqrt_recip_alphas_cumprod"][i], tab["sqrt_recipm1_alphas_cumprod"][i]
+        c1, c2 = tab["posterior_mean_coef1"][i], tab["posterior_mean_coef2"][i]
+        terms = [(c1 * cr + c2, img), (-c1 * cm, eps)]
+        # noise is drawn at every step (also t == 0, where it is masked) like noise_like() in ddpm.py:1132
+        noise = noise_fn(shape).to(dev) if noise_fn is not None else torch.randn(shape, device=dev)
+        if i != 0:
+            terms.append((np.exp(0.5 * tab["posterior_log_variance_clipped"][i]), noise))
+        img = E.lincomb(terms)
+        if i % log_every_t == 0 or i == T - 1:
+            inter.append(img)
+        if callback:
+            callback(i)
+        if img_callback:
+            img_callback(img, i)
+    return (img, inter) if return_intermediates else img

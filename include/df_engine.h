@@ -1,0 +1,132 @@
+/* df_engine.h -- C ABI of libdfengine.so, the MI355X (gfx950) engine behind the Diff-Foley
+ * Stage-2 sampling path.
+ *
+ * The reference (luosiallen/Diff-Foley) has NO FFI/plugin boundary: the hot path is a tree of
+ * torch.nn modules driven from Python.  Each entry point below replaces one Python-level call
+ * of the reference; the reference-side binding a maintainer would add is the ctypes stub shown
+ * in INTEGRATION.md (and implemented in diff-foley_amd/engine.py).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; df_last_error() gives the message
+ *     (thread-local); nothing throws across the ABI.
+ *   - "dev" pointers are device pointers (torch tensor.data_ptr()); the caller owns every I/O buffer,
+ *     the library owns packed weights and workspaces for the lifetime of the ctx.
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no internal
+ *     synchronisation except in df_load_tensor / df_finalize / df_autotune.
+ *   - latents are NCHW fp32 exactly as the reference passes them; internal layout is NHWC.
+ *   - one ctx per device per process; a ctx is not re-entrant.
+ */
+#ifndef DF_ENGINE_H
+#define DF_ENGINE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct df_ctx df_ctx;
+
+/* UNetModel / Classifier_Backbone hyper-parameters
+ * (diff_foley/modules/diffusionmodules/openai_unetmodel.py:443-468, inference/config/Stage2_LDM.yaml:21-36,
+ *  inference/config/Double_Guidance_Classifier.yaml:35-50). */
+typedef struct {
+  int in_channels, out_channels, model_channels, num_res_blocks;
+  int channel_mult[8];
+  int n_mult;
+  int attention_resolutions[8];
+  int n_attn;
+  int num_heads;
+  int context_dim;
+} df_unet_config;
+
+/* AutoencoderKL decoder ddconfig (Stage2_LDM.yaml:38-59) + LatentDiffusion.scale_factor (:17). */
+typedef struct {
+  int z_channels, embed_dim, ch, num_res_blocks, out_ch;
+  int ch_mult[8];
+  int n_mult;
+  float scale_factor;
+} df_vae_config;
+
+/* Video_Feat_Encoder_Posembed (Stage2_LDM.yaml:62-67). */
+typedef struct {
+  int origin_dim, embed_dim, seq_len;
+} df_cond_config;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int df_create(int device, df_ctx** out);
+void df_destroy(df_ctx* ctx);
+const char* df_last_error(void);
+int df_abi_version(void);
+
+/* ---- model definition: replaces instantiate_from_config(config.model) + load_state_dict()
+ *      (inference/diff_foley_inference.ipynb:80-95; diff_foley/util.py:176-191).
+ * `name` is the reference state_dict key (e.g. "model.diffusion_model.input_blocks.1.0.in_layers.2.weight");
+ * classifier tensors are loaded under the prefix "classifier." + their own key ("classifier.model....").
+ * `host` is fp32, C-contiguous; it is copied before the call returns. */
+int df_config_unet(df_ctx* ctx, const df_unet_config* cfg);
+int df_config_vae(df_ctx* ctx, const df_vae_config* cfg);
+int df_config_cond(df_ctx* ctx, const df_cond_config* cfg);
+int df_config_classifier(df_ctx* ctx, const df_unet_config* cfg);
+int df_load_tensor(df_ctx* ctx, const char* name, const float* host, const int64_t* shape, int ndim);
+/* Same, but the fp32 source already lives on the device (used after an RCCL weight broadcast). */
+int df_load_tensor_dev(df_ctx* ctx, const char* name, const float* dev, const int64_t* shape, int ndim);
+/* Checks every tensor the configured modules need is present and re-packs to bf16 MFMA layouts. */
+int df_finalize(df_ctx* ctx);
+/* Optional: time the candidate tile shapes of every GEMM of the plans built so far and keep the fastest. */
+int df_autotune(df_ctx* ctx, int enable);
+
+/* ---- LatentDiffusion.get_learned_conditioning (ddpm.py:568-579 -> video_feat_encoder.py:12-18)
+ * feats [B][T][origin_dim] fp32 -> out [B][T][embed_dim] fp32 */
+int df_cond_encode(df_ctx* ctx, const float* feats_dev, float* out_dev, int B, int T, void* stream);
+
+/* ---- UNetModel.forward (openai_unetmodel.py:710-742) through LatentDiffusion.apply_model (ddpm.py:925-1026).
+ * The cross-attention context is step-invariant, so it is set once per sample() call: K/V projections of
+ * all 16 SpatialTransformers are computed here, not per step.  context [N][T][context_dim] fp32. */
+int df_unet_set_context(df_ctx* ctx, const float* context_dev, int N, int T, void* stream);
+/* x [N][C][H][W] fp32, t [N] fp32 (integer or fractional timesteps), eps_out [N][C][H][W] fp32. */
+int df_unet_forward(df_ctx* ctx, const float* x_dev, const float* t_dev, float* eps_out_dev, int N, int H, int W,
+                    void* stream);
+/* Classifier-free-guidance step of p_sample_ddim (ddim.py:241-245): runs the UNet on cat([x,x]) against the
+ * 2B-row context set before ([uncond ; cond]) and returns e_u + scale*(e_c - e_u).  x, t, eps: B rows. */
+int df_unet_forward_cfg(df_ctx* ctx, const float* x_dev, const float* t_dev, float* eps_out_dev, int B, int H, int W,
+                        float guidance_scale, void* stream);
+
+/* ---- LatentDiffusion.decode_first_stage (ddpm.py:739-797 -> autoencoder.py:330-333 -> model.py:630-663)
+ * z [B][z_channels][H][W] fp32 -> out [B][out_ch][H*2^(n_mult-1)][W*2^(n_mult-1)] fp32 */
+int df_vae_decode(df_ctx* ctx, const float* z_dev, float* out_dev, int B, int H, int W, void* stream);
+
+/* ---- Alignment classifier forward (alignment_classifier.py:269-271 -> alignment_backbone.py:656-686)
+ * x [B][C][H][W], t [B], video_feat [B][T][context_dim] (raw CAVP features) -> prob [B][out_channels] */
+int df_classifier_forward(df_ctx* ctx, const float* x_dev, const float* t_dev, const float* feat_dev, float* prob_dev,
+                          int B, int H, int W, int T, void* stream);
+
+/* ---- sampler arithmetic on fp32 latents (n = number of elements) -------------------------------
+ * e = e_u + scale*(e_c - e_u), e2 = [e_u ; e_c]                     (ddim.py:245, dpm_solver.py:1386) */
+int df_cfg_combine(const float* e2_dev, float* e_dev, int64_t n, float scale, void* stream);
+/* out = sum_i coef[i]*in[i], 1..4 terms; out may alias an input  (DPM-Solver++ updates dpm_solver.py:504-549,
+ * 755-810; PLMS multistep plms.py:219-232; classifier guidance ddim.py:380) */
+int df_lincomb(float* out_dev, const float* const* in_dev, const float* coef, int nterms, int64_t n, void* stream);
+/* DDIM update (ddim.py:258-272).  noise may be NULL (eta = 0). */
+int df_ddim_update(const float* x_dev, const float* e_dev, const float* noise_dev, float* x_prev_dev,
+                   float* pred_x0_dev, int64_t n, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at,
+                   void* stream);
+
+/* ---- introspection for bench.py / tests --------------------------------------------------------- */
+/* Number of kernel launches of the last UNet plan executed and its algorithmic GEMM FLOPs. */
+int df_unet_plan_stats(df_ctx* ctx, int64_t* n_launches, double* gemm_flops, double* weight_bytes);
+/* Run ONE op family in isolation for unit tests (see tests/test_kernels_gpu.py). */
+int df_test_gemm(const uint16_t* A_dev, const uint16_t* W_dev, float* C_dev, int M, int N, int K, int tile, int splitk,
+                 void* stream);
+int df_test_conv3x3(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, float* C_dev, int NB, int H,
+                    int W, int Cin, int Cout, int stride, int ups, int tile, int splitk, void* stream);
+int df_test_groupnorm(const float* x_dev, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,
+                      int silu, uint16_t* out_dev, void* stream);
+int df_test_layernorm(const float* x_dev, int rows, int C, const float* gamma, const float* beta, uint16_t* out_dev,
+                      void* stream);
+int df_test_attention(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt, uint16_t* O,
+                      int ldo, int N, int heads, int D, int Tq, int Tk, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DF_ENGINE_H */

@@ -1,0 +1,162 @@
+"""GPU: each HIP kernel family through the C ABI against a plain PyTorch fp32 reference of the same op
+(operands rounded to bf16 first, so the only difference is fp32 accumulation order): tolerance 2e-3 relative."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rnd, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng():
+    from diff_foley_amd import engine as E
+    return E
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+TILES = [0, 1, 2, 3, 4]
+
+
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("M,N,K,splitk", [(256, 320, 640, 1), (100, 70, 128, 1), (128, 1280, 2560, 4), (32, 96, 512, 2)])
+def test_gemm(tile, M, N, K, splitk):
+    E = _eng()
+    a = bf(rnd((M, K), 1)).cuda()
+    w = bf(rnd((N, K), 2)).cuda()
+    c = torch.full((M, N), float("nan"), device="cuda")
+    rc = E.lib().df_test_gemm(ptr(a), ptr(w), ptr(c), M, N, K, tile, splitk, stream())
+    assert rc == 0, E.lib().df_last_error()
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().t()
+    assert torch.isfinite(c).all()
+    assert rel_l2(c.cpu(), ref.cpu()) < 2e-3
+
+
+@pytest.mark.parametrize("tile", [0, 1, 3])
+@pytest.mark.parametrize("NB,H,W,Cin,Cout,stride,ups,splitk", [
+    (2, 16, 64, 64, 64, 1, 0, 1), (2, 8, 32, 128, 192, 1, 0, 1), (1, 16, 64, 64, 64, 2, 0, 1),
+    (2, 4, 16, 128, 64, 1, 1, 1), (2, 2, 8, 256, 320, 1, 0, 4), (3, 8, 16, 64, 4, 1, 0, 1)])
+def test_conv3x3(tile, NB, H, W, Cin, Cout, stride, ups, splitk):
+    E = _eng()
+    x = bf(rnd((NB, Cin, H, W), 3))
+    w = bf(rnd((Cout, Cin, 3, 3), 4) / (3 * Cin ** 0.5))
+    b = rnd((Cout,), 5)
+    xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.float(), b, stride=stride, padding=1)
+    a = x.permute(0, 2, 3, 1).contiguous().cuda()                       # NHWC bf16
+    wp = w.permute(0, 2, 3, 1).contiguous().cuda()                      # [O][ky][kx][I]
+    OH, OW = ref.shape[2], ref.shape[3]
+    c = torch.full((NB * OH * OW, Cout), float("nan"), device="cuda")
+    bc = b.cuda()
+    rc = E.lib().df_test_conv3x3(ptr(a), ptr(wp), ptr(bc), ptr(c), NB, H, W, Cin, Cout, stride, ups, tile, splitk,
+                                 stream())
+    assert rc == 0, E.lib().df_last_error()
+    torch.cuda.synchronize()
+    got = c.cpu().reshape(NB, OH, OW, Cout).permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < 2e-3
+
+
+@pytest.mark.parametrize("N,HW,C,silu,eps", [(2, 1024, 320, 1, 1e-5), (3, 128, 64, 0, 1e-6), (1, 512, 960, 1, 1e-5),
+                                             (1, 65536, 128, 1, 1e-6)])
+def test_groupnorm(N, HW, C, silu, eps):
+    E = _eng()
+    x = rnd((N, C, HW), 6) * 2 + 0.5
+    g, b = rnd((C,), 7), rnd((C,), 8)
+    ref = F.group_norm(x, 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    xin = x.permute(0, 2, 1).contiguous().cuda()
+    out = torch.empty(N, HW, C, dtype=torch.bfloat16, device="cuda")
+    gc, bc = g.cuda(), b.cuda()
+    rc = E.lib().df_test_groupnorm(ptr(xin), C, N, HW, C, ptr(gc), ptr(bc), eps, silu, ptr(out), stream())
+    assert rc == 0, E.lib().df_last_error()
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu().permute(0, 2, 1), ref) < 4e-3     # bf16 output rounding
+
+
+@pytest.mark.parametrize("rows,C", [(1024, 320), (77, 640), (16, 1280), (128, 64)])
+def test_layernorm(rows, C):
+    E = _eng()
+    x = rnd((rows, C), 9) * 3 - 1
+    g, b = rnd((C,), 10), rnd((C,), 11)
+    ref = F.layer_norm(x, (C,), g, b, 1e-5)
+    xc, gc, bc = x.cuda(), g.cuda(), b.cuda()
+    out = torch.empty(rows, C, dtype=torch.bfloat16, device="cuda")
+    rc = E.lib().df_test_layernorm(ptr(xc), rows, C, ptr(gc), ptr(bc), ptr(out), stream())
+    assert rc == 0, E.lib().df_last_error()
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("N,heads,D,Tq,Tk", [(2, 8, 40, 1024, 1024), (2, 8, 80, 256, 256), (1, 8, 160, 64, 64),
+                                             (2, 8, 160, 16, 16), (2, 8, 40, 1024, 32), (2, 8, 32, 128, 33),
+                                             (1, 2, 64, 256, 256), (1, 2, 128, 64, 32), (1, 8, 80, 256, 32)])
+def test_attention(N, heads, D, Tq, Tk):
+    E = _eng()
+    C_ = heads * D
+    q = bf(rnd((N, Tq, C_), 12))
+    k = bf(rnd((N, Tk, C_), 13))
+    v = bf(rnd((N, Tk, C_), 14))
+    scale = D ** -0.5
+    sp = lambda t, T: t.float().reshape(N, T, heads, D).permute(0, 2, 1, 3)
+    att = torch.softmax(sp(q, Tq) @ sp(k, Tk).transpose(-1, -2) * scale, dim=-1)
+    ref = (att @ sp(v, Tk)).permute(0, 2, 1, 3).reshape(N, Tq, C_)
+    ldvt = (Tk + 31) // 32 * 32
+    vt = torch.full((N, C_, ldvt), float("nan"), dtype=torch.bfloat16)      # padding deliberately poisoned
+    vt[:, :, :Tk] = v.permute(0, 2, 1)
+    qc, kc, vc = q.cuda(), k.cuda(), vt.cuda()
+    o = torch.empty(N, Tq, C_, dtype=torch.bfloat16, device="cuda")
+    rc = E.lib().df_test_attention(ptr(qc), C_, ptr(kc), C_, ptr(vc), ldvt, ptr(o), C_, N, heads, D, Tq, Tk, scale,
+                                   stream())
+    assert rc == 0, E.lib().df_last_error()
+    torch.cuda.synchronize()
+    assert torch.isfinite(o.float()).all()
+    assert rel_l2(o.float().cpu(), ref) < 1e-2      # P and O are rounded to bf16 inside the kernel
+
+
+def test_attention_online_softmax_rescale():
+    """Force the running-max update: one key far above the rest in a late tile (guide rule 26)."""
+    E = _eng()
+    N, heads, D, T = 1, 1, 64, 256
+    q = bf(rnd((N, T, D), 20))
+    k = bf(rnd((N, T, D), 21) * 0.1)
+    k[0, 200] = q[0, 5] * 4            # spike for query 5 in the 7th key tile
+    v = bf(rnd((N, T, D), 22))
+    scale = D ** -0.5
+    att = torch.softmax(q.float() @ k.float().transpose(-1, -2) * scale, dim=-1)
+    ref = att @ v.float()
+    vt = v.permute(0, 2, 1).contiguous()
+    qc, kc, vc = q.cuda(), k.cuda(), vt.cuda()
+    o = torch.empty(N, T, D, dtype=torch.bfloat16, device="cuda")
+    rc = E.lib().df_test_attention(ptr(qc), D, ptr(kc), D, ptr(vc), T, ptr(o), D, N, heads, D, T, T, scale, stream())
+    assert rc == 0, E.lib().df_last_error()
+    torch.cuda.synchronize()
+    assert rel_l2(o.float().cpu(), ref) < 1e-2
+
+
+def test_sampler_arithmetic():
+    E = _eng()
+    x, e, e2 = rnd((4, 4, 16, 64), 30).cuda(), rnd((4, 4, 16, 64), 31).cuda(), rnd((8, 4, 16, 64), 32).cuda()
+    c = E.cfg_combine(e2, 4.5)
+    assert torch.allclose(c, e2[:4] + 4.5 * (e2[4:] - e2[:4]), atol=1e-6)
+    l = E.lincomb([(0.3, x), (-1.7, e), (2.0, c)])
+    assert torch.allclose(l, 0.3 * x - 1.7 * e + 2.0 * c, atol=1e-5)
+    a_t, a_prev, s1m = 0.5, 0.7, (1 - 0.5) ** 0.5
+    xp, p0 = E.ddim_update(x, e, a_t, a_prev, 0.0, s1m)
+    ref0 = (x - s1m * e) / a_t ** 0.5
+    assert torch.allclose(p0, ref0, atol=1e-5)
+    assert torch.allclose(xp, a_prev ** 0.5 * ref0 + (1 - a_prev) ** 0.5 * e, atol=1e-5)

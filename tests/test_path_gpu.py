@@ -1,0 +1,266 @@
+"""GPU parity tests of the hot path through the C ABI (LatentDiffusion facade -> libdfengine.so) against
+(i) the CPU oracle on the same seeded inputs and (ii) the golden vectors produced by the reference itself.
+
+Tolerances (bf16 MFMA operands, fp32 accumulation / statistics / residual stream; oracle and reference are fp32):
+  * one UNet / VAE forward:         rel-L2 <= 2e-2  (measured ~5e-3)
+  * short sampler trajectories:     rel-L2 <= 5e-2
+  * decoded mel, north-star metric: MAE reported and bounded (see test_full_ddim25_mel_mae)
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (gold, rnd, rel_l2, tiny_state_dict, full_state_dict, tiny_classifier_sd, full_classifier_sd)
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 2e-2
+TRAJ_TOL = 5e-2
+
+
+@pytest.fixture(scope="module")
+def P():
+    import diff_foley_amd
+    return diff_foley_amd
+
+
+@pytest.fixture(scope="module")
+def tiny(P):
+    from diff_foley_amd import synth
+    m = P.LatentDiffusion(**P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
+    m.load_state_dict(tiny_state_dict())
+    m.cuda()
+    return m
+
+
+@pytest.fixture(scope="module")
+def full(P):
+    m = P.LatentDiffusion(**P.stage2_config())
+    m.load_state_dict(full_state_dict())
+    m.cuda()
+    return m
+
+
+def _oracle_tiny():
+    from diff_foley_amd import synth
+    from oracle import unet as ou
+    sd = tiny_state_dict()
+    usd = ou.sub_state_dict(sd, "model.diffusion_model.")
+    vsd = ou.sub_state_dict(sd, "first_stage_model.")
+    csd = ou.sub_state_dict(sd, "cond_stage_model.")
+    return usd, vsd, csd, synth
+
+
+# ------------------------------------------------------------------------------------------- tiny config
+def test_tiny_unet_vs_golden_and_oracle(tiny):
+    g = gold("g3_tiny_unet.npz")
+    x, c = rnd((2, 4, 16, 64), 102), rnd((2, 32, 128), 101)
+    y = tiny.apply_model(x.cuda(), torch.tensor([500, 37]).cuda(), c.cuda()).cpu()
+    assert y.shape == g["y_int"].shape and y.dtype == torch.float32
+    assert rel_l2(y, g["y_int"]) < FWD_TOL
+    y = tiny.apply_model(x.cuda(), torch.tensor([500.25, 37.7]).cuda(), c.cuda()).cpu()     # fractional t (DPM path)
+    assert rel_l2(y, g["y_flt"]) < FWD_TOL
+
+
+def test_tiny_small_latent_ops_golden(tiny):
+    """G3: reference tensors captured on an 8x16 latent (other plan shapes than 16x64)."""
+    g = gold("g3_tiny_ops.npz")
+    y = tiny.apply_model(g["x"].cuda(), g["t"].cuda(), g["c"].cuda()).cpu()
+    assert rel_l2(y, g["y"]) < FWD_TOL
+
+
+def test_tiny_vae_and_cond_vs_golden(tiny):
+    g = gold("g3_tiny_unet.npz")
+    d = tiny.decode_first_stage(rnd((2, 4, 16, 64), 103).cuda()).cpu()
+    assert d.shape == g["decode"].shape
+    assert rel_l2(d, g["decode"]) < FWD_TOL
+    c = tiny.get_learned_conditioning(rnd((2, 32, 64), 104).cuda()).cpu()
+    assert rel_l2(c, g["cond"]) < 5e-3
+
+
+def test_tiny_batch_sizes_and_cfg_forward(tiny):
+    """Batch 1 / 3 / 8 plans and the fused CFG entry point against the oracle."""
+    usd, _, _, synth = _oracle_tiny()
+    from oracle import unet as ou
+    for B in (1, 3, 8):
+        x, c = rnd((B, 4, 16, 64), 300 + B), rnd((B, 32, 128), 400 + B)
+        t = torch.arange(B) * 100 + 7
+        ref = ou.unet_forward(usd, synth.UNET_TINY, x, t, c)
+        y = tiny.apply_model(x.cuda(), t.cuda(), c.cuda()).cpu()
+        assert rel_l2(y, ref) < FWD_TOL, B
+    B = 2
+    x, c = rnd((B, 4, 16, 64), 310), rnd((B, 32, 128), 410)
+    uc = torch.zeros_like(c)
+    t = torch.tensor([961, 961])
+    e2 = ou.unet_forward(usd, synth.UNET_TINY, torch.cat([x, x]), torch.cat([t, t]), torch.cat([uc, c]))
+    ref = e2[:B] + 4.5 * (e2[B:] - e2[:B])
+    tiny.engine.set_context(torch.cat([uc, c]).cuda())
+    y = tiny.engine.unet_forward_cfg(x.cuda(), t.float().cuda(), 4.5).cpu()
+    assert rel_l2(y, ref) < FWD_TOL
+
+
+def test_tiny_samplers_vs_golden(tiny):
+    g = gold("g5_tiny_samplers.npz")
+    from diff_foley_amd import synth
+    B = 2
+    xT = synth.synthetic_xT(B, seed=21)
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+    uc = torch.zeros_like(c)
+    for name, S in (("DDIM", 25), ("DPM_Solver", 25), ("DPM_Solver", 10), ("PLMS", 25)):
+        z, inter = tiny.sample_log_diff_sampler(c, B, name, S, unconditional_guidance_scale=4.5,
+                                                unconditional_conditioning=uc, x_T=xT.clone())
+        assert z.shape == (B, 4, 16, 64) and z.dtype == torch.float32
+        err = rel_l2(z.cpu(), g[f"{name}_{S}_z"])
+        assert err < TRAJ_TOL, (name, S, err)
+        if name == "DPM_Solver":
+            assert inter is None
+        else:
+            assert len(inter["x_inter"]) == int(g[f"{name}_{S}_n_inter"]) and len(inter["pred_x0"]) == len(inter["x_inter"])
+            assert rel_l2(inter["pred_x0"][-1].cpu(), g[f"{name}_{S}_pred_x0_last"]) < TRAJ_TOL
+    z, _ = tiny.sample_log_diff_sampler(c, B, "DDIM", 25, x_T=xT.clone())
+    assert rel_l2(z.cpu(), g["DDIM_25_nocfg_z"]) < TRAJ_TOL
+    z, _ = tiny.sample_log_diff_sampler(c, B, "DDIM", 25, unconditional_guidance_scale=4.5,
+                                        unconditional_conditioning=uc, x_T=xT.clone())
+    mel = tiny.decode_first_stage(z).cpu()
+    assert rel_l2(mel, g["DDIM_25_mel"]) < TRAJ_TOL
+
+
+def test_tiny_ancestral_sampler_vs_golden(tiny):
+    g = gold("g5_tiny_samplers.npz")
+    from diff_foley_amd import synth
+    B = 2
+    xT = synth.synthetic_xT(B, seed=21)
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+    torch.manual_seed(77)                      # the golden run drew its noise from the CPU generator
+    z, inter = tiny.sample(c, batch_size=B, return_intermediates=True, x_T=xT.clone(), timesteps=6,
+                           shape=(B, 4, 16, 64), noise_fn=lambda s: torch.randn(s))
+    assert rel_l2(z.cpu(), g["ancestral_6_z"]) < TRAJ_TOL
+
+
+def test_tiny_ddim_eta_and_intermediates_shape(tiny):
+    """eta > 0 draws noise on the device; only shapes/finite-ness and the log_every_t bookkeeping are checked."""
+    from diff_foley_amd import synth
+    B = 2
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64).cuda())
+    z, inter = tiny.sample_log_diff_sampler(c, B, "DDIM", 50, eta=1.0, log_every_t=10)
+    assert torch.isfinite(z).all()
+    assert len(inter["x_inter"]) == 1 + 5 + 0 + (1 if 49 % 10 != 0 else 0)
+
+
+def test_tiny_classifier_forward_vs_golden(P, tiny):
+    from diff_foley_amd import synth
+    g = gold("g6_tiny_classifier.npz")
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_TINY)))
+    cls.load_state_dict(tiny_classifier_sd())
+    cls.attach(tiny)
+    x = rnd((2, 4, 16, 64), 105)
+    vf = synth.synthetic_cavp(2, 33, 64, seed=4321)
+    p = cls(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda()).cpu()
+    assert p.shape == (2, 1)
+    assert torch.allclose(p, g["cls_p"], atol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------- full config
+def test_full_unet_forward_vs_golden(full):
+    g = gold("g4_full_unet.npz")
+    x, c = rnd((2, 4, 16, 64), 200), rnd((2, 32, 768), 201)
+    y = full.apply_model(x.cuda(), torch.tensor([961, 41]).cuda(), c.cuda()).cpu()
+    err = rel_l2(y, g["unet_y"])
+    mae = (y - g["unet_y"]).abs().mean().item()
+    print(f"full UNet forward: rel-L2 {err:.3e}  MAE {mae:.3e}")
+    assert err < FWD_TOL
+    y = full.apply_model(x.cuda(), torch.tensor([960.2, 40.96]).cuda(), c.cuda()).cpu()
+    assert rel_l2(y, g["unet_y_float_t"]) < FWD_TOL
+
+
+def test_full_vae_decode_vs_golden(full):
+    g = gold("g4_full_unet.npz")
+    d = full.decode_first_stage(rnd((1, 4, 16, 64), 202).cuda()).cpu()
+    assert d.shape == (1, 3, 128, 512)
+    err = rel_l2(d[:, 0], g["decode"])
+    print(f"full VAE decode: rel-L2 {err:.3e}  MAE {(d[:, 0] - g['decode']).abs().mean().item():.3e}")
+    assert err < FWD_TOL
+
+
+def test_full_ddim_first4_steps_vs_golden(full):
+    """Short trajectory (4 of 25 DDIM steps, CFG 4.5): close before chaotic divergence of the random-weight net."""
+    from diff_foley_amd import synth
+    g = gold("g5_full_samplers.npz")
+    xT = synth.synthetic_xT(1, seed=21)
+    c = full.get_learned_conditioning(synth.synthetic_cavp(1, 32, 512, seed=1234).cuda())
+    assert rel_l2(c.cpu()[:, :2], g["cond_21"]) < 5e-3
+    uc = torch.zeros_like(c)
+    s = full._sampler("DDIM")
+    s.make_schedule(25)
+    from diff_foley_amd import engine as E
+    full.engine.set_context(torch.cat([uc, c]))
+    img = xT.cuda()
+    steps = np.flip(s.ddim_timesteps)
+    for i in range(4):
+        idx = 25 - i - 1
+        t = torch.full((1,), float(steps[i]), device="cuda")
+        e = full.engine.unet_forward_cfg(img, t, 4.5)
+        img, _ = E.ddim_update(img, e, s.ddim_alphas[idx], s.ddim_alphas_prev[idx], 0.0, s.ddim_sqrt_one_minus_alphas[idx])
+    err = rel_l2(img.cpu(), g["ddim25_first4_x"])
+    print(f"4 DDIM steps: rel-L2 {err:.3e}")
+    assert err < TRAJ_TOL
+
+
+def test_full_ddim25_mel_mae(full):
+    """North-star parity metric: decoded mel MAE vs the reference CPU sampler on identical seeds/inputs
+    (B=1, 25-step DDIM, CFG 4.5; BASELINE.json config 1)."""
+    from diff_foley_amd import synth
+    g = gold("g5_full_samplers.npz")
+    for seed in (21, 22):
+        xT = synth.synthetic_xT(1, seed=seed)
+        c = full.get_learned_conditioning(synth.synthetic_cavp(1, 32, 512, seed=1234 + seed - 21).cuda())
+        uc = torch.zeros_like(c)
+        z, _ = full.sample_log_diff_sampler(c, 1, "DDIM", 25, unconditional_guidance_scale=4.5,
+                                            unconditional_conditioning=uc, x_T=xT.clone())
+        mel = full.decode_first_stage(z)[:, 0].cpu()
+        zr, mr = g[f"ddim25_z_{seed}"], g[f"ddim25_mel_{seed}"]
+        mae = (mel - mr).abs().mean().item()
+        print(f"seed {seed}: z rel-L2 {rel_l2(z.cpu(), zr):.3e}; mel MAE {mae:.3e} (mel std {mr.std().item():.3f}, "
+              f"range [{mr.min().item():.2f}, {mr.max().item():.2f}])")
+        assert mae < 2e-2 * max(1.0, mr.std().item())
+
+
+def test_full_dpm50_vs_golden(full):
+    from diff_foley_amd import synth
+    g = gold("g5_full_samplers.npz")
+    xT = synth.synthetic_xT(1, seed=21)
+    c = full.get_learned_conditioning(synth.synthetic_cavp(1, 32, 512, seed=1234).cuda())
+    uc = torch.zeros_like(c)
+    z, inter = full.sample_log_diff_sampler(c, 1, "DPM_Solver", 50, unconditional_guidance_scale=4.5,
+                                            unconditional_conditioning=uc, x_T=xT.clone())
+    assert inter is None
+    mel = full.decode_first_stage(z)[:, 0].cpu()
+    mae = (mel - g["dpm50_mel_21"]).abs().mean().item()
+    print(f"DPM-50: z rel-L2 {rel_l2(z.cpu(), g['dpm50_z_21']):.3e}; mel MAE {mae:.3e}")
+    assert mae < 2e-2 * max(1.0, g["dpm50_mel_21"].std().item())
+
+
+def test_full_batch4_matches_batch1(full):
+    """Config 2 shape (B=4 -> UNet batch 8): samples are independent, so row 0 of a B=4 run equals the B=1 run
+    (size-independent property at BASELINE.json's full size)."""
+    from diff_foley_amd import synth
+    xT = synth.synthetic_xT(4, seed=21)
+    c = full.get_learned_conditioning(synth.synthetic_cavp(4, 32, 512, seed=1234).cuda())
+    uc = torch.zeros_like(c)
+    z4, _ = full.sample_log_diff_sampler(c, 4, "DDIM", 5, unconditional_guidance_scale=4.5,
+                                         unconditional_conditioning=uc, x_T=xT.clone())
+    z1, _ = full.sample_log_diff_sampler(c[:1], 1, "DDIM", 5, unconditional_guidance_scale=4.5,
+                                         unconditional_conditioning=uc[:1], x_T=xT[:1].clone())
+    assert rel_l2(z4[:1].cpu(), z1.cpu()) < 1e-2
+
+
+def test_full_classifier_forward_vs_golden(P, full):
+    from diff_foley_amd import synth
+    g = gold("g6_full_classifier.npz")
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_FULL)))
+    cls.load_state_dict(full_classifier_sd())
+    cls.attach(full)
+    x = rnd((2, 4, 16, 64), 205)
+    vf = synth.synthetic_cavp(2, 33, 512, seed=4321)
+    p = cls(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda()).cpu()
+    assert torch.allclose(p, g["cls_p"], atol=2e-2), (p, g["cls_p"])
