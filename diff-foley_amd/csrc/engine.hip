@@ -139,12 +139,17 @@ struct df_ctx {
   float* ctx_copy = nullptr;
   size_t ctx_copy_bytes = 0;
   bool autotune = false;
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;      // pairs (start, stop) per executed op while profiling
+  std::vector<int> prof_fam;
+  size_t prof_used = 0;
   hipStream_t pack_stream = nullptr;
 
   ~df_ctx() {
     plans.clear();
     for (auto& kv : raw) (void)hipFree(kv.second.d);
     for (void* p : packed_blocks) (void)hipFree(p);
+    for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
   }
 
   const RawT& rt(const std::string& name) const {
@@ -974,10 +979,28 @@ void finish_plan(df_ctx* c, Plan* pl) {
   HIPCHK(hipStreamSynchronize(c->pack_stream));   // weight packing done before first use
 }
 
-void run_ops(Plan* pl, size_t begin, size_t end, hipStream_t s, const RunArgs& a) {
+int op_family(const Op& o) {
+  if (o.is_gemm) return 0;
+  if (!strncmp(o.tag, "attn", 4)) return 1;
+  if (!strcmp(o.tag, "groupnorm")) return 2;
+  if (!strcmp(o.tag, "layernorm")) return 3;
+  return 4;
+}
+
+void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const RunArgs& a) {
   for (size_t i = begin; i < end; ++i) {
     Op& o = pl->ops[i];
     hipError_t e;
+    if (c->prof_on) {
+      if (c->prof_used + 2 > c->prof_ev.size()) {
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        c->prof_ev.push_back(e0);
+        c->prof_ev.push_back(e1);
+      }
+      HIPCHK(hipEventRecord(c->prof_ev[c->prof_used], s));
+    }
     if (o.is_gemm) {
       GemmParams g = o.gp;
       if (o.c_ext) g.C = a.out;
@@ -986,6 +1009,11 @@ void run_ops(Plan* pl, size_t begin, size_t end, hipStream_t s, const RunArgs& a
       e = o.fn(s, a);
     }
     if (e != hipSuccess) fail("op %zu (%s) failed: %s", i, o.tag, hipGetErrorString(e));
+    if (c->prof_on) {
+      HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], s));
+      c->prof_fam.push_back(op_family(o));
+      c->prof_used += 2;
+    }
   }
 }
 
@@ -1175,7 +1203,7 @@ int df_cond_encode(df_ctx* c, const float* feats, float* out, int B, int T, void
     RunArgs a;
     a.x = feats;
     a.out = out;
-    run_ops(p, 0, p->ops.size(), (hipStream_t)stream, a);
+    run_ops(c, p, 0, p->ops.size(), (hipStream_t)stream, a);
   });
 }
 
@@ -1206,7 +1234,7 @@ int df_unet_set_context(df_ctx* c, const float* context, int N, int T, void* str
       if (kv.first.rfind("unet_", 0) != 0) continue;
       int n, h, w, t, g;
       if (sscanf(kv.first.c_str(), "unet_%d_%d_%d_%d_%d", &n, &h, &w, &t, &g) == 5 && n == N && t == T)
-        run_ops(kv.second.get(), 0, nctx, (hipStream_t)stream, a);
+        run_ops(c, kv.second.get(), 0, nctx, (hipStream_t)stream, a);
     }
     // keep a device copy so plans created later can still be primed
     const size_t bytes = (size_t)N * T * c->ucfg.context_dim * 4;
@@ -1232,9 +1260,9 @@ static void unet_run(df_ctx* c, const float* x, const float* t, float* out, int 
   a.scale = scale;
   if (fresh) {  // plan created after set_context: prime its K/V from the saved context copy
     a.aux = c->ctx_copy;
-    run_ops(p, 0, nctx, s, a);
+    run_ops(c, p, 0, nctx, s, a);
   }
-  run_ops(p, nctx, p->ops.size(), s, a);
+  run_ops(c, p, nctx, p->ops.size(), s, a);
   c->last_unet = p;
 }
 
@@ -1254,7 +1282,7 @@ int df_vae_decode(df_ctx* c, const float* z, float* out, int B, int H, int W, vo
     RunArgs a;
     a.x = z;
     a.out = out;
-    run_ops(p, 0, p->ops.size(), (hipStream_t)stream, a);
+    run_ops(c, p, 0, p->ops.size(), (hipStream_t)stream, a);
   });
 }
 
@@ -1269,7 +1297,7 @@ int df_classifier_forward(df_ctx* c, const float* x, const float* t, const float
     a.t = t;
     a.aux = feat;
     a.out = prob;
-    run_ops(p, 0, p->ops.size(), (hipStream_t)stream, a);
+    run_ops(c, p, 0, p->ops.size(), (hipStream_t)stream, a);
   });
 }
 
@@ -1297,6 +1325,31 @@ int df_unet_plan_stats(df_ctx* c, int64_t* n_launches, double* gemm_flops, doubl
     *n_launches = n;
     *gemm_flops = c->last_unet->gemm_flops;
     *weight_bytes = c->last_unet->weight_bytes;
+  });
+}
+
+int df_profile_begin(df_ctx* c) {
+  return guard([&] {
+    c->prof_on = true;
+    c->prof_used = 0;
+    c->prof_fam.clear();
+  });
+}
+
+int df_profile_end(df_ctx* c, double* ms_by_family, int64_t* count_by_family) {
+  return guard([&] {
+    c->prof_on = false;
+    HIPCHK(hipDeviceSynchronize());
+    for (int f = 0; f < 5; ++f) {
+      ms_by_family[f] = 0;
+      count_by_family[f] = 0;
+    }
+    for (size_t i = 0; i < c->prof_fam.size(); ++i) {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+      ms_by_family[c->prof_fam[i]] += ms;
+      count_by_family[c->prof_fam[i]] += 1;
+    }
   });
 }
 

@@ -54,6 +54,8 @@ _SIGS = {
     "df_ddim_update": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                        C.c_float, C.c_float, C.c_void_p],
     "df_unet_plan_stats": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "df_profile_begin": [C.c_void_p],
+    "df_profile_end": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "df_test_gemm": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "df_test_conv3x3": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p],
     "df_test_groupnorm": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
@@ -232,6 +234,15 @@ class Engine:
         _chk(lib().df_classifier_forward(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(out), B, H, W, feat.shape[1],
                                          _stream()))
         return out
+
+    def profile_begin(self):
+        _chk(lib().df_profile_begin(self._h))
+
+    def profile_end(self):
+        ms, cnt = (C.c_double * 5)(), (C.c_int64 * 5)()
+        _chk(lib().df_profile_end(self._h, ms, cnt))
+        names = ("gemm", "attention", "groupnorm", "layernorm", "other")
+        return {n: dict(ms=ms[i], launches=cnt[i]) for i, n in enumerate(names)}
 
     def plan_stats(self):
         n, f, w = C.c_int64(), C.c_double(), C.c_double()

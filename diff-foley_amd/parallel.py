@@ -1,0 +1,70 @@
+"""Multi-GPU plumbing: one process per GPU, batch-of-videos sharding, ONE weight broadcast at init.
+
+Every latent sample is independent for its whole trajectory, so the global batch is split
+contiguously over ranks and the step loop contains no collective.  The only exchange is the initial broadcast
+of the fp32 checkpoint from rank 0 as a single flat buffer (RCCL over xGMI when the backend is "nccl";
+"gloo" on CPU for the tests), after which each rank re-packs its own bf16 copy.
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_process_group(backend=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun style).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def shard_range(global_batch, rank, world):
+    """Contiguous split; the first (global_batch % world) ranks get one extra sample."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_state_dict(state_dict, spec, device, src=0):
+    """Broadcast a checkpoint as ONE flat fp32 buffer.
+
+    ``state_dict`` is needed on ``src`` only; ``spec`` (name -> shape, identical on all ranks) fixes the layout.
+    Returns an OrderedDict of views into the received buffer (on ``device``)."""
+    total = sum(int(np.prod(s)) for s in spec.values())
+    flat = torch.empty(total, dtype=torch.float32, device=device)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if rank == src:
+        off = 0
+        for k, s in spec.items():
+            n = int(np.prod(s))
+            flat[off:off + n].copy_(state_dict[k].reshape(-1).to(torch.float32), non_blocking=True)
+            off += n
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat, src=src)
+    out, off = OrderedDict(), 0
+    for k, s in spec.items():
+        n = int(np.prod(s))
+        out[k] = flat[off:off + n].view(*s)
+        off += n
+    return out
+
+
+def gather_to_rank0(t, dst=0):
+    """Concatenate per-rank result tensors (equal shapes) on rank dst; returns None elsewhere."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    world = dist.get_world_size()
+    bufs = [torch.empty_like(t) for _ in range(world)] if dist.get_rank() == dst else None
+    dist.gather(t, bufs, dst=dst)
+    return torch.cat(bufs) if bufs is not None else None

@@ -114,6 +114,12 @@ int df_ddim_update(const float* x_dev, const float* e_dev, const float* noise_de
 /* ---- introspection for bench.py / tests --------------------------------------------------------- */
 /* Number of kernel launches of the last UNet plan executed and its algorithmic GEMM FLOPs. */
 int df_unet_plan_stats(df_ctx* ctx, int64_t* n_launches, double* gemm_flops, double* weight_bytes);
+/* Per-op-family HIP-event timing of everything executed between begin and end (events are recorded on the
+ * stream the kernels are launched on).  Families: 0 MFMA implicit-GEMM (conv3x3/1x1/linear/batched, incl. split-K
+ * reduce), 1 fused attention, 2 GroupNorm, 3 LayerNorm, 4 other (packing, embeddings, sampler arithmetic).
+ * ms_by_family / count_by_family: arrays of 5. */
+int df_profile_begin(df_ctx* ctx);
+int df_profile_end(df_ctx* ctx, double* ms_by_family, int64_t* count_by_family);
 /* Run ONE op family in isolation for unit tests (see tests/test_kernels_gpu.py). */
 int df_test_gemm(const uint16_t* A_dev, const uint16_t* W_dev, float* C_dev, int M, int N, int K, int tile, int splitk,
                  void* stream);
