@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--dump-ops", default="", help="write a per-op CSV of the instrumented pass")
     a = ap.parse_args()
 
     rank, world, local = parallel.init_process_group()
@@ -138,6 +139,8 @@ def main():
     for i in range(a.steps):
         x = step(a.warmup + i, x)
     prof = eng.profile_end()
+    if a.dump_ops and rank == 0:
+        eng.profile_dump(a.dump_ops)
     stats = eng.plan_stats()
 
     if rank == 0:

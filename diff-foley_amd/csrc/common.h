@@ -7,6 +7,7 @@ typedef uint16_t bf16_t;  // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define DF_WAVE 64
 

@@ -142,6 +142,7 @@ struct df_ctx {
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;      // pairs (start, stop) per executed op while profiling
   std::vector<int> prof_fam;
+  std::vector<const void*> prof_op;
   size_t prof_used = 0;
   hipStream_t pack_stream = nullptr;
 
@@ -315,6 +316,7 @@ struct Builder {
     GemmParams g{};
     g.A = A; g.lda = K; g.W = W; g.M = M; g.N = N; g.K = K;
     g.taps = 1; g.Cin = K; g.alpha = 1.f; g.stride = 1;
+    g.a_bytes = (unsigned)((size_t)M * K * 2); g.w_bytes = (unsigned)((size_t)N * K * 2);
     return g;
   }
   static GemmParams gp_conv3(const bf16_t* A, int NB, int H, int Wd, int Cin, const bf16_t* W, int Cout, int stride,
@@ -326,6 +328,7 @@ struct Builder {
     g.OW = ups ? 2 * Wd : (stride == 2 ? Wd / 2 : Wd);
     g.M = NB * g.OH * g.OW; g.N = Cout; g.K = 9 * Cin;
     g.taps = 9; g.Cin = Cin; g.alpha = 1.f;
+    g.a_bytes = (unsigned)((size_t)NB * H * Wd * Cin * 2); g.w_bytes = (unsigned)((size_t)Cout * 9 * Cin * 2);
     return g;
   }
   static void out_f32(GemmParams& g, float* C, int ldc) { g.C = C; g.ldc = ldc; g.out_bf16 = 0; }
@@ -1012,6 +1015,7 @@ void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const
     if (c->prof_on) {
       HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], s));
       c->prof_fam.push_back(op_family(o));
+      c->prof_op.push_back(&o);
       c->prof_used += 2;
     }
   }
@@ -1333,6 +1337,7 @@ int df_profile_begin(df_ctx* c) {
     c->prof_on = true;
     c->prof_used = 0;
     c->prof_fam.clear();
+    c->prof_op.clear();
   });
 }
 
@@ -1350,6 +1355,27 @@ int df_profile_end(df_ctx* c, double* ms_by_family, int64_t* count_by_family) {
       ms_by_family[c->prof_fam[i]] += ms;
       count_by_family[c->prof_fam[i]] += 1;
     }
+  });
+}
+
+// Per-op CSV of the last profiled region (call between df_profile_begin and df_profile_end's sync is not needed:
+// call AFTER df_profile_end).  Columns: tag,M,N,K,taps,stride,ups,batch,tile,splitk,ms
+int df_profile_dump(df_ctx* c, const char* path) {
+  return guard([&] {
+    FILE* f = fopen(path, "w");
+    if (!f) fail("cannot open %s", path);
+    fprintf(f, "tag,M,N,K,taps,stride,ups,batch,tile,splitk,ms\n");
+    for (size_t i = 0; i < c->prof_fam.size(); ++i) {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+      const Op* o = (const Op*)c->prof_op[i];
+      if (o->is_gemm)
+        fprintf(f, "%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.5f\n", o->tag, o->gp.M, o->gp.N, o->gp.K, o->gp.taps, o->gp.stride,
+                o->gp.ups, o->batch, o->tile, o->gp.splitk, ms);
+      else
+        fprintf(f, "%s,0,0,0,0,0,0,0,0,0,%.5f\n", o->tag, ms);
+    }
+    fclose(f);
   });
 }
 

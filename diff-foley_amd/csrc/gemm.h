@@ -15,6 +15,7 @@ struct GemmParams {
   // operands
   const uint16_t* A; long a_bs; int lda;
   const uint16_t* W; long w_bs;
+  unsigned a_bytes, w_bytes;   // bytes addressable from A / W of ONE batch slice (buffer-load bounds, < 2 GiB)
   int M, N, K;
   // implicit-conv geometry
   int taps;    // 1 (linear / 1x1) or 9 (3x3, pad 1)

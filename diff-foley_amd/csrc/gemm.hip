@@ -2,10 +2,14 @@
 //
 // Block = 256 threads = 4 wavefronts (64 lanes) in a WGM x WGN grid; each wavefront owns a
 // (BM/WGM) x (BN/WGN) output tile made of 32x32 MFMA tiles (v_mfma_f32_32x32x16_bf16).
-// K is walked in steps of 64.  Operand tiles are staged global -> VGPR -> LDS with the next
-// tile's global loads issued before the current tile's MFMAs (T14 split), LDS double buffered,
-// one barrier per K step.  LDS rows are 128 B (64 bf16); the 16-B chunk index is XOR-swizzled
-// with (row>>1)&7 so the ds_read_b128 fragment reads of a 16-lane group hit 16 distinct slots.
+// K is walked in steps of 64.  Operand tiles go HBM -> LDS directly (buffer_load_dwordx4 ... lds, no VGPR
+// round trip) into an NST-deep LDS ring: tile kt+NST-1 is requested while tile kt is multiplied, so the
+// ~1 us load latency of this chip is covered even for the tiny-K GEMMs of the transformer blocks.  One raw
+// s_barrier per K step; waits are counted (s_waitcnt vmcnt(N)), never a full drain inside the loop.
+// LDS rows are 128 B (64 bf16); the 16-B chunk index is XOR-swizzled with (row>>1)&7 so the ds_read_b128
+// fragment reads of a 16-lane group hit 16 distinct slots.  The DMA writes LDS linearly (wave base +
+// lane*16), so the swizzle is applied to the per-lane SOURCE chunk instead (rule: both sides or neither).
+// Out-of-range rows / conv padding use an out-of-bounds buffer offset: the hardware then writes zeros.
 #include "common.h"
 #include "gemm.h"
 
@@ -23,12 +27,10 @@ __device__ __forceinline__ float epi_bias(const GemmParams& p, int row, int col,
   return v;
 }
 
-__device__ __forceinline__ void epi_out(const GemmParams& p, int z, int row, int col, float v) {
-  if (p.res) v += p.res[(long)z * p.res_bs + (long)row * p.ldr + col];
+__device__ __forceinline__ void epi_store(const GemmParams& p, int z, int row, int col, int nout, float v) {
   long idx;
   if (p.store_nchw) {
     const int b = row / p.hw_out, px = row - b * p.hw_out;
-    const int nout = p.geglu ? (p.N >> 1) : p.N;
     idx = ((long)b * nout + col) * p.hw_out + px;
   } else {
     idx = (long)row * p.ldc + col;
@@ -40,17 +42,28 @@ __device__ __forceinline__ void epi_out(const GemmParams& p, int z, int row, int
     reinterpret_cast<float*>(p.C)[idx] = v;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void epi_out(const GemmParams& p, int z, int row, int col, float v) {
+  if (p.res) v += p.res[(long)z * p.res_bs + (long)row * p.ldr + col];
+  epi_store(p, z, row, col, p.geglu ? (p.N >> 1) : p.N, v);
+}
+
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+template <int BM, int BN, int WGM, int WGN, int NST>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // host pass only needs the launch stub (LDS-DMA builtins do not parse there)
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int AP = BM / 32, BP = BN / 32;
   static_assert(WGM * WGN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* sB = sA + 2 * BM * BK;
+  bf16_t* sB = sA + NST * BM * BK;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WGN, wn = wid % WGN;
   const int l31 = lane & 31, lh = lane >> 5;
 
@@ -76,10 +89,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   const bf16_t* Ab = p.A + (long)batch * p.a_bs;
   const bf16_t* Wb = p.W + (long)batch * p.w_bs;
 
-  // ---- per-thread staging coordinates: chunk c (8 bf16 = 16 B) of rows (tid>>3) + 32*i
-  const int c8 = (tid & 7) * 8;
+  // ---- per-thread staging coordinates: chunk c (8 bf16 = 16 B) of rows (tid>>3) + 32*i.
+  // Operands are fetched with raw buffer loads: an out-of-range byte offset (OOB) makes the hardware return
+  // zeros, so zero padding / ragged tiles need no branches and all loads of a K step issue back to back.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)p.w_bytes, 0x00020000);
   const int r0 = tid >> 3;
-  long a_off[AP];   // taps==1: element offset of the row; taps==9: pixel base (n*H*W)
+  const int c8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;   // source chunk that lands in LDS slot (tid&7) of row r0+32i
+  unsigned a_off[AP];   // taps==1: byte offset of (row, chunk) ; taps==9: pixel index base n*H*W
   int a_iy[AP], a_ix[AP];
   const int UH = p.H << p.ups, UW = p.Wd << p.ups;
 #pragma unroll
@@ -87,65 +105,50 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int m = m0 + r0 + 32 * i;
     const bool mv = m < p.M;
     if (p.taps == 1) {
-      a_off[i] = mv ? (long)m * p.lda : -1;
+      a_off[i] = mv ? (unsigned)(((long)m * p.lda + c8) * 2) : OOB;
       a_iy[i] = a_ix[i] = 0;
     } else {
       const int ohw = p.OH * p.OW;
       const int nb = m / ohw, rem = m - nb * ohw;
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      a_off[i] = (long)nb * p.H * p.Wd;
+      a_off[i] = (unsigned)(nb * p.H * p.Wd);
       a_iy[i] = mv ? oy * p.stride - 1 : -(1 << 20);
       a_ix[i] = ox * p.stride - 1;
     }
   }
-  long b_off[BP];
+  unsigned b_off[BP];
 #pragma unroll
   for (int i = 0; i < BP; ++i) {
     const int n = n0 + r0 + 32 * i;
-    b_off[i] = (n < p.N) ? (long)n * p.K : -1;
+    b_off[i] = (n < p.N) ? (unsigned)(((long)n * p.K + c8) * 2) : OOB;
   }
 
-  uint4 ra[AP], rb[BP];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  constexpr int LPT = AP + BP;                  // DMA instructions per wave per K tile
 
-#define DF_GLOAD(KT)                                                                              \
+  // Request tile KT into ring slot ST: every wave writes 8 rows x 128 B (1 KiB, lane-linear) per instruction.
+#define DF_DMA(KT, ST)                                                                            \
   {                                                                                             \
-    const int k0 = (KT) * BK;                                                                   \
+    bf16_t* a_ = sA + (ST) * BM * BK + wid * (8 * BK);                                          \
+    bf16_t* b_ = sB + (ST) * BN * BK + wid * (8 * BK);                                          \
+    const unsigned k0b = (unsigned)(KT) * (BK * 2);                                             \
     if (p.taps == 1) {                                                                          \
-      _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                          \
-        ra[i] = zero4;                                                                          \
-        if (a_off[i] >= 0) ra[i] = *reinterpret_cast<const uint4*>(Ab + a_off[i] + k0 + c8);    \
-      }                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < AP; ++i)                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a_ + i * 32 * BK), 16, a_off[i] + k0b, 0, 0, 0); \
     } else {                                                                                    \
+      const int k0 = (KT) * BK;                                                                 \
       const int tap = k0 / p.Cin, cc = k0 - tap * p.Cin;                                        \
       const int ky = tap / 3, kx = tap - ky * 3;                                                \
       _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                          \
         const int uy = a_iy[i] + ky, ux = a_ix[i] + kx;                                         \
         const bool v = ((unsigned)uy < (unsigned)UH) && ((unsigned)ux < (unsigned)UW);          \
         const int sy = uy >> p.ups, sx = ux >> p.ups;                                           \
-        const long off = (a_off[i] + (long)sy * p.Wd + sx) * p.lda + cc + c8;                   \
-        ra[i] = zero4;                                                                          \
-        if (v) ra[i] = *reinterpret_cast<const uint4*>(Ab + off);                               \
+        const unsigned off = ((a_off[i] + (unsigned)(sy * p.Wd + sx)) * (unsigned)p.lda + (unsigned)(cc + c8)) * 2u; \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a_ + i * 32 * BK), 16, v ? off : OOB, 0, 0, 0); \
       }                                                                                         \
     }                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < BP; ++i) {                                            \
-      rb[i] = zero4;                                                                            \
-      if (b_off[i] >= 0) rb[i] = *reinterpret_cast<const uint4*>(Wb + b_off[i] + k0 + c8);      \
-    }                                                                                           \
-  }
-#define DF_SSTORE(BUF)                                                                            \
-  {                                                                                             \
-    bf16_t* a_ = sA + (BUF) * BM * BK;                                                          \
-    bf16_t* b_ = sB + (BUF) * BN * BK;                                                          \
-    const int c_ = tid & 7;                                                                     \
-    _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                            \
-      const int r = r0 + 32 * i;                                                                \
-      *reinterpret_cast<uint4*>(a_ + r * BK + ((c_ ^ ((r >> 1) & 7)) << 3)) = ra[i];            \
-    }                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < BP; ++i) {                                            \
-      const int r = r0 + 32 * i;                                                                \
-      *reinterpret_cast<uint4*>(b_ + r * BK + ((c_ ^ ((r >> 1) & 7)) << 3)) = rb[i];            \
-    }                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < BP; ++i)                                              \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(b_ + i * 32 * BK), 16, b_off[i] + k0b, 0, 0, 0); \
   }
 
   f32x16 acc[TM][TN];
@@ -156,17 +159,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (kt0 < kt1) {
-    DF_GLOAD(kt0);
-    DF_SSTORE(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const bool more = (kt + 1 < kt1);
-    if (more) DF_GLOAD(kt + 1);
-    const bf16_t* a = sA + buf * BM * BK;
-    const bf16_t* b = sB + buf * BN * BK;
+  // ---- prologue: fill NST-1 ring slots
+  const int nt = kt1 - kt0;
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nt) DF_DMA(kt0 + t, t);
+
+  for (int it = 0; it < nt; ++it) {
+    // tile `it` has landed once at most (NST-2) younger tiles of this wave are still in flight
+    if (it + NST - 2 < nt)
+      wait_vmcnt<(NST - 2) * LPT>();
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();      // every wave's part of tile `it` visible; everyone is done with tile it-1
+    if (it + NST - 1 < nt) DF_DMA(kt0 + it + NST - 1, (it + NST - 1) % NST);   // refill the slot tile it-1 used
+    const int st = it % NST;
+    const bf16_t* a = sA + st * BM * BK;
+    const bf16_t* b = sB + st * BN * BK;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       bf16x8 af[TM], bfr[TN];
@@ -187,12 +196,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (more) DF_SSTORE(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
   }
 
-  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // All loads of a 32x32 tile (bias, per-sample bias, residual) are issued unconditionally from clamped
+  // addresses before any use, so they overlap instead of serialising behind per-element branches.
   if (p.splitk > 1) {
     float* part = p.partial + (long)z * p.M * p.N;
 #pragma unroll
@@ -209,39 +217,79 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
       }
     return;
   }
-  if (p.geglu) {
-    if constexpr (TN % 2 == 0) {
+  const bool has_bias = p.bias != nullptr, has_rb = p.rowbias != nullptr, has_res = p.res != nullptr;
+  const int nout = p.geglu ? (p.N >> 1) : p.N;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
+    int rowv[16], rowc[16];
 #pragma unroll
-        for (int j = 0; j < TN; j += 2) {
+    for (int r = 0; r < 16; ++r) {
+      rowv[r] = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      rowc[r] = min(rowv[r], p.M - 1);
+    }
+    constexpr int JS = 1;
+#pragma unroll
+    for (int j = 0; j < TN; j += JS) {
+      if (p.geglu) {
+        if constexpr (TN % 2 == 0) {
+          if (j & 1) continue;
           const int xcol = n0 + wn * WTN + j * 32 + l31;
-          if (xcol >= p.N) continue;
+          const int xc = min(xcol, p.N - 33);
           const int ocol = (xcol >> 6) * 32 + (xcol & 63);
+          const float bx = has_bias ? p.bias[xc] : 0.f, bg = has_bias ? p.bias[xc + 32] : 0.f;
+          float v[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row >= p.M) continue;
-            const float xv = epi_bias(p, row, xcol, acc[i][j][r]);
-            const float gv = epi_bias(p, row, xcol + 32, acc[i][j + 1][r]);
-            epi_out(p, batch, row, ocol, xv * gelu_erf(gv));
+            const float xv = acc[i][j][r] * p.alpha + bx;
+            const float gv = acc[i][j + 1][r] * p.alpha + bg;
+            v[r] = xv * gelu_erf(gv);
+          }
+          if (has_res) {
+            float rr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rr[r] = p.res[(long)batch * p.res_bs + (long)rowc[r] * p.ldr + min(ocol, nout - 1)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += rr[r];
+          }
+          if (xcol < p.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (rowv[r] < p.M) epi_store(p, batch, rowv[r], ocol, nout, v[r]);
           }
         }
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
+        continue;
+      }
       const int col = n0 + wn * WTN + j * 32 + l31;
-      if (col >= p.N) continue;
+      const int cc = min(col, p.N - 1);
+      const float b0 = has_bias ? p.bias[cc] : 0.f;
+      float v[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < p.M) epi_out(p, batch, row, col, epi_bias(p, row, col, acc[i][j][r]));
+      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] * p.alpha + b0;
+      if (has_rb) {
+        float rb_[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ri = (p.rowbias_mode == 1) ? (rowc[r] / p.rows_per_sample) : (rowc[r] % p.rows_per_sample);
+          rb_[r] = p.rowbias[(long)ri * p.ld_rowbias + cc];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += rb_[r];
+      }
+      if (has_res) {
+        float rr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rr[r] = p.res[(long)batch * p.res_bs + (long)rowc[r] * p.ldr + cc];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += rr[r];
+      }
+      if (col < p.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rowv[r] < p.M) epi_store(p, batch, rowv[r], col, nout, v[r]);
       }
     }
+  }
+#endif
 }
 
 // Sums the split-K partial slabs and applies the same epilogue.  One thread per output element.
@@ -267,18 +315,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NST>
 hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const size_t lds = (size_t)(BM + BN) * BK * 2 * 2;
+  const size_t lds = (size_t)(BM + BN) * BK * 2 * NST;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, NST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN>), dim3(nbm * nbn, 1, zdim), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST>), dim3(nbm * nbn, 1, zdim), dim3(256), lds, stream, p);
   return hipGetLastError();
 }
 
@@ -288,11 +336,11 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
   const int zdim = (p.splitk > 1) ? p.splitk : (batch > 0 ? batch : 1);
   hipError_t e;
   switch (tile_cfg) {
-    case TILE_128x128: e = launch_cfg<128, 128, 2, 2>(p, zdim, stream); break;
-    case TILE_128x64:  e = launch_cfg<128, 64, 2, 2>(p, zdim, stream); break;
-    case TILE_64x128:  e = launch_cfg<64, 128, 2, 2>(p, zdim, stream); break;
-    case TILE_64x64:   e = launch_cfg<64, 64, 2, 2>(p, zdim, stream); break;
-    case TILE_32x128:  e = launch_cfg<32, 128, 1, 4>(p, zdim, stream); break;
+    case TILE_128x128: e = launch_cfg<128, 128, 2, 2, 3>(p, zdim, stream); break;
+    case TILE_128x64:  e = launch_cfg<128, 64, 2, 2, 4>(p, zdim, stream); break;
+    case TILE_64x128:  e = launch_cfg<64, 128, 2, 2, 4>(p, zdim, stream); break;
+    case TILE_64x64:   e = launch_cfg<64, 64, 2, 2, 4>(p, zdim, stream); break;
+    case TILE_32x128:  e = launch_cfg<32, 128, 1, 4, 4>(p, zdim, stream); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;

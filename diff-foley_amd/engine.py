@@ -56,6 +56,7 @@ _SIGS = {
     "df_unet_plan_stats": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "df_profile_begin": [C.c_void_p],
     "df_profile_end": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
+    "df_profile_dump": [C.c_void_p, C.c_char_p],
     "df_test_gemm": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "df_test_conv3x3": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p],
     "df_test_groupnorm": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
@@ -243,6 +244,9 @@ class Engine:
         _chk(lib().df_profile_end(self._h, ms, cnt))
         names = ("gemm", "attention", "groupnorm", "layernorm", "other")
         return {n: dict(ms=ms[i], launches=cnt[i]) for i, n in enumerate(names)}
+
+    def profile_dump(self, path):
+        _chk(lib().df_profile_dump(self._h, path.encode()))
 
     def plan_stats(self):
         n, f, w = C.c_int64(), C.c_double(), C.c_double()

@@ -120,6 +120,8 @@ int df_unet_plan_stats(df_ctx* ctx, int64_t* n_launches, double* gemm_flops, dou
  * ms_by_family / count_by_family: arrays of 5. */
 int df_profile_begin(df_ctx* ctx);
 int df_profile_end(df_ctx* ctx, double* ms_by_family, int64_t* count_by_family);
+/* CSV (tag,M,N,K,taps,stride,ups,batch,tile,splitk,ms) of every op of the region last closed by df_profile_end. */
+int df_profile_dump(df_ctx* ctx, const char* path);
 /* Run ONE op family in isolation for unit tests (see tests/test_kernels_gpu.py). */
 int df_test_gemm(const uint16_t* A_dev, const uint16_t* W_dev, float* C_dev, int M, int N, int K, int tile, int splitk,
                  void* stream);
