@@ -5,8 +5,60 @@
 namespace {
 
 // ------------------------------------------------------------------ GroupNorm(32) [+SiLU] -> bf16
-// One block per (group, sample).  The group slab (HW x cpg fp32, <= 1 MB) is read three times
-// (mean, centred variance, apply); passes 2-3 hit L1/L2.  Stats in fp32, two-pass variance.
+// One block per (group, sample).  Fast path (UNet sizes): the whole group slab (HW x cpg fp32) is held in
+// registers -- PER float2 items per thread, loaded unconditionally from clamped addresses so all loads are in
+// flight together -- and read from memory exactly once; mean and the centred variance (two-pass, fp32) are
+// block reductions.  Large slabs (VAE, up to 1 MB) take the streaming 3-pass path.
+template <int PER>
+__global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                     int silu, bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw) {
+  __shared__ float red[16];
+  const int g = blockIdx.x, n = blockIdx.y;
+  const float* xb = x + (long)n * HW * ld + g * cpg;
+  const int half = cpg >> 1;
+  const int items = HW * half;
+  float2 v[PER];
+  int px[PER], jj[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = threadIdx.x + k * blockDim.x;
+    const int ic = min(i, items - 1);
+    px[k] = ic / half;
+    jj[k] = ic - px[k] * half;
+    v[k] = *reinterpret_cast<const float2*>(xb + (long)px[k] * ld + 2 * jj[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k)
+    if (threadIdx.x + k * blockDim.x < items) s += v[k].x + v[k].y;
+  const float cnt = (float)HW * (float)cpg;
+  const float mean = block_sum(s, red) / cnt;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k)
+    if (threadIdx.x + k * blockDim.x < items) {
+      const float a = v[k].x - mean, b = v[k].y - mean;
+      q += a * a + b * b;
+    }
+  const float rstd = rsqrtf(block_sum(q, red) / cnt + eps);
+  bf16_t* ob = out + (long)n * HW * ldo + g * cpg;
+  bf16_t* rb = raw ? raw + (long)n * HW * ldo + g * cpg : nullptr;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (threadIdx.x + k * blockDim.x >= items) continue;
+    const int c = g * cpg + 2 * jj[k];
+    float a = (v[k].x - mean) * rstd * gamma[c] + beta[c];
+    float b = (v[k].y - mean) * rstd * gamma[c + 1] + beta[c + 1];
+    if (silu) {
+      a = silu_f(a);
+      b = silu_f(b);
+    }
+    *reinterpret_cast<uint32_t*>(ob + (long)px[k] * ldo + 2 * jj[k]) = pack_bf2(a, b);
+    if (rb) *reinterpret_cast<uint32_t*>(rb + (long)px[k] * ldo + 2 * jj[k]) = pack_bf2(v[k].x, v[k].y);
+  }
+}
+
 __global__ void groupnorm_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                  int silu, bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw) {
@@ -49,36 +101,35 @@ __global__ void groupnorm_kernel(const float* __restrict__ x, int ld, int HW, in
 }
 
 // ------------------------------------------------------------------ LayerNorm -> bf16, one wave per row
-template <int MAXV>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ld, int rows, int C,
+// C == 64 * NV exactly, so every lane issues its NV loads unconditionally (all in flight at once).
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ld, int rows,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         bf16_t* __restrict__ out) {
+  constexpr int C = NV * 64;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (long)row * ld;
-  float v[MAXV];
+  float v[NV];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = i * 64 + lane;
-    v[i] = (c < C) ? xr[c] : 0.f;
-    s += v[i];
-  }
-  const float mean = wave_sum(s) / (float)C;
+  for (int i = 0; i < NV; ++i) v[i] = xr[i * 64 + lane];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += v[i];
+  const float mean = wave_sum(s) * (1.0f / (float)C);
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = i * 64 + lane;
-    const float d = (c < C) ? v[i] - mean : 0.f;
+  for (int i = 0; i < NV; ++i) {
+    const float d = v[i] - mean;
     q += d * d;
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / (float)C) + eps);
   bf16_t* orow = out + (long)row * C;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = i * 64 + lane;
-    if (c < C) orow[c] = f2bf((v[i] - mean) * rstd * gamma[c] + beta[c]);
+    orow[c] = f2bf((v[i] - mean) * rstd * gamma[c] + beta[c]);
   }
 }
 
@@ -273,23 +324,38 @@ hipError_t launch_groupnorm(const float* x, int ld, int N, int HW, int C, const 
   if (C % 64 != 0) return hipErrorInvalidValue;
   const int cpg = C / 32;
   const long items = (long)HW * (cpg / 2);
-  const int threads = items >= 8192 ? 1024 : (items >= 2048 ? 512 : 256);
-  hipLaunchKernelGGL(groupnorm_kernel, dim3(32, N), dim3(threads), 0, s, x, ld, HW, C, cpg, gamma, beta, eps, silu,
-                     out, ldo, raw_out);
+#define DF_GN_REG(PER, THREADS)                                                                                     \
+  hipLaunchKernelGGL(groupnorm_reg_kernel<PER>, dim3(32, N), dim3(THREADS), 0, s, x, ld, HW, C, cpg, gamma, beta, eps, \
+                     silu, out, ldo, raw_out)
+  if (items <= 256) DF_GN_REG(1, 256);
+  else if (items <= 512) DF_GN_REG(2, 256);
+  else if (items <= 1024) DF_GN_REG(2, 512);
+  else if (items <= 2048) DF_GN_REG(2, 1024);
+  else if (items <= 4096) DF_GN_REG(4, 1024);
+  else if (items <= 8192) DF_GN_REG(8, 1024);
+  else if (items <= 16384) DF_GN_REG(16, 1024);
+  else
+    hipLaunchKernelGGL(groupnorm_kernel, dim3(32, N), dim3(1024), 0, s, x, ld, HW, C, cpg, gamma, beta, eps, silu, out,
+                       ldo, raw_out);
+#undef DF_GN_REG
   return hipGetLastError();
 }
 
 hipError_t launch_layernorm(const float* x, int ld, int rows, int C, const float* gamma, const float* beta,
                             float eps, uint16_t* out, hipStream_t s) {
   const int blocks = (rows + 3) / 4;
-  if (C <= 320)
-    hipLaunchKernelGGL(layernorm_kernel<5>, dim3(blocks), dim3(256), 0, s, x, ld, rows, C, gamma, beta, eps, out);
-  else if (C <= 640)
-    hipLaunchKernelGGL(layernorm_kernel<10>, dim3(blocks), dim3(256), 0, s, x, ld, rows, C, gamma, beta, eps, out);
-  else if (C <= 1280)
-    hipLaunchKernelGGL(layernorm_kernel<20>, dim3(blocks), dim3(256), 0, s, x, ld, rows, C, gamma, beta, eps, out);
-  else
-    return hipErrorInvalidValue;
+#define DF_LN(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, dim3(blocks), dim3(256), 0, s, x, ld, rows, gamma, beta, eps, out)
+  switch (C) {
+    case 64: DF_LN(1); break;
+    case 128: DF_LN(2); break;
+    case 256: DF_LN(4); break;
+    case 320: DF_LN(5); break;
+    case 512: DF_LN(8); break;
+    case 640: DF_LN(10); break;
+    case 1280: DF_LN(20); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef DF_LN
   return hipGetLastError();
 }
 

@@ -52,7 +52,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST>
+template <int BM, int BN, int WGM, int WGN, int NST, bool CONV>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // host pass only needs the launch stub (LDS-DMA builtins do not parse there)
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   for (int i = 0; i < AP; ++i) {
     const int m = m0 + r0 + 32 * i;
     const bool mv = m < p.M;
-    if (p.taps == 1) {
+    if (!CONV) {
       a_off[i] = mv ? (unsigned)(((long)m * p.lda + c8) * 2) : OOB;
       a_iy[i] = a_ix[i] = 0;
     } else {
@@ -126,29 +126,43 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
   constexpr int LPT = AP + BP;                  // DMA instructions per wave per K tile
 
-  // Request tile KT into ring slot ST: every wave writes 8 rows x 128 B (1 KiB, lane-linear) per instruction.
-#define DF_DMA(KT, ST)                                                                            \
+  // Request tile T (relative to kt0) into ring slot ST: every wave writes 8 rows x 128 B (1 KiB, lane-linear)
+  // per instruction.  Tiles past the end are requested with an out-of-bounds offset (zeros land in a dead slot),
+  // so the DMA count per iteration is constant and the loop body has no branch.
+  int d_tap = 0, d_cc = 0;       // conv: (tap, channel offset) of the NEXT tile to request, advanced incrementally
+  if (CONV) {
+    const int k0 = kt0 * BK;
+    d_tap = k0 / p.Cin;
+    d_cc = k0 - d_tap * p.Cin;
+  }
+#define DF_DMA(T, ST)                                                                             \
   {                                                                                             \
     bf16_t* a_ = sA + (ST) * BM * BK + wid * (8 * BK);                                          \
     bf16_t* b_ = sB + (ST) * BN * BK + wid * (8 * BK);                                          \
-    const unsigned k0b = (unsigned)(KT) * (BK * 2);                                             \
-    if (p.taps == 1) {                                                                          \
+    const bool live = (T) < nt;                                                                 \
+    const unsigned k0b = (unsigned)(kt0 + (T)) * (BK * 2);                                      \
+    if (!CONV) {                                                                                \
       _Pragma("unroll") for (int i = 0; i < AP; ++i)                                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a_ + i * 32 * BK), 16, a_off[i] + k0b, 0, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a_ + i * 32 * BK), 16,          \
+                                                 live ? a_off[i] + k0b : OOB, 0, 0, 0);         \
     } else {                                                                                    \
-      const int k0 = (KT) * BK;                                                                 \
-      const int tap = k0 / p.Cin, cc = k0 - tap * p.Cin;                                        \
-      const int ky = tap / 3, kx = tap - ky * 3;                                                \
+      const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                    \
       _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                          \
         const int uy = a_iy[i] + ky, ux = a_ix[i] + kx;                                         \
-        const bool v = ((unsigned)uy < (unsigned)UH) && ((unsigned)ux < (unsigned)UW);          \
+        const bool v = live && ((unsigned)uy < (unsigned)UH) && ((unsigned)ux < (unsigned)UW);  \
         const int sy = uy >> p.ups, sx = ux >> p.ups;                                           \
-        const unsigned off = ((a_off[i] + (unsigned)(sy * p.Wd + sx)) * (unsigned)p.lda + (unsigned)(cc + c8)) * 2u; \
+        const unsigned off = ((a_off[i] + (unsigned)(sy * p.Wd + sx)) * (unsigned)p.lda + (unsigned)(d_cc + c8)) * 2u; \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a_ + i * 32 * BK), 16, v ? off : OOB, 0, 0, 0); \
+      }                                                                                         \
+      d_cc += BK;                                                                               \
+      if (d_cc == p.Cin) {                                                                      \
+        d_cc = 0;                                                                               \
+        ++d_tap;                                                                                \
       }                                                                                         \
     }                                                                                           \
     _Pragma("unroll") for (int i = 0; i < BP; ++i)                                              \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(b_ + i * 32 * BK), 16, b_off[i] + k0b, 0, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(b_ + i * 32 * BK), 16,            \
+                                               live ? b_off[i] + k0b : OOB, 0, 0, 0);           \
   }
 
   f32x16 acc[TM][TN];
@@ -162,41 +176,57 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   // ---- prologue: fill NST-1 ring slots
   const int nt = kt1 - kt0;
 #pragma unroll
-  for (int t = 0; t < NST - 1; ++t)
-    if (t < nt) DF_DMA(kt0 + t, t);
+  for (int t = 0; t < NST - 1; ++t) DF_DMA(t, t);
 
+  // LDS fragment addresses (elements) of k-step 0; k-step s toggles the chunk index by 2*s
+  int fa[TM], fb[TN], sa[TM], sb[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = wm * WTM + i * 32 + l31;
+    fa[i] = row * BK;
+    sa[i] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * WTN + j * 32 + l31;
+    fb[j] = row * BK;
+    sb[j] = (row >> 1) & 7;
+  }
+#define DF_FRAG(DSTA, DSTB, S)                                                                    \
+  {                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+      DSTA[i] = *reinterpret_cast<const bf16x8*>(a + fa[i] + (((2 * (S) + lh) ^ sa[i]) << 3));  \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
+      DSTB[j] = *reinterpret_cast<const bf16x8*>(b + fb[j] + (((2 * (S) + lh) ^ sb[j]) << 3));  \
+  }
+#define DF_MMA(SRCA, SRCB)                                                                        \
+  {                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRCA[i], SRCB[j], acc[i][j], 0, 0, 0); \
+  }
+
+  int st = 0, dst = NST - 1;
   for (int it = 0; it < nt; ++it) {
     // tile `it` has landed once at most (NST-2) younger tiles of this wave are still in flight
-    if (it + NST - 2 < nt)
-      wait_vmcnt<(NST - 2) * LPT>();
-    else
-      wait_vmcnt<0>();
+    wait_vmcnt<(NST - 2) * LPT>();
     __builtin_amdgcn_s_barrier();      // every wave's part of tile `it` visible; everyone is done with tile it-1
-    if (it + NST - 1 < nt) DF_DMA(kt0 + it + NST - 1, (it + NST - 1) % NST);   // refill the slot tile it-1 used
-    const int st = it % NST;
     const bf16_t* a = sA + st * BM * BK;
     const bf16_t* b = sB + st * BN * BK;
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      bf16x8 af[TM], bfr[TN];
-      const int ch = 2 * s + lh;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * WTM + i * 32 + l31;
-        af[i] = *reinterpret_cast<const bf16x8*>(a + row * BK + ((ch ^ ((row >> 1) & 7)) << 3));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * WTN + j * 32 + l31;
-        bfr[j] = *reinterpret_cast<const bf16x8*>(b + row * BK + ((ch ^ ((row >> 1) & 7)) << 3));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
+    bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+    DF_FRAG(a0, b0, 0);
+    DF_DMA(it + NST - 1, dst);         // refill the slot tile it-1 used (overlaps the first MFMAs)
+    DF_FRAG(a1, b1, 1);
+    DF_MMA(a0, b0);
+    DF_FRAG(a0, b0, 2);
+    DF_MMA(a1, b1);
+    DF_FRAG(a1, b1, 3);
+    DF_MMA(a0, b0);
+    DF_MMA(a1, b1);
+    st = (st + 1 == NST) ? 0 : st + 1;
+    dst = (dst + 1 == NST) ? 0 : dst + 1;
   }
+  wait_vmcnt<0>();                     // dead-slot requests of the last iterations must land before LDS is released
 
   // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   // All loads of a 32x32 tile (bias, per-sample bias, residual) are issued unconditionally from clamped
@@ -315,18 +345,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST>
+template <int BM, int BN, int WGM, int WGN, int NST, bool CONV>
 hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)(BM + BN) * BK * 2 * NST;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, NST>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, NST, CONV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST>), dim3(nbm * nbn, 1, zdim), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST, CONV>), dim3(nbm * nbn, 1, zdim), dim3(256), lds, stream, p);
   return hipGetLastError();
 }
 
@@ -335,12 +365,18 @@ hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
 hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t stream) {
   const int zdim = (p.splitk > 1) ? p.splitk : (batch > 0 ? batch : 1);
   hipError_t e;
+  const bool conv = p.taps == 9;
+#define DF_CASE(T, BM, BN, WGM, WGN, NST)                                              \
+  case T:                                                                             \
+    e = conv ? launch_cfg<BM, BN, WGM, WGN, NST, true>(p, zdim, stream)               \
+             : launch_cfg<BM, BN, WGM, WGN, NST, false>(p, zdim, stream);             \
+    break;
   switch (tile_cfg) {
-    case TILE_128x128: e = launch_cfg<128, 128, 2, 2, 3>(p, zdim, stream); break;
-    case TILE_128x64:  e = launch_cfg<128, 64, 2, 2, 4>(p, zdim, stream); break;
-    case TILE_64x128:  e = launch_cfg<64, 128, 2, 2, 4>(p, zdim, stream); break;
-    case TILE_64x64:   e = launch_cfg<64, 64, 2, 2, 4>(p, zdim, stream); break;
-    case TILE_32x128:  e = launch_cfg<32, 128, 1, 4, 4>(p, zdim, stream); break;
+    DF_CASE(TILE_128x128, 128, 128, 2, 2, 3)
+    DF_CASE(TILE_128x64, 128, 64, 2, 2, 4)
+    DF_CASE(TILE_64x128, 64, 128, 2, 2, 4)
+    DF_CASE(TILE_64x64, 64, 64, 2, 2, 4)
+    DF_CASE(TILE_32x128, 32, 128, 1, 4, 4)
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;

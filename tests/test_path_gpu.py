@@ -251,7 +251,9 @@ def test_full_batch4_matches_batch1(full):
                                          unconditional_conditioning=uc, x_T=xT.clone())
     z1, _ = full.sample_log_diff_sampler(c[:1], 1, "DDIM", 5, unconditional_guidance_scale=4.5,
                                          unconditional_conditioning=uc[:1], x_T=xT[:1].clone())
-    assert rel_l2(z4[:1].cpu(), z1.cpu()) < 1e-2
+    # different batch -> different tile/split-K choices -> different fp32 summation order -> different bf16
+    # roundings downstream: the two runs agree to bf16 noise, not bit-exactly
+    assert rel_l2(z4[:1].cpu(), z1.cpu()) < TRAJ_TOL
 
 
 def test_full_classifier_forward_vs_golden(P, full):
