@@ -32,8 +32,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
   constexpr int DKP = DKC * 16;           // padded head dim
   constexpr int DT = (D + 31) / 32;       // 32-row tiles of O^T
   constexpr int KROW = DKP + 8;           // K LDS row stride (bf16): +16 B pad de-conflicts ds_read_b128
-  __shared__ __attribute__((aligned(16))) bf16_t sK[KT * KROW];
-  __shared__ __attribute__((aligned(16))) bf16_t sV[DT * 32 * VROW];
+  __shared__ __attribute__((aligned(16))) bf16_t sK[2 * KT * KROW];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[2 * DT * 32 * VROW];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -49,8 +49,9 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
 #pragma unroll
     for (int c = 0; c < DKC; ++c) {
       const int d0 = 16 * c + 8 * lh;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (qv && d0 < D) v = *reinterpret_cast<const uint4*>(qr + d0);   // D % 8 == 0
+      const bool ok = qv && d0 < D;                                    // D % 8 == 0
+      uint4 v = *reinterpret_cast<const uint4*>(qr + (ok ? d0 : 0));   // unconditional load, then select
+      if (!ok) v = make_uint4(0, 0, 0, 0);
       qf[c] = *reinterpret_cast<bf16x8*>(&v);
     }
   }
@@ -66,31 +67,68 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
   const bf16_t* Vb = Vt + ((long)n * heads + h) * D * ldvt;
   const int ntiles = (Tk + KT - 1) / KT;
 
+  // ---- K / V^T tile staging, software pipelined (T14): the global loads of tile kt+1 are issued before the MFMAs
+  // of tile kt and written to the other LDS buffer afterwards; all loads are unconditional (clamped address +
+  // select) so they stay in flight together.  Thread t owns chunk slots t + i*NT.
+  constexpr int NT = NW * 64;
+  constexpr int KCH = (KT * (DKP / 8) + NT - 1) / NT;      // 16-B K chunks per thread
+  constexpr int VCH = (DT * 32 * 8 + NT - 1) / NT;         // 8-B V^T chunks per thread
+  uint4 kreg[KCH];
+  uint2 vreg[VCH];
+  auto gfetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int c = tid + i * NT;
+      const int key = c / (DKP / 8), ch = c - key * (DKP / 8);
+      const bool ok = (c < KT * (DKP / 8)) && (k0 + key < Tk) && (ch * 8 < D);
+      const bf16_t* src = Kb + (long)(ok ? (k0 + key) : 0) * ldk + (ok ? ch * 8 : 0);
+      uint4 v = *reinterpret_cast<const uint4*>(src);
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      kreg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+      const int c = tid + i * NT;
+      const int d = c >> 3, ch = c & 7;
+      const int nvalid = Tk - (k0 + ch * 4);   // keys of this 4-key chunk that exist
+      const bool ok = (c < DT * 32 * 8) && (d < D) && (nvalid > 0);
+      const bf16_t* src = Vb + (long)(ok ? d : 0) * ldvt + (ok ? k0 + ch * 4 : 0);   // ldvt padded to 32
+      uint2 v = *reinterpret_cast<const uint2*>(src);
+      if (!ok) v = make_uint2(0, 0);
+      if (nvalid < 4) {   // ragged tail (e.g. 33 context tokens): padding may hold stale bits
+        if (nvalid < 3) v.y = 0; else v.y &= 0xFFFFu;
+        if (nvalid < 2) v.x &= 0xFFFFu;
+      }
+      vreg[i] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+    bf16_t* k_ = sK + buf * (KT * KROW);
+    bf16_t* v_ = sV + buf * (DT * 32 * VROW);
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+      const int c = tid + i * NT;
+      const int key = c / (DKP / 8), ch = c - key * (DKP / 8);
+      if (c < KT * (DKP / 8)) *reinterpret_cast<uint4*>(&k_[key * KROW + ch * 8]) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+      const int c = tid + i * NT;
+      const int d = c >> 3, ch = c & 7;
+      if (c < DT * 32 * 8) *reinterpret_cast<uint2*>(&v_[d * VROW + ch * 4]) = vreg[i];
+    }
+  };
+
+  gfetch(0);
+  sstore(0);
+  __syncthreads();
+
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * KT;
-    __syncthreads();   // previous tile fully consumed
-    // ---- stage K tile [32 keys][DKP] (zero padded) : 16-B chunks
-    for (int i = tid; i < KT * (DKP / 8); i += NW * 64) {
-      const int key = i / (DKP / 8), ch = i - key * (DKP / 8);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (k0 + key < Tk && ch * 8 < D) v = *reinterpret_cast<const uint4*>(Kb + (long)(k0 + key) * ldk + ch * 8);
-      *reinterpret_cast<uint4*>(&sK[key * KROW + ch * 8]) = v;
-    }
-    // ---- stage V^T tile [DT*32 d-rows][32 keys] : 8-B chunks (rows beyond D zero)
-    for (int i = tid; i < DT * 32 * 8; i += NW * 64) {
-      const int d = i >> 3, ch = i & 7;
-      uint2 v = make_uint2(0, 0);
-      const int nvalid = Tk - (k0 + ch * 4);   // keys of this 4-key chunk that exist
-      if (d < D && nvalid > 0) {
-        v = *reinterpret_cast<const uint2*>(Vb + (long)d * ldvt + k0 + ch * 4);  // ldvt padded to 32
-        if (nvalid < 4) {   // ragged tail (e.g. 33 context tokens): padding may hold stale bits
-          if (nvalid < 3) v.y = 0; else v.y &= 0xFFFFu;
-          if (nvalid < 2) v.x &= 0xFFFFu;
-        }
-      }
-      *reinterpret_cast<uint2*>(&sV[d * VROW + ch * 4]) = v;
-    }
-    __syncthreads();
+    const int buf = kt & 1;
+    const bf16_t* cK = sK + buf * (KT * KROW);
+    const bf16_t* cV = sV + buf * (DT * 32 * VROW);
+    if (kt + 1 < ntiles) gfetch(k0 + KT);
 
     // ---- S^T = K Q^T
     f32x16 s;
@@ -98,7 +136,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
     for (int c = 0; c < DKC; ++c) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[l31 * KROW + 16 * c + 8 * lh]);
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&cK[l31 * KROW + 16 * c + 8 * lh]);
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], s, 0, 0, 0);
     }
     // ---- online softmax over this lane's 16 keys (+ partner half-wave)
@@ -133,7 +171,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
       const bf16x8 pf = *reinterpret_cast<bf16x8*>(&pv);
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
-        const bf16_t* vr = &sV[(t * 32 + l31) * VROW + 16 * c + 4 * lh];
+        const bf16_t* vr = &cV[(t * 32 + l31) * VROW + 16 * c + 4 * lh];
         const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
         const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
         uint4 vv = make_uint4(v0.x, v0.y, v1.x, v1.y);
@@ -141,6 +179,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
         o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
       }
     }
+    if (kt + 1 < ntiles) sstore(buf ^ 1);   // the other buffer was last read in iteration kt-1
+    __syncthreads();
   }
 
   // ---- normalise and store: lane (q, lh) holds O[q][32t + (r&3) + 8(r>>2) + 4lh]

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -300,6 +301,12 @@ struct Builder {
     o.tag = tag;
     int sk = 1;
     choose_tile(gp.M, gp.N, gp.K, batch, gp.geglu != 0, &o.tile, &sk);
+    if (gp.taps == 9 && gemm_tile_valid(gp, TILE_HALO_128x64, batch, 1)) {   // halo reuse beats re-fetching A per tap
+      o.tile = TILE_HALO_128x64;
+      const long blocks = (long)((gp.M + 127) / 128) * ((gp.N + 63) / 64);
+      sk = 1;
+      while (blocks * sk < 160 && sk < 16 && gp.Cin / 64 / (sk * 2) >= 2) sk *= 2;
+    }
     gp.splitk = sk;
     if (sk > 1) {
       const size_t need = (size_t)sk * gp.M * gp.N * 4;
@@ -1041,11 +1048,9 @@ void autotune_plan(Plan* pl, hipStream_t s) {
     }
     float best = 1e30f;
     int bt = o.tile, bs = g.splitk;
-    const int nk = g.K / 64;
-    for (int t = 0; t < TILE_COUNT; ++t) {
-      if (g.geglu && !(t == TILE_128x128 || t == TILE_64x128)) continue;
+    for (int t = 0; t < TILE_ALL; ++t) {
       for (int sk = 1; sk <= 16; sk *= 2) {
-        if (sk > 1 && (o.batch > 1 || nk / sk < 2)) break;
+        if (!gemm_tile_valid(g, t, o.batch, sk)) { if (sk > 1) break; else continue; }
         const size_t need = (size_t)sk * g.M * g.N * 4;
         if (sk > 1 && need > pl->partial_bytes) break;
         GemmParams q = g;
@@ -1384,6 +1389,7 @@ int df_test_gemm(const uint16_t* A, const uint16_t* W, float* C, int M, int N, i
   return guard([&] {
     GemmParams g = Builder::gp_linear(A, M, K, W, N);
     Builder::out_f32(g, C, N);
+    g.dbg = getenv("DF_GEMM_DBG") ? atoi(getenv("DF_GEMM_DBG")) : 0;
     g.splitk = splitk;
     float* part = nullptr;
     if (splitk > 1) {

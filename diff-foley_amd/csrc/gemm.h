@@ -24,6 +24,7 @@ struct GemmParams {
   int OH, OW;  // output spatial size (M = batch * OH * OW)
   int stride;  // 1 | 2
   int ups;     // 1: conv runs on the nearest-x2 upsampled input
+  int th, tw;  // halo kernels: spatial patch of output pixels owned per block (th*tw divides BM)
   // epilogue
   void* C; long c_bs; int ldc; int out_bf16;
   float alpha;
@@ -32,17 +33,25 @@ struct GemmParams {
   const float* res; long res_bs; int ldr;   // fp32 residual, may alias C
   int geglu;                         // columns come in (x:32 | gate:32) groups, output width N/2
   int store_nchw; int hw_out;        // write C as [batch][N][hw_out] instead of [rows][ldc]
+  int dbg;     // tools only: 1 = every K tile re-reads tile 0 (cache-resident operands; isolates memory latency)
   // split-K
   int splitk; float* partial;
 };
 
-enum GemmTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_COUNT = 5 };
+enum GemmTile {
+  TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_COUNT = 5,   // generic
+  // conv3x3 stride-1 kernels with an LDS-staged halo tile (BM output pixels = patches of th x tw, BN couts)
+  TILE_HALO_128x64 = 5, TILE_HALO_256x64 = 6, TILE_HALO_128x128 = 7, TILE_ALL = 8
+};
 
 static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
-  static const int d[TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}};
+  static const int d[TILE_ALL][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}, {128, 64}, {256, 64}, {128, 128}};
   *bm = d[cfg][0];
   *bn = d[cfg][1];
 }
+
+// Can (tile, batch, splitk) run this problem?  (halo tiles: 3x3 stride-1 convs whose patch geometry fits LDS)
+bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk);
 
 // batch > 1 and splitk > 1 are mutually exclusive.
 hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t stream);

@@ -17,6 +17,18 @@ namespace {
 
 constexpr int BK = 64;
 
+// Spatial patch (th x tw output pixels) owned by one block of a halo kernel with BM rows.
+bool halo_patch(int H, int W, int BM, int* th, int* tw) {
+  const int w = (W % 16 == 0) ? 16 : W;
+  if (w <= 0 || BM % w != 0) return false;
+  int h = BM / w;
+  if (h > H) h = H;
+  if (h <= 0 || H % h != 0 || BM % (h * w) != 0) return false;
+  *th = h;
+  *tw = w;
+  return true;
+}
+
 __device__ __forceinline__ float epi_bias(const GemmParams& p, int row, int col, float v) {
   v *= p.alpha;
   if (p.bias) v += p.bias[col];
@@ -47,12 +59,100 @@ __device__ __forceinline__ void epi_out(const GemmParams& p, int z, int row, int
   epi_store(p, z, row, col, p.geglu ? (p.N >> 1) : p.N, v);
 }
 
+// Epilogue of one 32-row band of a wavefront's tile: TN 32x32 accumulator tiles side by side.
+// C/D layout of the 32x32 MFMA: col = lane&31, row r -> (r&3) + 8*(r>>2) + 4*(lane>>5).  rowv[r] is the OUTPUT row
+// (NHWC pixel index) of accumulator register r, or >= p.M when that row does not exist.  All loads of a tile
+// (bias, per-sample bias, residual) are issued unconditionally from clamped addresses before any use, so they
+// overlap instead of serialising behind per-element branches.
+template <int TN>
+__device__ __forceinline__ void epilogue_band(const GemmParams& p, int z, int batch, const int (&rowv)[16],
+                                              f32x16 (&acc)[TN], int col0, int l31) {
+  if (p.splitk > 1) {
+    float* part = p.partial + (long)z * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = col0 + j * 32 + l31;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (rowv[r] < p.M) part[(long)rowv[r] * p.N + col] = acc[j][r];
+    }
+    return;
+  }
+  const bool has_bias = p.bias != nullptr, has_rb = p.rowbias != nullptr, has_res = p.res != nullptr;
+  const int nout = p.geglu ? (p.N >> 1) : p.N;
+  int rowc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rowc[r] = min(rowv[r], p.M - 1);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    if (p.geglu) {
+      if constexpr (TN % 2 == 0) {
+        if (j & 1) continue;
+        const int xcol = col0 + j * 32 + l31;
+        const int xc = min(xcol, p.N - 33);
+        const int ocol = (xcol >> 6) * 32 + (xcol & 63);
+        const float bx = has_bias ? p.bias[xc] : 0.f, bg = has_bias ? p.bias[xc + 32] : 0.f;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float xv = acc[j][r] * p.alpha + bx;
+          const float gv = acc[j + 1][r] * p.alpha + bg;
+          v[r] = xv * gelu_erf(gv);
+        }
+        if (has_res) {
+          float rr[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            rr[r] = p.res[(long)batch * p.res_bs + (long)rowc[r] * p.ldr + min(ocol, nout - 1)];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += rr[r];
+        }
+        if (xcol < p.N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (rowv[r] < p.M) epi_store(p, batch, rowv[r], ocol, nout, v[r]);
+        }
+      }
+      continue;
+    }
+    const int col = col0 + j * 32 + l31;
+    const int cc = min(col, p.N - 1);
+    const float b0 = has_bias ? p.bias[cc] : 0.f;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[j][r] * p.alpha + b0;
+    if (has_rb) {
+      float rb_[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ri = (p.rowbias_mode == 1) ? (rowc[r] / p.rows_per_sample) : (rowc[r] % p.rows_per_sample);
+        rb_[r] = p.rowbias[(long)ri * p.ld_rowbias + cc];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += rb_[r];
+    }
+    if (has_res) {
+      float rr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rr[r] = p.res[(long)batch * p.res_bs + (long)rowc[r] * p.ldr + cc];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += rr[r];
+    }
+    if (col < p.N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (rowv[r] < p.M) epi_store(p, batch, rowv[r], col, nout, v[r]);
+    }
+  }
+}
+
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, bool CONV>
+template <int BM, int BN, int WGM, int WGN, int NST, int MODE>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // host pass only needs the launch stub (LDS-DMA builtins do not parse there)
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -60,8 +160,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   constexpr int AP = BM / 32, BP = BN / 32;
   static_assert(WGM * WGN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* sA = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* sB = sA + NST * BM * BK;
+  static_assert(NST >= 3 && NST <= 5, "ring depth");
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WGN, wn = wid % WGN;
@@ -91,29 +190,45 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
   // ---- per-thread staging coordinates: chunk c (8 bf16 = 16 B) of rows (tid>>3) + 32*i.
   // Operands are fetched with raw buffer loads: an out-of-range byte offset (OOB) makes the hardware return
-  // zeros, so zero padding / ragged tiles need no branches and all loads of a K step issue back to back.
+  // zeros, so zero padding / ragged tiles need no branches.  Everything the inner loop needs is hoisted: a DMA
+  // request costs one v_add (+ one v_cndmask for conv padding), an LDS fragment read costs no VALU at all
+  // (per-k-step byte offsets are precomputed, the ring slot is a compile-time immediate).
   constexpr unsigned OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)p.w_bytes, 0x00020000);
   const int r0 = tid >> 3;
   const int c8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;   // source chunk that lands in LDS slot (tid&7) of row r0+32i
-  unsigned a_off[AP];   // taps==1: byte offset of (row, chunk) ; taps==9: pixel index base n*H*W
+  unsigned a_off[AP];   // MODE 0: byte offset of (row, chunk); MODE 1: byte offset of the centre-tap pixel;
+                        // MODE 2: pixel index base n*H*W
+  unsigned a_msk[AP];   // MODE 1: bit t set <=> tap t of this row reads inside the image
   int a_iy[AP], a_ix[AP];
   const int UH = p.H << p.ups, UW = p.Wd << p.ups;
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     const int m = m0 + r0 + 32 * i;
     const bool mv = m < p.M;
-    if (!CONV) {
+    a_msk[i] = 0;
+    a_iy[i] = a_ix[i] = 0;
+    if (MODE == 0) {
       a_off[i] = mv ? (unsigned)(((long)m * p.lda + c8) * 2) : OOB;
-      a_iy[i] = a_ix[i] = 0;
     } else {
       const int ohw = p.OH * p.OW;
       const int nb = m / ohw, rem = m - nb * ohw;
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      a_off[i] = (unsigned)(nb * p.H * p.Wd);
-      a_iy[i] = mv ? oy * p.stride - 1 : -(1 << 20);
-      a_ix[i] = ox * p.stride - 1;
+      if (MODE == 1) {
+        a_off[i] = (unsigned)((((long)(nb * p.H + oy) * p.Wd + ox) * p.lda + c8) * 2);
+        unsigned msk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int y = oy + t / 3 - 1, x = ox + t % 3 - 1;
+          if (mv && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd) msk |= 1u << t;
+        }
+        a_msk[i] = msk;
+      } else {
+        a_off[i] = (unsigned)(nb * p.H * p.Wd);
+        a_iy[i] = mv ? oy * p.stride - 1 : -(1 << 20);
+        a_ix[i] = ox * p.stride - 1;
+      }
     }
   }
   unsigned b_off[BP];
@@ -125,26 +240,35 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
   typedef __attribute__((address_space(3))) void* lds_ptr;
   constexpr int LPT = AP + BP;                  // DMA instructions per wave per K tile
+  const int nt = (p.dbg & 4) ? 0 : kt1 - kt0;
 
-  // Request tile T (relative to kt0) into ring slot ST: every wave writes 8 rows x 128 B (1 KiB, lane-linear)
-  // per instruction.  Tiles past the end are requested with an out-of-bounds offset (zeros land in a dead slot),
-  // so the DMA count per iteration is constant and the loop body has no branch.
+  // Request tile T (relative to kt0) into ring slot ST (compile-time): every wave writes 8 rows x 128 B (1 KiB,
+  // lane-linear) per instruction.  Tiles past the end are requested out of bounds (zeros land in a dead slot), so
+  // the DMA count per iteration is constant.
   int d_tap = 0, d_cc = 0;       // conv: (tap, channel offset) of the NEXT tile to request, advanced incrementally
-  if (CONV) {
+  if (MODE != 0) {
     const int k0 = kt0 * BK;
     d_tap = k0 / p.Cin;
     d_cc = k0 - d_tap * p.Cin;
   }
+  char* const dmaA = smem + wid * (8 * BK * 2);
+  char* const dmaB = smem + NST * BM * BK * 2 + wid * (8 * BK * 2);
 #define DF_DMA(T, ST)                                                                             \
   {                                                                                             \
-    bf16_t* a_ = sA + (ST) * BM * BK + wid * (8 * BK);                                          \
-    bf16_t* b_ = sB + (ST) * BN * BK + wid * (8 * BK);                                          \
     const bool live = (T) < nt;                                                                 \
-    const unsigned k0b = (unsigned)(kt0 + (T)) * (BK * 2);                                      \
-    if (!CONV) {                                                                                \
+    const unsigned k0b = (p.dbg & 1) ? 0u : (unsigned)(kt0 + (T)) * (BK * 2);                         \
+    if (MODE == 0) {                                                                            \
+      const unsigned kb = live ? k0b : OOB;                                                     \
       _Pragma("unroll") for (int i = 0; i < AP; ++i)                                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a_ + i * 32 * BK), 16,          \
-                                                 live ? a_off[i] + k0b : OOB, 0, 0, 0);         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * 32) * (BK * 2)), 16, \
+                                                 a_off[i] + kb, 0, 0, 0);                       \
+    } else if (MODE == 1) {                                                                     \
+      const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                    \
+      const unsigned delta = (unsigned)((((ky - 1) * p.Wd + (kx - 1)) * p.lda + d_cc) * 2);     \
+      const unsigned bit = live ? (1u << d_tap) : 0u;                                           \
+      _Pragma("unroll") for (int i = 0; i < AP; ++i)                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * 32) * (BK * 2)), 16, \
+                                                 (a_msk[i] & bit) ? a_off[i] + delta : OOB, 0, 0, 0); \
     } else {                                                                                    \
       const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                    \
       _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                          \
@@ -152,17 +276,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         const bool v = live && ((unsigned)uy < (unsigned)UH) && ((unsigned)ux < (unsigned)UW);  \
         const int sy = uy >> p.ups, sx = ux >> p.ups;                                           \
         const unsigned off = ((a_off[i] + (unsigned)(sy * p.Wd + sx)) * (unsigned)p.lda + (unsigned)(d_cc + c8)) * 2u; \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a_ + i * 32 * BK), 16, v ? off : OOB, 0, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * 32) * (BK * 2)), 16, \
+                                                 v ? off : OOB, 0, 0, 0);                       \
       }                                                                                         \
+    }                                                                                           \
+    if (MODE != 0) {                                                                            \
       d_cc += BK;                                                                               \
       if (d_cc == p.Cin) {                                                                      \
         d_cc = 0;                                                                               \
         ++d_tap;                                                                                \
       }                                                                                         \
     }                                                                                           \
-    _Pragma("unroll") for (int i = 0; i < BP; ++i)                                              \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(b_ + i * 32 * BK), 16,            \
-                                               live ? b_off[i] + k0b : OOB, 0, 0, 0);           \
+    {                                                                                           \
+      const unsigned kb = live ? k0b : OOB;                                                     \
+      _Pragma("unroll") for (int i = 0; i < BP; ++i)                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(dmaB + ((ST) * BN + i * 32) * (BK * 2)), 16, \
+                                                 b_off[i] + kb, 0, 0, 0);                       \
+    }                                                                                           \
   }
 
   f32x16 acc[TM][TN];
@@ -173,31 +303,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- prologue: fill NST-1 ring slots
-  const int nt = kt1 - kt0;
-#pragma unroll
-  for (int t = 0; t < NST - 1; ++t) DF_DMA(t, t);
-
-  // LDS fragment addresses (elements) of k-step 0; k-step s toggles the chunk index by 2*s
-  int fa[TM], fb[TN], sa[TM], sb[TN];
+  // ---- LDS fragment byte offsets (slot 0) for the 4 k-steps of a tile: loop invariant
+  const char* fA[TM][4];
+  const char* fB[TN][4];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int row = wm * WTM + i * 32 + l31;
-    fa[i] = row * BK;
-    sa[i] = (row >> 1) & 7;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) fA[i][s2] = smem + (row * BK + (((2 * s2 + lh) ^ ((row >> 1) & 7)) << 3)) * 2;
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int row = wn * WTN + j * 32 + l31;
-    fb[j] = row * BK;
-    sb[j] = (row >> 1) & 7;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+      fB[j][s2] = smem + NST * BM * BK * 2 + (row * BK + (((2 * s2 + lh) ^ ((row >> 1) & 7)) << 3)) * 2;
   }
-#define DF_FRAG(DSTA, DSTB, S)                                                                    \
+#define DF_FRAG(DSTA, DSTB, S, ST)                                                                \
   {                                                                                             \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
-      DSTA[i] = *reinterpret_cast<const bf16x8*>(a + fa[i] + (((2 * (S) + lh) ^ sa[i]) << 3));  \
+      DSTA[i] = *reinterpret_cast<const bf16x8*>(fA[i][S] + (ST) * BM * BK * 2);                \
     _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
-      DSTB[j] = *reinterpret_cast<const bf16x8*>(b + fb[j] + (((2 * (S) + lh) ^ sb[j]) << 3));  \
+      DSTB[j] = *reinterpret_cast<const bf16x8*>(fB[j][S] + (ST) * BN * BK * 2);                \
   }
 #define DF_MMA(SRCA, SRCB)                                                                        \
   {                                                                                             \
@@ -205,119 +332,292 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
       _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRCA[i], SRCB[j], acc[i][j], 0, 0, 0); \
   }
+  // One K tile out of ring slot ST; refills the slot of the previous tile ((ST + NST - 1) % NST).
+#define DF_ITER(ST)                                                                               \
+  {                                                                                             \
+    wait_vmcnt<(NST - 2) * LPT>();   /* tile `it` landed: <= NST-2 younger tiles of this wave in flight */ \
+    __builtin_amdgcn_s_barrier();    /* all parts of tile `it` visible; everyone is done with tile it-1 */  \
+    bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];                                                      \
+    DF_FRAG(a0, b0, 0, ST);                                                                     \
+    DF_DMA(it + NST - 1, ((ST) + NST - 1) % NST);                                               \
+    DF_FRAG(a1, b1, 1, ST);                                                                     \
+    DF_MMA(a0, b0);                                                                             \
+    DF_FRAG(a0, b0, 2, ST);                                                                     \
+    DF_MMA(a1, b1);                                                                             \
+    DF_FRAG(a1, b1, 3, ST);                                                                     \
+    DF_MMA(a0, b0);                                                                             \
+    DF_MMA(a1, b1);                                                                             \
+    ++it;                                                                                       \
+  }
 
-  int st = 0, dst = NST - 1;
-  for (int it = 0; it < nt; ++it) {
-    // tile `it` has landed once at most (NST-2) younger tiles of this wave are still in flight
-    wait_vmcnt<(NST - 2) * LPT>();
-    __builtin_amdgcn_s_barrier();      // every wave's part of tile `it` visible; everyone is done with tile it-1
-    const bf16_t* a = sA + st * BM * BK;
-    const bf16_t* b = sB + st * BN * BK;
-    bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
-    DF_FRAG(a0, b0, 0);
-    DF_DMA(it + NST - 1, dst);         // refill the slot tile it-1 used (overlaps the first MFMAs)
-    DF_FRAG(a1, b1, 1);
-    DF_MMA(a0, b0);
-    DF_FRAG(a0, b0, 2);
-    DF_MMA(a1, b1);
-    DF_FRAG(a1, b1, 3);
-    DF_MMA(a0, b0);
-    DF_MMA(a1, b1);
-    st = (st + 1 == NST) ? 0 : st + 1;
-    dst = (dst + 1 == NST) ? 0 : dst + 1;
+  // ---- prologue: fill NST-1 ring slots
+  DF_DMA(0, 0);
+  DF_DMA(1, 1);
+  if (NST > 3) DF_DMA(2, 2);
+  if (NST > 4) DF_DMA(3, 3);
+
+  int it = 0;
+  while (it < nt) {
+    DF_ITER(0);
+    if (it >= nt) break;
+    DF_ITER(1);
+    if (it >= nt) break;
+    DF_ITER(2);
+    if (NST > 3) {
+      if (it >= nt) break;
+      DF_ITER(3 % NST);
+    }
+    if (NST > 4) {
+      if (it >= nt) break;
+      DF_ITER(4 % NST);
+    }
   }
   wait_vmcnt<0>();                     // dead-slot requests of the last iterations must land before LDS is released
 
-  // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  // All loads of a 32x32 tile (bias, per-sample bias, residual) are issued unconditionally from clamped
-  // addresses before any use, so they overlap instead of serialising behind per-element branches.
-  if (p.splitk > 1) {
-    float* part = p.partial + (long)z * p.M * p.N;
+  // ---- epilogue
+  if (p.dbg & 2) {   // tools: keep the accumulators alive, store nothing
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * WTN + j * 32 + l31;
-        if (col >= p.N) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < p.M) part[(long)row * p.N + col] = acc[i][j][r];
-        }
-      }
+      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  const bool has_bias = p.bias != nullptr, has_rb = p.rowbias != nullptr, has_res = p.res != nullptr;
-  const int nout = p.geglu ? (p.N >> 1) : p.N;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    int rowv[16], rowc[16];
+    int rowv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rowv[r] = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    epilogue_band<TN>(p, z, batch, rowv, acc[i], n0 + wn * WTN, l31);
+  }
+#endif
+}
+
+
+// Runtime-valued vmcnt wait (the immediate must be a literal): small switch over the values that occur.
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  switch (n) {
+    case 2: wait_vmcnt<2>(); break;
+    case 3: wait_vmcnt<3>(); break;
+    case 4: wait_vmcnt<4>(); break;
+    case 5: wait_vmcnt<5>(); break;
+    case 6: wait_vmcnt<6>(); break;
+    case 7: wait_vmcnt<7>(); break;
+    case 8: wait_vmcnt<8>(); break;
+    case 9: wait_vmcnt<9>(); break;
+    case 10: wait_vmcnt<10>(); break;
+    case 11: wait_vmcnt<11>(); break;
+    case 12: wait_vmcnt<12>(); break;
+    case 13: wait_vmcnt<13>(); break;
+    case 14: wait_vmcnt<14>(); break;
+    case 15: wait_vmcnt<15>(); break;
+    case 16: wait_vmcnt<16>(); break;
+    default: wait_vmcnt<2>(); break;   // conservative: waits for more than needed
+  }
+}
+
+// ===============================================================================================================
+// conv3x3 (stride 1, pad 1) with an LDS-staged HALO tile.
+//
+// The implicit-GEMM kernel above re-fetches the A operand once per tap (9x).  On this chip the L2->LDS fill rate of
+// a CU (~20 B/clk measured) is what bounds these GEMMs, so here a block owns PB spatial patches of TH x TW output
+// pixels (BM = PB*TH*TW), stages their (TH+2) x (TW+2) input halo for a 64-channel slice ONCE, and runs all 9 taps
+// out of it: per slice the block fetches HR*128 B of activations + 9 * BN*128 B of weights for 9*2*BM*BN*64 FLOP.
+// Pipeline: A halo double-buffered (slice c+1 requested during slice c), weights in a 4-deep ring requested 3 taps
+// ahead; the 9 taps are unrolled so every wait is a compile-time `vmcnt` (loads retire in issue order):
+//   wait for W(c,t):  younger = W(+1), W(+2) and, for t in {1,2,3}, the A(c+1) request issued at tap 0.
+// Zero padding and ragged edges come from out-of-bounds buffer offsets (hardware writes zeros to LDS).
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NT = 64 * WGM * WGN;          // threads
+  constexpr int RPP = NT / 8;                 // LDS rows written per DMA pass of the whole block
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int WPASS = (BN + RPP - 1) / RPP; // weight passes per tap
+  constexpr int NSTW = 4;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WGN, wn = wid % WGN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int TH = p.th, TW = p.tw, HWp = (TH + 2) * (TW + 2), PPX = TH * TW;
+  const int PB = BM / PPX;                      // patches per block
+  const int HR = PB * HWp;                      // halo rows
+  const int APASS = (HR + RPP - 1) / RPP;       // halo passes (block-uniform)
+  const int HRP = APASS * RPP;
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem);                 // [2][HRP][64]
+  bf16_t* sW = sA + 2 * HRP * BK;                               // [NSTW][max(BN,RPP)][64]
+  constexpr int WROWS = WPASS * RPP;
+
+  const int npx = p.Wd / TW, npy = p.H / TH;    // patches per image
+  const int npatch = (p.M / PPX);               // total patches (M = NB*H*W)
+  const int nbm = (npatch + PB - 1) / PB, nbn = (p.N + BN - 1) / BN;
+  const int nblk = nbm * nbn;
+  int lid;
+  {
+    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = lid % nbm, n0 = (lid / nbm) * BN;
+
+  const int z = blockIdx.z;
+  const int nchunk = p.Cin / BK;
+  int c0 = 0, c1 = nchunk;
+  if (p.splitk > 1) {
+    const int per = (nchunk + p.splitk - 1) / p.splitk;
+    c0 = z * per;
+    c1 = min(nchunk, c0 + per);
+  }
+  const int nc = max(c1 - c0, 0);
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
+
+  // ---- staging coordinates.  Thread (r0 = tid>>3, slot = tid&7) fills LDS slot `slot` of rows r0 + RPP*i with the
+  // source chunk slot ^ ((row>>1)&7)   (RPP is a multiple of 16, so the swizzle term is the same for every pass).
+  const int r0 = tid >> 3;
+  const int c8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;
+  constexpr int MAXAP = 12;
+  unsigned a_off[MAXAP];
+#pragma unroll
+  for (int i = 0; i < MAXAP; ++i) {
+    const int hr = r0 + RPP * i;                 // halo row
+    unsigned off = OOB;
+    if (i < APASS && hr < HR) {
+      const int pi = hr / HWp, rem = hr - pi * HWp;
+      const int hy = rem / (TW + 2), hx = rem - hy * (TW + 2);
+      const int g = mt * PB + pi;                // global patch id
+      if (g < npatch) {
+        const int n = g / (npy * npx), gr = g - n * (npy * npx);
+        const int y = (gr / npx) * TH + hy - 1, x = (gr % npx) * TW + hx - 1;
+        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd)
+          off = (unsigned)((((long)(n * p.H + y) * p.Wd + x) * p.lda + c8) * 2);
+      }
+    }
+    a_off[i] = off;
+  }
+  unsigned w_off[WPASS];
+#pragma unroll
+  for (int i = 0; i < WPASS; ++i) {
+    const int n = n0 + r0 + RPP * i;
+    w_off[i] = (n < p.N && r0 + RPP * i < BN) ? (unsigned)(((long)n * p.K + c8) * 2) : OOB;
+  }
+
+  // ---- MFMA row -> halo row of tap (0,0) and output pixel index
+  int hb[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * WTM + i * 32 + l31;
+    const int pi = r / PPX, rem = r - pi * PPX;
+    const int y = rem / TW, x = rem - y * TW;
+    hb[i] = pi * HWp + y * (TW + 2) + x;
+  }
+  int fb[TN], sb[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * WTN + j * 32 + l31;
+    fb[j] = row * BK;
+    sb[j] = (row >> 1) & 7;
+  }
+
+  // DMA helpers -------------------------------------------------------------------------------------------------
+  // A halo of channel slice C (absolute slice index) into buffer BUF
+#define DF_HALO_A(C, BUF)                                                                         \
+  {                                                                                             \
+    bf16_t* a_ = sA + (BUF) * HRP * BK + wid * (8 * BK);                                        \
+    const bool live = (C) < c1;                                                                 \
+    const unsigned cb = (unsigned)(C) * (BK * 2);                                               \
+    _Pragma("unroll") for (int i = 0; i < MAXAP; ++i)                                           \
+      if (i < APASS)                                                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a_ + i * RPP * BK), 16,         \
+                                                 (live && a_off[i] != OOB) ? a_off[i] + cb : OOB, 0, 0, 0); \
+  }
+  // weights of iteration IT (= slice*9 + tap, relative to c0) into ring slot ST
+#define DF_HALO_W(IT, ST)                                                                         \
+  {                                                                                             \
+    bf16_t* w_ = sW + (ST) * WROWS * BK + wid * (8 * BK);                                       \
+    const int cs_ = (IT) / 9, tp_ = (IT) - cs_ * 9;                                             \
+    const bool live = cs_ < nc;                                                                 \
+    const unsigned kb = (unsigned)(tp_ * p.Cin + (c0 + cs_) * BK) * 2u;                         \
+    _Pragma("unroll") for (int i = 0; i < WPASS; ++i)                                           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(w_ + i * RPP * BK), 16,           \
+                                               (live && w_off[i] != OOB) ? w_off[i] + kb : OOB, 0, 0, 0); \
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue: A(0), W(0..2)
+  DF_HALO_A(c0, 0);
+  DF_HALO_W(0, 0);
+  DF_HALO_W(1, 1);
+  DF_HALO_W(2, 2);
+
+  // One tap.  VM = loads of this wave allowed to be still in flight when W(c,t) must have landed.
+#define DF_TAP(T, VMEXTRA)                                                                        \
+  {                                                                                             \
+    if (VMEXTRA) wait_vmcnt_dyn(2 * WPASS + APASS);                                             \
+    else wait_vmcnt<2 * WPASS>();                                                               \
+    __builtin_amdgcn_s_barrier();                                                               \
+    const int it_ = cs * 9 + (T);                                                               \
+    const bf16_t* a = sA + (cs & 1) * HRP * BK;                                                 \
+    const bf16_t* b = sW + (it_ & 3) * WROWS * BK;                                              \
+    DF_HALO_W(it_ + 3, (it_ + 3) & 3);                                                          \
+    if ((T) == 0) DF_HALO_A(c0 + cs + 1, (cs + 1) & 1);                                         \
+    constexpr int dy_ = (T) / 3, dx_ = (T) - dy_ * 3;                                           \
+    int ha_[TM], sa_[TM];                                                                       \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                            \
+      const int hr = hb[i] + dy_ * (TW + 2) + dx_;                                              \
+      ha_[i] = hr * BK;                                                                         \
+      sa_[i] = (hr >> 1) & 7;                                                                   \
+    }                                                                                           \
+    _Pragma("unroll") for (int s = 0; s < BK / 16; ++s) {                                       \
+      bf16x8 af[TM], bfr[TN];                                                                   \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
+        af[i] = *reinterpret_cast<const bf16x8*>(a + ha_[i] + (((2 * s + lh) ^ sa_[i]) << 3));  \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
+        bfr[j] = *reinterpret_cast<const bf16x8*>(b + fb[j] + (((2 * s + lh) ^ sb[j]) << 3));   \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0); \
+    }                                                                                           \
+  }
+
+  for (int cs = 0; cs < nc; ++cs) {
+    DF_TAP(0, 0)
+    DF_TAP(1, 1)
+    DF_TAP(2, 1)
+    DF_TAP(3, 1)
+    DF_TAP(4, 0)
+    DF_TAP(5, 0)
+    DF_TAP(6, 0)
+    DF_TAP(7, 0)
+    DF_TAP(8, 0)
+  }
+  wait_vmcnt<0>();
+
+  // ---- epilogue: accumulator row -> NHWC pixel index of its output pixel
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int rowv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      rowv[r] = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      rowc[r] = min(rowv[r], p.M - 1);
+      const int rr = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int pi = rr / PPX, rem = rr - pi * PPX;
+      const int y = rem / TW, x = rem - y * TW;
+      const int g = mt * PB + pi;
+      const int n = g / (npy * npx), gr = g - n * (npy * npx);
+      rowv[r] = (g < npatch) ? (n * p.H + (gr / npx) * TH + y) * p.Wd + (gr % npx) * TW + x : p.M;
     }
-    constexpr int JS = 1;
-#pragma unroll
-    for (int j = 0; j < TN; j += JS) {
-      if (p.geglu) {
-        if constexpr (TN % 2 == 0) {
-          if (j & 1) continue;
-          const int xcol = n0 + wn * WTN + j * 32 + l31;
-          const int xc = min(xcol, p.N - 33);
-          const int ocol = (xcol >> 6) * 32 + (xcol & 63);
-          const float bx = has_bias ? p.bias[xc] : 0.f, bg = has_bias ? p.bias[xc + 32] : 0.f;
-          float v[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float xv = acc[i][j][r] * p.alpha + bx;
-            const float gv = acc[i][j + 1][r] * p.alpha + bg;
-            v[r] = xv * gelu_erf(gv);
-          }
-          if (has_res) {
-            float rr[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rr[r] = p.res[(long)batch * p.res_bs + (long)rowc[r] * p.ldr + min(ocol, nout - 1)];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] += rr[r];
-          }
-          if (xcol < p.N) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (rowv[r] < p.M) epi_store(p, batch, rowv[r], ocol, nout, v[r]);
-          }
-        }
-        continue;
-      }
-      const int col = n0 + wn * WTN + j * 32 + l31;
-      const int cc = min(col, p.N - 1);
-      const float b0 = has_bias ? p.bias[cc] : 0.f;
-      float v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] * p.alpha + b0;
-      if (has_rb) {
-        float rb_[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ri = (p.rowbias_mode == 1) ? (rowc[r] / p.rows_per_sample) : (rowc[r] % p.rows_per_sample);
-          rb_[r] = p.rowbias[(long)ri * p.ld_rowbias + cc];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += rb_[r];
-      }
-      if (has_res) {
-        float rr[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rr[r] = p.res[(long)batch * p.res_bs + (long)rowc[r] * p.ldr + cc];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += rr[r];
-      }
-      if (col < p.N) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (rowv[r] < p.M) epi_store(p, batch, rowv[r], col, nout, v[r]);
-      }
-    }
+    epilogue_band<TN>(p, z, 0, rowv, acc[i], n0 + wn * WTN, l31);
   }
 #endif
 }
@@ -345,31 +645,80 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, bool CONV>
+template <int BM, int BN, int WGM, int WGN, int NST, int MODE>
 hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   const size_t lds = (size_t)(BM + BN) * BK * 2 * NST;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, NST, CONV>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST, CONV>), dim3(nbm * nbn, 1, zdim), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE>), dim3(nbm * nbn, 1, zdim), dim3(256), lds, stream, p);
+  return hipGetLastError();
+}
+
+
+template <int BM, int BN, int WGM, int WGN>
+hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
+  constexpr int NT = 64 * WGM * WGN, RPP = NT / 8;
+  GemmParams p = pin;
+  if (!halo_patch(p.H, p.Wd, BM, &p.th, &p.tw)) return hipErrorInvalidValue;
+  const int ppx = p.th * p.tw;
+  if (ppx <= 0 || BM % ppx != 0 || p.H % p.th != 0 || p.Wd % p.tw != 0 || p.stride != 1 || p.ups != 0 || p.taps != 9)
+    return hipErrorInvalidValue;
+  const int PB = BM / ppx, HR = PB * (p.th + 2) * (p.tw + 2);
+  const int APASS = (HR + RPP - 1) / RPP;
+  if (APASS > 12) return hipErrorInvalidValue;
+  constexpr int WPASS = (BN + RPP - 1) / RPP;
+  const size_t lds = ((size_t)2 * APASS * RPP + (size_t)4 * WPASS * RPP) * BK * 2;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WGM, WGN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = lds;
+  }
+  const int npatch = p.M / ppx;
+  const int nbm = (npatch + PB - 1) / PB, nbn = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WGM, WGN>), dim3(nbm * nbn, 1, zdim), dim3(NT), lds, stream, p);
   return hipGetLastError();
 }
 
 }  // namespace
 
+bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
+  const int nk = p.K / 64;
+  if (tile < TILE_COUNT) {
+    if (p.geglu && !(tile == TILE_128x128 || tile == TILE_64x128)) return false;
+    return splitk == 1 || (batch <= 1 && nk / splitk >= 2);
+  }
+  if (tile >= TILE_ALL || p.taps != 9 || p.stride != 1 || p.ups != 0 || p.geglu || batch > 1) return false;
+  int bm, bn, th, tw;
+  gemm_tile_dims(tile, &bm, &bn);
+  if (!halo_patch(p.H, p.Wd, bm, &th, &tw)) return false;
+  const int threads = (tile == TILE_HALO_256x64) ? 512 : 256, rpp = threads / 8;
+  const int hr = (bm / (th * tw)) * (th + 2) * (tw + 2);
+  const int apass = (hr + rpp - 1) / rpp, wpass = (bn + rpp - 1) / rpp;
+  if (apass > 12) return false;
+  if (((size_t)2 * apass * rpp + (size_t)4 * wpass * rpp) * 128 > 160 * 1024) return false;
+  const int nchunk = p.Cin / 64;
+  return splitk == 1 || nchunk / splitk >= 1;
+}
+
 hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t stream) {
   const int zdim = (p.splitk > 1) ? p.splitk : (batch > 0 ? batch : 1);
   hipError_t e;
-  const bool conv = p.taps == 9;
-#define DF_CASE(T, BM, BN, WGM, WGN, NST)                                              \
-  case T:                                                                             \
-    e = conv ? launch_cfg<BM, BN, WGM, WGN, NST, true>(p, zdim, stream)               \
-             : launch_cfg<BM, BN, WGM, WGN, NST, false>(p, zdim, stream);             \
+  // MODE 0: linear / 1x1;  1: 3x3 stride 1 (tap offsets are linear, 2 VALU per request);  2: 3x3 stride 2 / upsampled
+  const int mode = (p.taps != 9) ? 0 : ((p.stride == 1 && !p.ups) ? 1 : 2);
+#define DF_CASE(T, BM, BN, WGM, WGN, NST)                                                              \
+  case T:                                                                                             \
+    e = mode == 0 ? launch_cfg<BM, BN, WGM, WGN, NST, 0>(p, zdim, stream)                             \
+                  : (mode == 1 ? launch_cfg<BM, BN, WGM, WGN, NST, 1>(p, zdim, stream)                \
+                               : launch_cfg<BM, BN, WGM, WGN, NST, 2>(p, zdim, stream));              \
     break;
   switch (tile_cfg) {
     DF_CASE(TILE_128x128, 128, 128, 2, 2, 3)
@@ -377,6 +726,9 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
     DF_CASE(TILE_64x128, 64, 128, 2, 2, 4)
     DF_CASE(TILE_64x64, 64, 64, 2, 2, 4)
     DF_CASE(TILE_32x128, 32, 128, 1, 4, 4)
+    case TILE_HALO_128x64: e = launch_halo<128, 64, 2, 2>(p, zdim, stream); break;
+    case TILE_HALO_256x64: e = launch_halo<256, 64, 4, 2>(p, zdim, stream); break;
+    case TILE_HALO_128x128: e = launch_halo<128, 128, 2, 2>(p, zdim, stream); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
