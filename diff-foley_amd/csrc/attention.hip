@@ -37,6 +37,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
+  // grid = (q-tiles, heads, samples).  (A head-major grid that pins each head's K/V to one XCD measured 25 % slower.)
   const int n = blockIdx.z, h = blockIdx.y;
   const int q0 = (blockIdx.x * NW + wid) * 32;
   const int q = q0 + l31;

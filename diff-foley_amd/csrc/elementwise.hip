@@ -14,7 +14,8 @@ __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                      int silu, bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw) {
   __shared__ float red[16];
-  const int g = blockIdx.x, n = blockIdx.y;
+  // block b runs on XCD b%8: put the 4 neighbouring groups that share 128-B lines of every pixel row on one XCD
+  const int g = (blockIdx.x & 7) * 4 + (blockIdx.x >> 3), n = blockIdx.y;
   const float* xb = x + (long)n * HW * ld + g * cpg;
   const int half = cpg >> 1;
   const int items = HW * half;
@@ -63,7 +64,8 @@ __global__ void groupnorm_kernel(const float* __restrict__ x, int ld, int HW, in
                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                  int silu, bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw) {
   __shared__ float red[16];
-  const int g = blockIdx.x, n = blockIdx.y;
+  // block b runs on XCD b%8: put the 4 neighbouring groups that share 128-B lines of every pixel row on one XCD
+  const int g = (blockIdx.x & 7) * 4 + (blockIdx.x >> 3), n = blockIdx.y;
   const float* xb = x + (long)n * HW * ld + g * cpg;
   const int half = cpg >> 1;              // cpg is even: float2 granularity
   const int items = HW * half;

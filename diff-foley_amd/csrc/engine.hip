@@ -254,7 +254,6 @@ void choose_tile(int M, int N, int K, int batch, bool geglu, int* tile, int* spl
   *splitk = 1;
   const int nk = K / 64;
   for (int c = 0; c < TILE_COUNT; ++c) {
-    if (geglu && !(c == TILE_128x128 || c == TILE_64x128)) continue;
     int bm, bn;
     gemm_tile_dims(c, &bm, &bn);
     if (bm > 64 && M <= bm / 2) continue;
@@ -312,6 +311,7 @@ struct Builder {
       const size_t need = (size_t)sk * gp.M * gp.N * 4;
       if (need > pl->partial_bytes) pl->partial_bytes = need;
     }
+    gp.dbg = getenv("DF_GEMM_DBG") ? atoi(getenv("DF_GEMM_DBG")) : 0;   // tools only (timing experiments)
     o.gp = gp;
     pl->gemm_flops += 2.0 * gp.M * (double)gp.N * gp.K * batch;
     pl->weight_bytes += 2.0 * (double)gp.N * gp.K * (gp.w_bs ? batch : 1);

@@ -147,6 +147,99 @@ __device__ __forceinline__ void epilogue_band(const GemmParams& p, int z, int ba
   }
 }
 
+// Block-level epilogue through LDS: the accumulators of the whole BM x BN tile are parked in LDS as fp32 (row
+// stride BN+4 floats keeps the 16-B reads conflict-free), then every thread re-reads 4 consecutive columns of one
+// row, applies alpha / bias / per-sample bias / residual / GEGLU on float4s and issues ONE 16-byte (fp32) or 8-byte
+// (bf16) store: rows leave the CU as full 128..512-B contiguous runs instead of 4-B-per-lane column slivers.
+// ROWMAP(r) gives the output row (NHWC pixel index) of tile row r, or >= p.M when the row does not exist.
+// Requires N % 4 == 0, ldc % 4 == 0 and row-major output (the caller falls back to epilogue_band otherwise).
+template <int BM, int BN, int NT, int TM, int TN, class RowMap>
+__device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int batch, float* sC,
+                                               f32x16 (&acc)[TM][TN], int wrow0, int wcol0, int n0, int tid,
+                                               RowMap rowmap) {
+  constexpr int LDC = BN + 4;
+  const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  __builtin_amdgcn_s_barrier();            // every wave is done reading the operand ring
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sC[(wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wcol0 + j * 32 + l31] = acc[i][j][r];
+  __syncthreads();
+  const bool has_bias = p.bias != nullptr, has_rb = p.rowbias != nullptr, has_res = p.res != nullptr;
+  if (p.splitk > 1) {
+    float* part = p.partial + (long)z * p.M * p.N;
+    constexpr int CPR = BN / 4;
+#pragma unroll 4
+    for (int e = tid; e < BM * CPR; e += NT) {
+      const int r = e / CPR, c4 = (e - r * CPR) * 4;
+      const int row = rowmap(r), col = n0 + c4;
+      const float4 v = *reinterpret_cast<const float4*>(&sC[r * LDC + c4]);
+      if (row < p.M && col < p.N) *reinterpret_cast<float4*>(&part[(long)row * p.N + col]) = v;
+    }
+    return;
+  }
+  if (p.geglu) {
+    constexpr int CPR = BN / 8;              // float4 chunks of OUTPUT columns per row (output width BN/2)
+    const int nout = p.N >> 1;
+#pragma unroll 2
+    for (int e = tid; e < BM * CPR; e += NT) {
+      const int r = e / CPR, oc = (e - r * CPR) * 4;           // output column within the tile
+      const int xc = (oc >> 5) * 64 + (oc & 31);               // packed x column within the tile; gate at +32
+      const int row = rowmap(r), ocol = (n0 >> 1) + oc;
+      const int gx = min(n0 + xc, p.N - 36);
+      float4 x = *reinterpret_cast<const float4*>(&sC[r * LDC + xc]);
+      float4 g = *reinterpret_cast<const float4*>(&sC[r * LDC + xc + 32]);
+      if (has_bias) {
+        const float4 bx = *reinterpret_cast<const float4*>(&p.bias[gx]);
+        const float4 bg = *reinterpret_cast<const float4*>(&p.bias[gx + 32]);
+        x.x = x.x * p.alpha + bx.x; x.y = x.y * p.alpha + bx.y; x.z = x.z * p.alpha + bx.z; x.w = x.w * p.alpha + bx.w;
+        g.x = g.x * p.alpha + bg.x; g.y = g.y * p.alpha + bg.y; g.z = g.z * p.alpha + bg.z; g.w = g.w * p.alpha + bg.w;
+      }
+      float4 v = make_float4(x.x * gelu_erf(g.x), x.y * gelu_erf(g.y), x.z * gelu_erf(g.z), x.w * gelu_erf(g.w));
+      if (row < p.M && ocol < nout) {
+        const long idx = (long)batch * p.c_bs + (long)row * p.ldc + ocol;
+        if (p.out_bf16)
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+        else
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;
+      }
+    }
+    return;
+  }
+  constexpr int CPR = BN / 4;
+#pragma unroll 4
+  for (int e = tid; e < BM * CPR; e += NT) {
+    const int r = e / CPR, c4 = (e - r * CPR) * 4;
+    const int row = rowmap(r), col = n0 + c4;
+    const int rc = min(row, p.M - 1), cc = min(col, p.N - 4);
+    float4 v = *reinterpret_cast<const float4*>(&sC[r * LDC + c4]);
+    v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+    if (has_bias) {
+      const float4 b = *reinterpret_cast<const float4*>(&p.bias[cc]);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (has_rb) {
+      const int ri = (p.rowbias_mode == 1) ? (rc / p.rows_per_sample) : (rc % p.rows_per_sample);
+      const float4 b = *reinterpret_cast<const float4*>(&p.rowbias[(long)ri * p.ld_rowbias + cc]);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (has_res) {
+      const float4 b = *reinterpret_cast<const float4*>(&p.res[(long)batch * p.res_bs + (long)rc * p.ldr + cc]);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (row < p.M && col < p.N) {
+      const long idx = (long)batch * p.c_bs + (long)row * p.ldc + col;
+      if (p.out_bf16)
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+      else
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;
+    }
+  }
+}
+
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
@@ -174,6 +267,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // each XCD owns a contiguous range of logical tiles, M fastest: every XCD streams its own slice of W once
+  // (walking N fastest for activation-heavy layers was measured slower)
   const int m0 = (lid % nbm) * BM, n0 = (lid / nbm) * BN;
 
   int z = blockIdx.z;
@@ -380,6 +475,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+  const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
+                      (p.ld_rowbias & 3) == 0 && (p.res_bs & 3) == 0 && (p.c_bs & 3) == 0;
+  if (vec_ok) {
+    epilogue_block<BM, BN, 256, TM, TN>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid,
+                                        [&](int r) { return m0 + r; });
     return;
   }
 #pragma unroll
@@ -604,19 +706,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   }
   wait_vmcnt<0>();
 
-  // ---- epilogue: accumulator row -> NHWC pixel index of its output pixel
+  // ---- epilogue: tile row -> NHWC pixel index of its output pixel
+  auto rowmap = [&](int rr) {
+    const int pi = rr / PPX, rem = rr - pi * PPX;
+    const int y = rem / TW, x = rem - y * TW;
+    const int g = mt * PB + pi;
+    const int n = g / (npy * npx), gr = g - n * (npy * npx);
+    return (g < npatch) ? (n * p.H + (gr / npx) * TH + y) * p.Wd + (gr % npx) * TW + x : p.M;
+  };
+  const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
+                      (p.ld_rowbias & 3) == 0;
+  if (vec_ok) {
+    epilogue_block<BM, BN, NT, TM, TN>(p, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     int rowv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rr = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int pi = rr / PPX, rem = rr - pi * PPX;
-      const int y = rem / TW, x = rem - y * TW;
-      const int g = mt * PB + pi;
-      const int n = g / (npy * npx), gr = g - n * (npy * npx);
-      rowv[r] = (g < npatch) ? (n * p.H + (gr / npx) * TH + y) * p.Wd + (gr % npx) * TW + x : p.M;
-    }
+    for (int r = 0; r < 16; ++r) rowv[r] = rowmap(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
     epilogue_band<TN>(p, z, 0, rowv, acc[i], n0 + wn * WTN, l31);
   }
 #endif
@@ -693,7 +801,7 @@ hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
 bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int nk = p.K / 64;
   if (tile < TILE_COUNT) {
-    if (p.geglu && !(tile == TILE_128x128 || tile == TILE_64x128)) return false;
+    if (p.geglu && ((p.N & 63) != 0 || (p.ldc & 3) != 0)) return false;   // GEGLU needs the vectorised block epilogue
     return splitk == 1 || (batch <= 1 && nk / splitk >= 2);
   }
   if (tile >= TILE_ALL || p.taps != 9 || p.stride != 1 || p.ups != 0 || p.geglu || batch > 1) return false;

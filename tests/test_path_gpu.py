@@ -2,9 +2,10 @@
 (i) the CPU oracle on the same seeded inputs and (ii) the golden vectors produced by the reference itself.
 
 Tolerances (bf16 MFMA operands, fp32 accumulation / statistics / residual stream; oracle and reference are fp32):
-  * one UNet / VAE forward:         rel-L2 <= 2e-2  (measured ~5e-3)
-  * short sampler trajectories:     rel-L2 <= 5e-2
-  * decoded mel, north-star metric: MAE reported and bounded (see test_full_ddim25_mel_mae)
+  * one UNet / VAE forward:         rel-L2 <= 2e-2  (measured 1.2e-2 / 7e-3 at full size)
+  * sampler trajectories:           rel-L2 <= 5e-2  (measured 5e-3 .. 7e-3 over 25-50 full-size steps)
+  * decoded mel, north-star metric: MAE < 1e-3 in units of the reference mel's range (measured 8.8e-4), and
+                                    < 1.5 % of its standard deviation in absolute terms (test_full_ddim25_mel_mae)
 """
 import numpy as np
 import pytest
@@ -220,9 +221,14 @@ def test_full_ddim25_mel_mae(full):
         mel = full.decode_first_stage(z)[:, 0].cpu()
         zr, mr = g[f"ddim25_z_{seed}"], g[f"ddim25_mel_{seed}"]
         mae = (mel - mr).abs().mean().item()
+        span = (mr.max() - mr.min()).item()
         print(f"seed {seed}: z rel-L2 {rel_l2(z.cpu(), zr):.3e}; mel MAE {mae:.3e} (mel std {mr.std().item():.3f}, "
-              f"range [{mr.min().item():.2f}, {mr.max().item():.2f}])")
-        assert mae < 2e-2 * max(1.0, mr.std().item())
+              f"range [{mr.min().item():.2f}, {mr.max().item():.2f}]); MAE on the [0,1]-normalised mel {mae / span:.3e}")
+        # north-star tolerance: mel-spec MAE < 1e-3 with the mel in [0,1] (data_preprocess/wav2spec.py:142-155 clips the
+        # training mels to [0,1]).  The random-weight decoder is not confined to [0,1], so the reference mel's own
+        # range is used as the unit; the absolute bound keeps the bf16-vs-fp32 error at < 1.5 % of the signal's sigma.
+        assert mae / span < 1e-3
+        assert mae < 1.5e-2 * mr.std().item()
 
 
 def test_full_dpm50_vs_golden(full):
@@ -235,9 +241,11 @@ def test_full_dpm50_vs_golden(full):
                                             unconditional_conditioning=uc, x_T=xT.clone())
     assert inter is None
     mel = full.decode_first_stage(z)[:, 0].cpu()
-    mae = (mel - g["dpm50_mel_21"]).abs().mean().item()
-    print(f"DPM-50: z rel-L2 {rel_l2(z.cpu(), g['dpm50_z_21']):.3e}; mel MAE {mae:.3e}")
-    assert mae < 2e-2 * max(1.0, g["dpm50_mel_21"].std().item())
+    mr = g["dpm50_mel_21"]
+    mae = (mel - mr).abs().mean().item()
+    span = (mr.max() - mr.min()).item()
+    print(f"DPM-50: z rel-L2 {rel_l2(z.cpu(), g['dpm50_z_21']):.3e}; mel MAE {mae:.3e}; normalised {mae / span:.3e}")
+    assert mae / span < 1e-3 and mae < 1.5e-2 * mr.std().item()
 
 
 def test_full_batch4_matches_batch1(full):
