@@ -1,0 +1,355 @@
+// Input-gradient (VJP) kernels for the alignment classifier (double guidance needs d log p / d x,
+// ddim.py:333-341 / dpm_solver.py:1340-1349).  Only gradients w.r.t. activations are computed; the backward
+// data GEMMs (conv^T, Linear^T) reuse gemm_bf16_kernel with transposed / flipped weight packings.
+// Gradients travel as fp32 NHWC; every kernel that feeds a GEMM also emits the bf16 copy the GEMM consumes.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------ GroupNorm(32) [+SiLU] backward
+// y = act(xhat * gamma + beta), xhat = (x - mean) * rstd over the (HW x cpg) slab of one (sample, group).
+//   g_i   = dy_i * act'(.) * gamma_c
+//   dx_i  = rstd * (g_i - mean(g) - xhat_i * mean(g * xhat))       [+ addend_i]
+// One block per (group, sample); statistics are recomputed from the saved fp32 input.
+__global__ void groupnorm_bwd_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                     int silu, const float* __restrict__ dy, int lddy, const float* __restrict__ addend,
+                                     int ldadd, float* __restrict__ dx, int lddx, bf16_t* __restrict__ dx_b16) {
+  __shared__ float red[16];
+  const int g = (blockIdx.x & 7) * 4 + (blockIdx.x >> 3), n = blockIdx.y;
+  const long rowbase = (long)n * HW;
+  const int c0 = g * cpg, items = HW * cpg;
+  const float cnt = (float)items;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < items; i += blockDim.x) {
+    const int px = i / cpg, j = i - px * cpg;
+    s += x[(rowbase + px) * ld + c0 + j];
+  }
+  const float mean = block_sum(s, red) / cnt;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < items; i += blockDim.x) {
+    const int px = i / cpg, j = i - px * cpg;
+    const float d = x[(rowbase + px) * ld + c0 + j] - mean;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(block_sum(q, red) / cnt + eps);
+  float sg = 0.f, sgx = 0.f;
+  for (int i = threadIdx.x; i < items; i += blockDim.x) {
+    const int px = i / cpg, j = i - px * cpg, c = c0 + j;
+    const float xh = (x[(rowbase + px) * ld + c] - mean) * rstd;
+    float gi = dy[(rowbase + px) * lddy + c];
+    if (silu) {
+      const float u = xh * gamma[c] + beta[c];
+      const float sig = 1.0f / (1.0f + __expf(-u));
+      gi *= sig * (1.0f + u * (1.0f - sig));
+    }
+    gi *= gamma[c];
+    sg += gi;
+    sgx += gi * xh;
+  }
+  const float mg = block_sum(sg, red) / cnt;
+  const float mgx = block_sum(sgx, red) / cnt;
+  for (int i = threadIdx.x; i < items; i += blockDim.x) {
+    const int px = i / cpg, j = i - px * cpg, c = c0 + j;
+    const float xh = (x[(rowbase + px) * ld + c] - mean) * rstd;
+    float gi = dy[(rowbase + px) * lddy + c];
+    if (silu) {
+      const float u = xh * gamma[c] + beta[c];
+      const float sig = 1.0f / (1.0f + __expf(-u));
+      gi *= sig * (1.0f + u * (1.0f - sig));
+    }
+    gi *= gamma[c];
+    float r = rstd * (gi - mg - xh * mgx);
+    if (addend) r += addend[(rowbase + px) * ldadd + c];
+    dx[(rowbase + px) * lddx + c] = r;
+    if (dx_b16) dx_b16[(rowbase + px) * C + c] = f2bf(r);
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward (one wave per row)
+//   g = dy * gamma ; dx = rstd * (g - mean(g) - xhat * mean(g * xhat))  [+ addend]
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int rows, int C,
+                                                            const float* __restrict__ gamma, float eps,
+                                                            const float* __restrict__ dy,
+                                                            const float* __restrict__ addend,
+                                                            float* __restrict__ dx, bf16_t* __restrict__ dx_b16) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long)row * C;
+  const float* dr = dy + (long)row * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = xr[c] - mean;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  float sg = 0.f, sgx = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float gi = dr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
+    sg += gi;
+    sgx += gi * xh;
+  }
+  const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+  for (int c = lane; c < C; c += 64) {
+    const float gi = dr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
+    float r = rstd * (gi - mg - xh * mgx);
+    if (addend) r += addend[(long)row * C + c];
+    dx[(long)row * C + c] = r;
+    if (dx_b16) dx_b16[(long)row * C + c] = f2bf(r);
+  }
+}
+
+// ------------------------------------------------------------------ GEGLU forward (unfused) / backward
+// u = [x | gate] bf16 [rows][2H] (bias already added); y = x * gelu(gate)
+__global__ void geglu_fwd_kernel(const bf16_t* __restrict__ u, bf16_t* __restrict__ y, long rows, int H) {
+  const long total = rows * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / H;
+    const int c = (int)(i - r * H);
+    const float xv = bf2f(u[r * 2 * H + c]), gv = bf2f(u[r * 2 * H + H + c]);
+    y[i] = f2bf(xv * gelu_erf(gv));
+  }
+}
+// du = [dy * gelu(g) | dy * x * gelu'(g)],  gelu'(g) = Phi(g) + g * phi(g)
+__global__ void geglu_bwd_kernel(const bf16_t* __restrict__ u, const float* __restrict__ dy,
+                                 bf16_t* __restrict__ du, long rows, int H) {
+  const long total = rows * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / H;
+    const int c = (int)(i - r * H);
+    const float xv = bf2f(u[r * 2 * H + c]), gv = bf2f(u[r * 2 * H + H + c]);
+    const float d = dy[i];
+    const float Phi = 0.5f * (1.0f + erf_as(gv * 0.70710678118654752440f));
+    const float phi = 0.39894228040143267794f * __expf(-0.5f * gv * gv);
+    du[r * 2 * H + c] = f2bf(d * gv * Phi);
+    du[r * 2 * H + H + c] = f2bf(d * xv * (Phi + gv * phi));
+  }
+}
+
+// ------------------------------------------------------------------ attention backward (small T, VALU)
+// One block per (head, sample).  Phase A: thread per query row -> softmax statistics (m, l), delta = sum_j p dp,
+// and dQ.  Phase B: thread per key -> dK, dV from the saved row statistics.  K / V / Q / dO are staged in LDS as
+// fp32; all loops are plain FMAs (the classifier's attention is ~0.1 % of its FLOPs).
+template <int D>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const bf16_t* __restrict__ Q, int ldq,
+                                                            const bf16_t* __restrict__ K, int ldk,
+                                                            const bf16_t* __restrict__ Vt, int ldvt,
+                                                            const float* __restrict__ dO, int lddo,
+                                                            bf16_t* __restrict__ dQ, int lddq, bf16_t* __restrict__ dK,
+                                                            int lddk, bf16_t* __restrict__ dV, int lddv, int heads,
+                                                            int Tq, int Tk, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sK = sm;                    // [Tk][D+1]
+  float* sV = sK + Tk * (D + 1);     // [Tk][D+1]
+  float* sQ = sV + Tk * (D + 1);     // [Tq][D+1]
+  float* sD = sQ + Tq * (D + 1);     // [Tq][D+1]  dO
+  float* sM = sD + Tq * (D + 1);     // [Tq] row max
+  float* sL = sM + Tq;               // [Tq] row sum
+  float* sDel = sL + Tq;             // [Tq] delta
+  const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  for (int i = tid; i < Tk * D; i += 256) {
+    const int j = i / D, d = i - j * D;
+    sK[j * (D + 1) + d] = bf2f(K[((long)n * Tk + j) * ldk + h * D + d]);
+    sV[j * (D + 1) + d] = bf2f(Vt[((long)n * heads + h) * D * ldvt + (long)d * ldvt + j]);
+  }
+  for (int i = tid; i < Tq * D; i += 256) {
+    const int q = i / D, d = i - q * D;
+    sQ[q * (D + 1) + d] = bf2f(Q[((long)n * Tq + q) * ldq + h * D + d]);
+    sD[q * (D + 1) + d] = dO[((long)n * Tq + q) * lddo + h * D + d];
+  }
+  __syncthreads();
+  // ---- phase A
+  for (int q = tid; q < Tq; q += 256) {
+    float qv[D], dv[D], dq[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      qv[d] = sQ[q * (D + 1) + d];
+      dv[d] = sD[q * (D + 1) + d];
+      dq[d] = 0.f;
+    }
+    float m = -INFINITY;
+    for (int j = 0; j < Tk; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) s += qv[d] * sK[j * (D + 1) + d];
+      m = fmaxf(m, s * scale);
+    }
+    float l = 0.f, del = 0.f;
+    for (int j = 0; j < Tk; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        s += qv[d] * sK[j * (D + 1) + d];
+        dp += dv[d] * sV[j * (D + 1) + d];
+      }
+      const float e = __expf(s * scale - m);
+      l += e;
+      del += e * dp;
+    }
+    del /= l;
+    for (int j = 0; j < Tk; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        s += qv[d] * sK[j * (D + 1) + d];
+        dp += dv[d] * sV[j * (D + 1) + d];
+      }
+      const float pj = __expf(s * scale - m) / l;
+      const float ds = pj * (dp - del) * scale;
+#pragma unroll
+      for (int d = 0; d < D; ++d) dq[d] += ds * sK[j * (D + 1) + d];
+    }
+    sM[q] = m;
+    sL[q] = l;
+    sDel[q] = del;
+#pragma unroll
+    for (int d = 0; d < D; ++d) dQ[((long)n * Tq + q) * lddq + h * D + d] = f2bf(dq[d]);
+  }
+  if (!dK) return;
+  __syncthreads();
+  // ---- phase B
+  for (int j = tid; j < Tk; j += 256) {
+    float kv[D], vv[D], dk[D], dvv[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      kv[d] = sK[j * (D + 1) + d];
+      vv[d] = sV[j * (D + 1) + d];
+      dk[d] = 0.f;
+      dvv[d] = 0.f;
+    }
+    for (int q = 0; q < Tq; ++q) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        s += sQ[q * (D + 1) + d] * kv[d];
+        dp += sD[q * (D + 1) + d] * vv[d];
+      }
+      const float pj = __expf(s * scale - sM[q]) / sL[q];
+      const float ds = pj * (dp - sDel[q]) * scale;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        dk[d] += ds * sQ[q * (D + 1) + d];
+        dvv[d] += pj * sD[q * (D + 1) + d];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      dK[((long)n * Tk + j) * lddk + h * D + d] = f2bf(dk[d]);
+      dV[((long)n * Tk + j) * lddv + h * D + d] = f2bf(dvv[d]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ classifier head backward
+// p = sigmoid(z), objective sum log p  ->  dz = 1 - p;  pooled = mean_px(h);  z = w . pooled + b
+//   dh[n][px][c] = (1 - p_n) * w[c] / HW          (out_channels == 1)
+__global__ void cls_head_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ w, float* __restrict__ dh,
+                                    bf16_t* __restrict__ dh_b16, int N, int HW, int C) {
+  const long total = (long)N * HW * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int n = (int)(i / ((long)HW * C));
+    const float v = (1.0f - prob[n]) * w[c] / (float)HW;
+    dh[i] = v;
+    if (dh_b16) dh_b16[i] = f2bf(v);
+  }
+}
+
+// Linear weight [O][I] fp32 -> transposed bf16 [I][O]
+__global__ void pack_linear_t_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int O, int I, int ldo,
+                                     int off) {
+  const long total = (long)O * I;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int o = (int)(e % O);
+    const int i = (int)(e / O);
+    out[(long)i * ldo + off + o] = f2bf(w[(long)o * I + i]);
+  }
+}
+// conv OIHW fp32 -> backward-data packing bf16 [I][ky'][kx'][Opad] with (ky', kx') = (2-ky, 2-kx)
+__global__ void pack_conv_bwd_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int O, int I, int Opad) {
+  const long total = (long)I * 9 * Opad;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int o = (int)(e % Opad);
+    long r = e / Opad;
+    const int kx = (int)(r % 3);
+    r /= 3;
+    const int ky = (int)(r % 3);
+    const int i = (int)(r / 3);
+    out[e] = (o < O) ? f2bf(w[(((long)o * I + i) * 3 + (2 - ky)) * 3 + (2 - kx)]) : (bf16_t)0;
+  }
+}
+
+inline int grid_for(long n, int block = 256, int cap = 4096) {
+  long g = (n + block - 1) / block;
+  return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+hipError_t launch_groupnorm_bwd(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
+                                float eps, int silu, const float* dy, int lddy, const float* addend, int ldadd,
+                                float* dx, int lddx, uint16_t* dx_b16, hipStream_t s) {
+  if (C % 32 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(32, N), dim3(512), 0, s, x, ld, HW, C, C / 32, gamma, beta, eps, silu, dy,
+                     lddy, addend, ldadd, dx, lddx, dx_b16);
+  return hipGetLastError();
+}
+
+hipError_t launch_layernorm_bwd(const float* x, int rows, int C, const float* gamma, float eps, const float* dy,
+                                const float* addend, float* dx, uint16_t* dx_b16, hipStream_t s) {
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, C, gamma, eps, dy, addend, dx,
+                     dx_b16);
+  return hipGetLastError();
+}
+
+hipError_t launch_geglu_fwd(const uint16_t* u, uint16_t* y, long rows, int H, hipStream_t s) {
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(rows * H)), dim3(256), 0, s, u, y, rows, H);
+  return hipGetLastError();
+}
+hipError_t launch_geglu_bwd(const uint16_t* u, const float* dy, uint16_t* du, long rows, int H, hipStream_t s) {
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(rows * H)), dim3(256), 0, s, u, dy, du, rows, H);
+  return hipGetLastError();
+}
+
+hipError_t launch_attention_bwd(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt,
+                                const float* dO, int lddo, uint16_t* dQ, int lddq, uint16_t* dK, int lddk, uint16_t* dV,
+                                int lddv, int N, int heads, int D, int Tq, int Tk, float scale, hipStream_t s) {
+  const size_t lds = ((size_t)(2 * Tk + 2 * Tq) * (D + 1) + 3 * (size_t)Tq) * 4;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+#define DF_ABWD(DD)                                                                                                   \
+  {                                                                                                                   \
+    static size_t attr = 0;                                                                                           \
+    if (lds > attr) {                                                                                                 \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel<DD>),                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+      if (e != hipSuccess) return e;                                                                                  \
+      attr = lds;                                                                                                     \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(attention_bwd_kernel<DD>, dim3(heads, N), dim3(256), lds, s, Q, ldq, K, ldk, Vt, ldvt, dO, lddo, \
+                       dQ, lddq, dK, lddk, dV, lddv, heads, Tq, Tk, scale);                                           \
+  }
+  if (D == 32) DF_ABWD(32)
+  else if (D == 64) DF_ABWD(64)
+  else return hipErrorInvalidValue;
+#undef DF_ABWD
+  return hipGetLastError();
+}
+
+hipError_t launch_cls_head_bwd(const float* prob, const float* w, float* dh, uint16_t* dh_b16, int N, int HW, int C,
+                               hipStream_t s) {
+  hipLaunchKernelGGL(cls_head_bwd_kernel, dim3(grid_for((long)N * HW * C)), dim3(256), 0, s, prob, w, dh, dh_b16, N, HW, C);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_linear_t(const float* w, uint16_t* out, int O, int I, int ldo, int off, hipStream_t s) {
+  hipLaunchKernelGGL(pack_linear_t_kernel, dim3(grid_for((long)O * I)), dim3(256), 0, s, w, out, O, I, ldo, off);
+  return hipGetLastError();
+}
+hipError_t launch_pack_conv_bwd(const float* w, uint16_t* out, int O, int I, int Opad, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_bwd_kernel, dim3(grid_for((long)I * 9 * Opad)), dim3(256), 0, s, w, out, O, I, Opad);
+  return hipGetLastError();
+}

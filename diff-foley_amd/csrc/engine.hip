@@ -60,6 +60,7 @@ struct RunArgs {
   const float* t = nullptr;      // external timesteps
   const float* aux = nullptr;    // external context / features
   float* out = nullptr;          // external output
+  float* out2 = nullptr;         // optional second external output (classifier probability in the grad plan)
   float scale = 1.f;             // guidance scale
 };
 
@@ -219,6 +220,36 @@ struct df_ctx {
     const int O = (int)t.shape[0], I = (int)t.shape[1];
     bf16_t* o = (bf16_t*)pmalloc((size_t)O * 9 * ipad * 2);
     HIPCHK(launch_pack_conv_weight(t.d, o, O, I, 3, 3, ipad, pack_stream));
+    packed[key] = o;
+    return o;
+  }
+  // Linear weights [O_j][I] stacked along O and transposed -> bf16 [I][sum O_j]  (backward-data operand)
+  const bf16_t* w_stack_t(const std::string& key, const std::vector<std::string>& names) {
+    auto it = packed.find(key);
+    if (it != packed.end()) return (const bf16_t*)it->second;
+    int otot = 0;
+    const int I = (int)rt(names[0]).shape[1];
+    for (auto& n : names) otot += (int)rt(n).shape[0];
+    bf16_t* o = (bf16_t*)pmalloc((size_t)I * otot * 2);
+    int off = 0;
+    for (auto& n : names) {
+      const RawT& t = rt(n);
+      HIPCHK(launch_pack_linear_t(t.d, o, (int)t.shape[0], I, otot, off, pack_stream));
+      off += (int)t.shape[0];
+    }
+    packed[key] = o;
+    return o;
+  }
+  // 3x3 conv weight OIHW -> backward-data packing bf16 [I][ky'][kx'][O] (flipped taps)
+  const bf16_t* w_conv3_bwd(const std::string& name) {
+    const std::string key = name + "#c3bwd";
+    auto it = packed.find(key);
+    if (it != packed.end()) return (const bf16_t*)it->second;
+    const RawT& t = rt(name);
+    const int O = (int)t.shape[0], I = (int)t.shape[1];
+    if (O % 64 != 0) fail("'%s': backward-data packing needs Cout %% 64 == 0", name.c_str());
+    bf16_t* o = (bf16_t*)pmalloc((size_t)I * 9 * O * 2);
+    HIPCHK(launch_pack_conv_bwd(t.d, o, O, I, O, pack_stream));
     packed[key] = o;
     return o;
   }
@@ -840,6 +871,391 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Alignment classifier: forward + input gradient  g = d sum(log p) / d x   (cal_classifier_loglikelihood_grad,
+// ddim.py:333-341; cond_grad_fn_classifier, dpm_solver.py:1340-1349).  The encoder is a chain, so the plan is built
+// with a tape: every forward module pushes a closure that, given the gradient w.r.t. its output, appends the
+// backward ops and returns the gradient w.r.t. its input.  Nothing is freed during the forward (the saved
+// activations are the backward's operands).  Only activation gradients are formed -- weights are constants here.
+void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
+  const df_unet_config& u = c->ccfg;
+  const std::string pre = "classifier.model.";
+  Builder b{c, pl, pre, 1};
+  UNetTopo topo = make_topo(u, true);
+  const int mc = u.model_channels, temb = 4 * mc, HW = H * W, heads = u.num_heads, Dc = u.context_dim;
+  if (u.out_channels != 1) fail("classifier gradient: out_channels must be 1");
+
+  auto cast_rows = [&](const F32& x) { return b.cast2d(x); };
+  auto f32buf = [&](int rows, int C) { return F32{b.buf<float>((size_t)rows * C), rows, C, C}; };
+  // dX = dY . W  for y = x W^T : plain GEMM against the transposed packing
+  auto lin_bwd = [&](const bf16_t* dyb, int M, int O, const bf16_t* wt, int I, const char* tag) {
+    F32 dx = f32buf(M, I);
+    GemmParams g = Builder::gp_linear(dyb, M, O, wt, I);
+    Builder::out_f32(g, dx.p, I);
+    b.gemm(g, 1, tag);
+    return dx;
+  };
+  // backward-data of a stride-1 3x3 conv: conv of dY with flipped, transposed weights
+  auto conv_bwd = [&](const bf16_t* dyb, int hh, int ww, int O, const std::string& wname, int I, const char* tag) {
+    F32 dx = f32buf(N * hh * ww, I);
+    GemmParams g = Builder::gp_conv3(dyb, N, hh, ww, O, c->w_conv3_bwd(wname), I, 1, 0);
+    Builder::out_f32(g, dx.p, I);
+    b.gemm(g, 1, tag);
+    return dx;
+  };
+  auto gn_bwd = [&](const F32& x, const std::string& p, float eps, int silu, const F32& dy, const F32* addend,
+                    bool want_b16, bf16_t** b16) {
+    F32 dx = f32buf(x.rows, x.C);
+    bf16_t* db = want_b16 ? b.buf<bf16_t>((size_t)x.rows * x.C) : nullptr;
+    if (b16) *b16 = db;
+    const float* gm = c->f32(pre + p + ".weight");
+    const float* bt = c->f32(pre + p + ".bias");
+    const float *xp = x.p, *dyp = dy.p, *ap = addend ? addend->p : nullptr;
+    const int ld = x.ld, hw = x.rows / N, C = x.C, lddy = dy.ld, ldadd = addend ? addend->ld : 0;
+    float* dxp = dx.p;
+    b.other("gn.bwd", [=](hipStream_t s, const RunArgs&) {
+      return launch_groupnorm_bwd(xp, ld, N, hw, C, gm, bt, eps, silu, dyp, lddy, ap, ldadd, dxp, C, db, s);
+    });
+    return dx;
+  };
+  auto ln_bwd = [&](const F32& x, const std::string& p, const F32& dy, const F32& addend, bf16_t** b16) {
+    F32 dx = f32buf(x.rows, x.C);
+    bf16_t* db = b.buf<bf16_t>((size_t)x.rows * x.C);
+    *b16 = db;
+    const float* gm = c->f32(pre + p + ".weight");
+    const float *xp = x.p, *dyp = dy.p, *ap = addend.p;
+    const int rows = x.rows, C = x.C;
+    float* dxp = dx.p;
+    b.other("ln.bwd", [=](hipStream_t s, const RunArgs&) {
+      return launch_layernorm_bwd(xp, rows, C, gm, 1e-5f, dyp, ap, dxp, db, s);
+    });
+    return dx;
+  };
+
+  // ---- context K / V^T (raw CAVP features, recomputed every call), time embedding, input packing
+  std::vector<BlockDesc> sts = topo_sts(topo);
+  const int ldvtc = rup(Tc, 32);
+  bf16_t* ctxb = b.buf<bf16_t>((size_t)N * Tc * Dc);
+  std::map<std::string, std::pair<bf16_t*, bf16_t*>> kv;
+  {
+    const long n = (long)N * Tc * Dc;
+    b.other("ctx.cast", [=](hipStream_t s, const RunArgs& a) { return launch_cast_bf16(a.aux, ctxb, n, s); });
+    for (auto& d : sts) {
+      bf16_t *K, *Vt;
+      b.context_kv(ctxb, N, Tc, Dc, d.prefix, d.cin, &K, &Vt, ldvtc);
+      kv[d.prefix] = {K, Vt};
+    }
+  }
+  float* tbuf = b.buf<float>(N);
+  b.other("t.copy", [=](hipStream_t s, const RunArgs& a) { return hipMemcpyAsync(tbuf, a.t, (size_t)N * 4, hipMemcpyDeviceToDevice, s); });
+  float* te = b.buf<float>((size_t)N * mc);
+  b.other("t.embed", [=](hipStream_t s, const RunArgs&) { return launch_timestep_embedding(tbuf, te, N, mc, s); });
+  float* e1 = b.buf<float>((size_t)N * temb);
+  float* semb = b.buf<float>((size_t)N * temb);
+  {
+    const bf16_t* w0 = c->w_linear(pre + "time_embed.0.weight");
+    const float* b0 = c->f32(pre + "time_embed.0.bias");
+    const bf16_t* w2 = c->w_linear(pre + "time_embed.2.weight");
+    const float* b2 = c->f32(pre + "time_embed.2.bias");
+    b.other("t.mlp0", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(te, mc, w0, b0, e1, temb, N, temb, mc, 1, s); });
+    b.other("t.mlp2", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(e1, temb, w2, b2, semb, temb, N, temb, temb, 1, s); });
+  }
+  const int etot = c->emb_total[1];
+  float* E = b.buf<float>((size_t)N * etot);
+  {
+    std::vector<std::string> wn, bn;
+    for (auto& r : topo_resblocks(topo)) {
+      wn.push_back(pre + r + ".emb_layers.1.weight");
+      bn.push_back(pre + r + ".emb_layers.1.bias");
+    }
+    const bf16_t* w = c->w_stack(pre + "#embw", wn);
+    const float* bb = c->b_stack(pre + "#embb", bn);
+    b.other("t.embproj", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(semb, temb, w, bb, E, etot, N, etot, temb, 0, s); });
+  }
+  const int cin = u.in_channels;
+  bf16_t* xin = b.buf<bf16_t>((size_t)N * HW * 64);
+  b.other("x.pack", [=](hipStream_t s, const RunArgs& a) { return launch_pack_latent(a.x, xin, N, cin, HW, 64, 1, 1.0f, nullptr, nullptr, s); });
+
+  std::vector<std::function<F32(F32)>> tape;
+
+  // ---- forward modules (each pushes its backward)
+  auto fwd_conv_in = [&](const BlockDesc& d) {
+    F32 h = f32buf(N * HW, d.cout);
+    GemmParams g = Builder::gp_conv3(xin, N, H, W, 64, c->w_conv3(pre + d.prefix + ".weight", 64), d.cout, 1, 0);
+    Builder::out_f32(g, h.p, h.ld);
+    g.bias = c->f32(pre + d.prefix + ".bias");
+    b.gemm(g, 1, "conv_in");
+    const std::string wname = pre + d.prefix + ".weight";
+    const int co = d.cout;
+    tape.push_back([=, &b](F32 dh) mutable -> F32 {
+      bf16_t* db = b.cast2d(dh);
+      GemmParams g2 = Builder::gp_conv3(db, N, H, W, co, c->w_conv3_bwd(wname), cin, 1, 0);
+      Builder::out_f32(g2, nullptr, cin);
+      g2.store_nchw = 1;
+      g2.hw_out = HW;
+      Op& o = b.gemm(g2, 1, "conv_in.bwd");
+      o.c_ext = true;                      // the final gradient goes straight to the caller's NCHW buffer
+      return F32{};
+    });
+    return h;
+  };
+
+  auto fwd_res = [&](const BlockDesc& d, const F32& x, int hh, int ww) {
+    const std::string p = d.prefix;
+    const int ci = x.C, co = d.cout, M = x.rows;
+    const bool has_skip = c->has(pre + p + ".skip_connection.weight");
+    bf16_t* xraw = nullptr;
+    bf16_t* a1 = b.groupnorm(x, N, p + ".in_layers.0", 1e-5f, 1, has_skip ? &xraw : nullptr);
+    F32 h1 = f32buf(M, co);
+    {
+      GemmParams g = Builder::gp_conv3(a1, N, hh, ww, ci, c->w_conv3(pre + p + ".in_layers.2.weight", ci), co, 1, 0);
+      Builder::out_f32(g, h1.p, co);
+      g.bias = c->f32(pre + p + ".in_layers.2.bias");
+      g.rowbias = E + c->emb_off[1].at(p); g.ld_rowbias = etot; g.rows_per_sample = hh * ww; g.rowbias_mode = 1;
+      b.gemm(g, 1, "res.conv1");
+    }
+    bf16_t* a2 = b.groupnorm(h1, N, p + ".out_layers.0", 1e-5f, 1, nullptr);
+    F32 out = f32buf(M, co);
+    if (has_skip) {
+      GemmParams g = Builder::gp_linear(xraw, M, ci, c->w_linear(pre + p + ".skip_connection.weight"), co);
+      Builder::out_f32(g, out.p, co);
+      g.bias = c->f32(pre + p + ".skip_connection.bias");
+      b.gemm(g, 1, "res.skip");
+    }
+    {
+      GemmParams g = Builder::gp_conv3(a2, N, hh, ww, co, c->w_conv3(pre + p + ".out_layers.3.weight", co), co, 1, 0);
+      Builder::out_f32(g, out.p, co);
+      g.bias = c->f32(pre + p + ".out_layers.3.bias");
+      if (has_skip) { g.res = out.p; g.ldr = co; } else { g.res = x.p; g.ldr = x.ld; }
+      b.gemm(g, 1, "res.conv2");
+    }
+    tape.push_back([=, &b](F32 dout) mutable -> F32 {
+      bf16_t* dob = b.cast2d(dout);
+      F32 d_a2 = conv_bwd(dob, hh, ww, co, pre + p + ".out_layers.3.weight", co, "res.conv2.bwd");
+      bf16_t* d_h1b = nullptr;
+      F32 d_h1 = gn_bwd(h1, p + ".out_layers.0", 1e-5f, 1, d_a2, nullptr, true, &d_h1b);
+      (void)d_h1;
+      F32 d_a1 = conv_bwd(d_h1b, hh, ww, co, pre + p + ".in_layers.2.weight", ci, "res.conv1.bwd");
+      F32 ds = dout;
+      if (has_skip)
+        ds = lin_bwd(dob, M, co, c->w_stack_t(pre + p + ".skip#t", {pre + p + ".skip_connection.weight"}), ci, "res.skip.bwd");
+      return gn_bwd(x, p + ".in_layers.0", 1e-5f, 1, d_a1, &ds, false, nullptr);
+    });
+    return out;
+  };
+
+  auto fwd_down = [&](const BlockDesc& d, const F32& x, int hh, int ww) {
+    bf16_t* hb = b.cast2d(x);
+    F32 out = f32buf(x.rows / 4, d.cout);
+    GemmParams g = Builder::gp_conv3(hb, N, hh, ww, d.cin, c->w_conv3(pre + d.prefix + ".op.weight", d.cin), d.cout, 2, 0);
+    Builder::out_f32(g, out.p, d.cout);
+    g.bias = c->f32(pre + d.prefix + ".op.bias");
+    b.gemm(g, 1, "down");
+    const std::string wname = pre + d.prefix + ".op.weight";
+    const int ci = d.cin, co = d.cout;
+    tape.push_back([=, &b](F32 dy) mutable -> F32 {
+      bf16_t* dyb = b.cast2d(dy);
+      F32 dx = f32buf(N * hh * ww, ci);
+      // transposed stride-2 conv: conv over the zero-stuffed x2 grid of dY with flipped taps
+      GemmParams g2 = Builder::gp_conv3(dyb, N, hh / 2, ww / 2, co, c->w_conv3_bwd(wname), ci, 1, 1);
+      g2.zstuff = 1;
+      Builder::out_f32(g2, dx.p, ci);
+      b.gemm(g2, 1, "down.bwd");
+      return dx;
+    });
+    return out;
+  };
+
+  auto fwd_st = [&](const BlockDesc& d, const F32& x, int T) {
+    const std::string p = d.prefix, tb = p + ".transformer_blocks.0";
+    const int C = x.C, M = x.rows, D = C / heads;
+    if (!attention_supported(D) || !(D == 32 || D == 64)) fail("classifier gradient: head dim %d not supported", D);
+    const float scale = 1.0f / sqrtf((float)D);
+    const bf16_t* ctxK = kv[p].first;
+    const bf16_t* ctxVt = kv[p].second;
+    bf16_t* a0 = b.groupnorm(x, N, p + ".norm", 1e-6f, 0, nullptr);
+    F32 t0 = f32buf(M, C), t1 = f32buf(M, C), t2 = f32buf(M, C), out = f32buf(M, C);
+    bf16_t* a = b.buf<bf16_t>((size_t)M * C);
+    {
+      GemmParams g = Builder::gp_linear(a0, M, C, c->w_linear(pre + p + ".proj_in.weight"), C);
+      Builder::out_f32(g, t0.p, C);
+      g.bias = c->f32(pre + p + ".proj_in.bias");
+      b.gemm(g, 1, "st.proj_in");
+    }
+    b.layernorm(t0, tb + ".norm1", a);
+    bf16_t* qk = b.buf<bf16_t>((size_t)M * 2 * C);
+    {
+      const bf16_t* w = c->w_stack(pre + tb + ".attn1.qk", {pre + tb + ".attn1.to_q.weight", pre + tb + ".attn1.to_k.weight"});
+      GemmParams g = Builder::gp_linear(a, M, C, w, 2 * C);
+      Builder::out_b16(g, qk, 2 * C);
+      b.gemm(g, 1, "st.qk");
+    }
+    const int ldvt = rup(T, 32);
+    bf16_t* vt = b.buf<bf16_t>((size_t)N * C * ldvt);
+    {
+      GemmParams g = Builder::gp_linear(c->w_linear(pre + tb + ".attn1.to_v.weight"), C, C, a, T);
+      g.w_bs = (long)T * C;
+      Builder::out_b16(g, vt, ldvt);
+      g.c_bs = (long)C * ldvt;
+      b.gemm(g, N, "st.vT");
+    }
+    bf16_t* o = b.buf<bf16_t>((size_t)M * C);
+    b.other("attn.self", [=](hipStream_t s, const RunArgs&) {
+      return launch_attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, o, C, N, heads, D, T, T, scale, s);
+    });
+    {
+      GemmParams g = Builder::gp_linear(o, M, C, c->w_linear(pre + tb + ".attn1.to_out.0.weight"), C);
+      Builder::out_f32(g, t1.p, C);
+      g.bias = c->f32(pre + tb + ".attn1.to_out.0.bias");
+      g.res = t0.p; g.ldr = C;
+      b.gemm(g, 1, "st.attn1.out");
+    }
+    b.layernorm(t1, tb + ".norm2", a);
+    bf16_t* q2 = b.buf<bf16_t>((size_t)M * C);
+    {
+      GemmParams g = Builder::gp_linear(a, M, C, c->w_linear(pre + tb + ".attn2.to_q.weight"), C);
+      Builder::out_b16(g, q2, C);
+      b.gemm(g, 1, "st.q2");
+    }
+    b.other("attn.cross", [=](hipStream_t s, const RunArgs&) {
+      return launch_attention(q2, C, ctxK, C, ctxVt, ldvtc, o, C, N, heads, D, T, Tc, scale, s);
+    });
+    {
+      GemmParams g = Builder::gp_linear(o, M, C, c->w_linear(pre + tb + ".attn2.to_out.0.weight"), C);
+      Builder::out_f32(g, t2.p, C);
+      g.bias = c->f32(pre + tb + ".attn2.to_out.0.bias");
+      g.res = t1.p; g.ldr = C;
+      b.gemm(g, 1, "st.attn2.out");
+    }
+    b.layernorm(t2, tb + ".norm3", a);
+    bf16_t* uu = b.buf<bf16_t>((size_t)M * 8 * C);       // raw [x | gate] of the GEGLU projection (saved)
+    {
+      GemmParams g = Builder::gp_linear(a, M, C, c->w_linear(pre + tb + ".ff.net.0.proj.weight"), 8 * C);
+      Builder::out_b16(g, uu, 8 * C);
+      g.bias = c->f32(pre + tb + ".ff.net.0.proj.bias");
+      b.gemm(g, 1, "st.ff1.raw");
+    }
+    bf16_t* gl = b.buf<bf16_t>((size_t)M * 4 * C);
+    b.other("geglu", [=](hipStream_t s, const RunArgs&) { return launch_geglu_fwd(uu, gl, (long)M, 4 * C, s); });
+    {
+      GemmParams g = Builder::gp_linear(gl, M, 4 * C, c->w_linear(pre + tb + ".ff.net.2.weight"), C);
+      Builder::out_b16(g, a, C);
+      g.bias = c->f32(pre + tb + ".ff.net.2.bias");
+      g.res = t2.p; g.ldr = C;
+      b.gemm(g, 1, "st.ff2");
+    }
+    {
+      GemmParams g = Builder::gp_linear(a, M, C, c->w_linear(pre + p + ".proj_out.weight"), C);
+      Builder::out_f32(g, out.p, C);
+      g.bias = c->f32(pre + p + ".proj_out.bias");
+      g.res = x.p; g.ldr = x.ld;
+      b.gemm(g, 1, "st.proj_out");
+    }
+    tape.push_back([=, &b](F32 dout) mutable -> F32 {
+      auto wt = [&](const std::string& n) { return c->w_stack_t(pre + n + "#t", {pre + n}); };
+      bf16_t* doutb = b.cast2d(dout);
+      F32 dt3 = lin_bwd(doutb, M, C, wt(p + ".proj_out.weight"), C, "st.proj_out.bwd");
+      bf16_t* dt3b = b.cast2d(dt3);
+      F32 dgl = lin_bwd(dt3b, M, C, wt(tb + ".ff.net.2.weight"), 4 * C, "st.ff2.bwd");
+      bf16_t* du = b.buf<bf16_t>((size_t)M * 8 * C);
+      {
+        const float* dglp = dgl.p;
+        b.other("geglu.bwd", [=](hipStream_t s, const RunArgs&) { return launch_geglu_bwd(uu, dglp, du, (long)M, 4 * C, s); });
+      }
+      F32 da3 = lin_bwd(du, M, 8 * C, wt(tb + ".ff.net.0.proj.weight"), C, "st.ff1.bwd");
+      bf16_t* dt2b = nullptr;
+      F32 dt2 = ln_bwd(t2, tb + ".norm3", da3, dt3, &dt2b);
+      // cross attention (context is a constant: dQ only)
+      F32 do2 = lin_bwd(dt2b, M, C, wt(tb + ".attn2.to_out.0.weight"), C, "st.attn2.out.bwd");
+      bf16_t* dq2 = b.buf<bf16_t>((size_t)M * C);
+      {
+        const float* dop = do2.p;
+        b.other("attn.cross.bwd", [=](hipStream_t s, const RunArgs&) {
+          return launch_attention_bwd(q2, C, ctxK, C, ctxVt, ldvtc, dop, C, dq2, C, nullptr, 0, nullptr, 0, N, heads, D, T, Tc,
+                                      scale, s);
+        });
+      }
+      F32 da2 = lin_bwd(dq2, M, C, wt(tb + ".attn2.to_q.weight"), C, "st.q2.bwd");
+      bf16_t* dt1b = nullptr;
+      F32 dt1 = ln_bwd(t1, tb + ".norm2", da2, dt2, &dt1b);
+      // self attention
+      F32 do1 = lin_bwd(dt1b, M, C, wt(tb + ".attn1.to_out.0.weight"), C, "st.attn1.out.bwd");
+      bf16_t* dqkv = b.buf<bf16_t>((size_t)M * 3 * C);
+      {
+        const float* dop = do1.p;
+        b.other("attn.self.bwd", [=](hipStream_t s, const RunArgs&) {
+          return launch_attention_bwd(qk, 2 * C, qk + C, 2 * C, vt, ldvt, dop, C, dqkv, 3 * C, dqkv + C, 3 * C, dqkv + 2 * C,
+                                      3 * C, N, heads, D, T, T, scale, s);
+        });
+      }
+      const bf16_t* wqkv_t = c->w_stack_t(pre + tb + ".attn1.qkv#t", {pre + tb + ".attn1.to_q.weight", pre + tb + ".attn1.to_k.weight",
+                                                                       pre + tb + ".attn1.to_v.weight"});
+      F32 da1 = lin_bwd(dqkv, M, 3 * C, wqkv_t, C, "st.qkv.bwd");
+      bf16_t* dt0b = nullptr;
+      F32 dt0 = ln_bwd(t0, tb + ".norm1", da1, dt1, &dt0b);
+      (void)dt0;
+      F32 da0 = lin_bwd(dt0b, M, C, wt(p + ".proj_in.weight"), C, "st.proj_in.bwd");
+      return gn_bwd(x, p + ".norm", 1e-6f, 0, da0, &dout, false, nullptr);
+    });
+    return out;
+  };
+
+  // ---- forward
+  F32 h{};
+  const int nin = (int)topo.input.size();
+  for (int k = 0; k < nin; ++k) {
+    for (auto& d : topo.input[k]) {
+      const int ds = (d.kind == BlockDesc::DOWN) ? topo.in_ds[k] / 2 : topo.in_ds[k];
+      const int hh = H / ds, ww = W / ds;
+      if (d.kind == BlockDesc::CONV_IN) h = fwd_conv_in(d);
+      else if (d.kind == BlockDesc::RES) h = fwd_res(d, h, hh, ww);
+      else if (d.kind == BlockDesc::ST) h = fwd_st(d, h, hh * ww);
+      else if (d.kind == BlockDesc::DOWN) h = fwd_down(d, h, hh, ww);
+      else fail("classifier gradient: unexpected block kind");
+    }
+  }
+  const int ds_mid = topo.in_ds.back(), hm = H / ds_mid, wmid = W / ds_mid;
+  for (auto& d : topo.middle) {
+    if (d.kind == BlockDesc::RES) h = fwd_res(d, h, hm, wmid);
+    else h = fwd_st(d, h, hm * wmid);
+  }
+  // head: GN -> SiLU -> conv3x3 -> global avg-pool -> Linear -> sigmoid (alignment_backbone.py:630-638)
+  const int chf = topo.final_ch, co = chf / 2, hw2 = hm * wmid;
+  bf16_t* ah = b.groupnorm(h, N, "out.0", 1e-5f, 1, nullptr);
+  F32 ho = f32buf(h.rows, co);
+  {
+    GemmParams g = Builder::gp_conv3(ah, N, hm, wmid, chf, c->w_conv3(pre + "out.2.weight", chf), co, 1, 0);
+    Builder::out_f32(g, ho.p, co);
+    g.bias = c->f32(pre + "out.2.bias");
+    b.gemm(g, 1, "cls.out");
+  }
+  float* pooled = b.buf<float>((size_t)N * rup(co, 8));
+  float* prob = b.buf<float>((size_t)rup(N, 8));
+  {
+    const float* hop = ho.p;
+    b.other("cls.pool", [=](hipStream_t s, const RunArgs&) { return launch_avgpool(hop, pooled, N, hw2, co, s); });
+    const bf16_t* wc = c->w_linear(pre + "classifier.weight");
+    const float* bc = c->f32(pre + "classifier.bias");
+    b.other("cls.head", [=](hipStream_t s, const RunArgs& ar) {
+      hipError_t e = launch_linear_rows(pooled, co, wc, bc, prob, 1, N, 1, co, 2, s);
+      if (e == hipSuccess && ar.out2) e = hipMemcpyAsync(ar.out2, prob, (size_t)N * 4, hipMemcpyDeviceToDevice, s);
+      return e;
+    });
+  }
+  // ---- backward: head, then the tape in reverse
+  F32 dho = f32buf(h.rows, co);
+  bf16_t* dhob = b.buf<bf16_t>((size_t)h.rows * co);
+  {
+    const float* wcls = c->f32(pre + "classifier.weight");
+    float* dp = dho.p;
+    b.other("cls.head.bwd", [=](hipStream_t s, const RunArgs&) { return launch_cls_head_bwd(prob, wcls, dp, dhob, N, hw2, co, s); });
+  }
+  F32 d_ah = conv_bwd(dhob, hm, wmid, co, pre + "out.2.weight", chf, "cls.out.bwd");
+  F32 g = gn_bwd(h, "out.0", 1e-5f, 1, d_ah, nullptr, false, nullptr);
+  for (int i = (int)tape.size() - 1; i >= 0; --i) g = tape[i](g);
+}
+
 // VAE decoder plan (autoencoder.py:330-333, stage1_autoencoder/model.py:630-663)
 void build_vae(df_ctx* c, Plan* pl, int B, int H, int W) {
   const df_vae_config& v = c->vcfg;
@@ -1306,6 +1722,21 @@ int df_classifier_forward(df_ctx* c, const float* x, const float* t, const float
     a.t = t;
     a.aux = feat;
     a.out = prob;
+    run_ops(c, p, 0, p->ops.size(), (hipStream_t)stream, a);
+  });
+}
+
+int df_classifier_grad(df_ctx* c, const float* x, const float* t, const float* feat, float* prob, float* grad, int B,
+                       int H, int W, int T, void* stream) {
+  return guard([&] {
+    if (!c->has_cls) fail("classifier not configured");
+    Plan* p = get_plan(c, keyf("clsgrad_%d_%d_%d_%d", B, H, W, T), [&](Plan* pl) { build_classifier_grad(c, pl, B, H, W, T); });
+    RunArgs a;
+    a.x = x;
+    a.t = t;
+    a.aux = feat;
+    a.out = grad;
+    a.out2 = prob;
     run_ops(c, p, 0, p->ops.size(), (hipStream_t)stream, a);
   });
 }

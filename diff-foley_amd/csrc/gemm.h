@@ -24,6 +24,7 @@ struct GemmParams {
   int OH, OW;  // output spatial size (M = batch * OH * OW)
   int stride;  // 1 | 2
   int ups;     // 1: conv runs on the nearest-x2 upsampled input
+  int zstuff;  // with ups=1: the x2 input is ZERO-stuffed (transposed stride-2 conv, backward of Downsample), not nearest
   int th, tw;  // halo kernels: spatial patch of output pixels owned per block (th*tw divides BM)
   // epilogue
   void* C; long c_bs; int ldc; int out_bf16;

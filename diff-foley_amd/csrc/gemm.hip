@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
       const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                    \
       _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                          \
         const int uy = a_iy[i] + ky, ux = a_ix[i] + kx;                                         \
-        const bool v = live && ((unsigned)uy < (unsigned)UH) && ((unsigned)ux < (unsigned)UW);  \
+        const bool v = live && ((unsigned)uy < (unsigned)UH) && ((unsigned)ux < (unsigned)UW) && \
+                       !(p.zstuff && ((uy | ux) & 1));                                          \
         const int sy = uy >> p.ups, sx = ux >> p.ups;                                           \
         const unsigned off = ((a_off[i] + (unsigned)(sy * p.Wd + sx)) * (unsigned)p.lda + (unsigned)(d_cc + c8)) * 2u; \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * 32) * (BK * 2)), 16, \

@@ -61,3 +61,21 @@ hipError_t launch_ddim_update(const float* x, const float* e, const float* noise
                               hipStream_t s);
 // mean over HW of NHWC fp32 [N][HW][C] -> [N][C]   (classifier head avg-pool)
 hipError_t launch_avgpool(const float* x, float* out, int N, int HW, int C, hipStream_t s);
+
+// ---- input-gradient kernels (alignment classifier VJP, csrc/backward.hip) --------------------------------------
+hipError_t launch_groupnorm_bwd(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
+                                float eps, int silu, const float* dy, int lddy, const float* addend, int ldadd,
+                                float* dx, int lddx, uint16_t* dx_b16, hipStream_t s);
+hipError_t launch_layernorm_bwd(const float* x, int rows, int C, const float* gamma, float eps, const float* dy,
+                                const float* addend, float* dx, uint16_t* dx_b16, hipStream_t s);
+hipError_t launch_geglu_fwd(const uint16_t* u, uint16_t* y, long rows, int H, hipStream_t s);
+hipError_t launch_geglu_bwd(const uint16_t* u, const float* dy, uint16_t* du, long rows, int H, hipStream_t s);
+// dQ always; dK/dV only when dK != nullptr (cross-attention needs dQ only: the context is a constant)
+hipError_t launch_attention_bwd(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt,
+                                const float* dO, int lddo, uint16_t* dQ, int lddq, uint16_t* dK, int lddk, uint16_t* dV,
+                                int lddv, int N, int heads, int D, int Tq, int Tk, float scale, hipStream_t s);
+hipError_t launch_cls_head_bwd(const float* prob, const float* w, float* dh, uint16_t* dh_b16, int N, int HW, int C,
+                               hipStream_t s);
+// Linear weight [O][I] fp32 -> transposed bf16 written at out[i*ldo + off + o]  (ldo >= off + O)
+hipError_t launch_pack_linear_t(const float* w, uint16_t* out, int O, int I, int ldo, int off, hipStream_t s);
+hipError_t launch_pack_conv_bwd(const float* w, uint16_t* out, int O, int I, int Opad, hipStream_t s);

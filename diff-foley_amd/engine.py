@@ -49,6 +49,8 @@ _SIGS = {
     "df_vae_decode": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "df_classifier_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_void_p],
+    "df_classifier_grad": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                           C.c_int, C.c_int, C.c_void_p],
     "df_cfg_combine": [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p],
     "df_lincomb": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_void_p],
     "df_ddim_update": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
@@ -235,6 +237,17 @@ class Engine:
         _chk(lib().df_classifier_forward(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(out), B, H, W, feat.shape[1],
                                          _stream()))
         return out
+
+    def classifier_grad(self, x, t, feat, want_prob=False):
+        x = _dev_f32(x, self.device)
+        t = _dev_f32(t, self.device)
+        feat = _dev_f32(feat, self.device)
+        B, Cc, H, W = x.shape
+        grad = torch.empty_like(x)
+        prob = torch.empty(B, 1, device=self.device, dtype=torch.float32) if want_prob else None
+        _chk(lib().df_classifier_grad(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(prob) if want_prob else None,
+                                      _ptr(grad), B, H, W, feat.shape[1], _stream()))
+        return (grad, prob) if want_prob else grad
 
     def profile_begin(self):
         _chk(lib().df_profile_begin(self._h))

@@ -239,8 +239,8 @@ class LatentDiffusion:
 class AlignmentClassifier:
     """Alignment_Classifier_Double_Guidance.forward (alignment_classifier.py:269-271): prob = sigmoid(head(backbone)).
 
-    Shares the engine of the LatentDiffusion it guides (``attach``).  ``log_prob_grad`` (the input gradient that
-    double guidance needs, ddim.py:333-341) is not implemented natively yet -- see DESIGN.md 'next'."""
+    Shares the engine of the LatentDiffusion it guides (``attach``).  ``log_prob_grad`` is the input gradient that
+    double guidance needs (ddim.py:333-341): forward + hand-written backward-data pass in libdfengine.so."""
 
     def __init__(self, classifier_config=None, **ignored):
         cfg = _params(classifier_config)
@@ -276,3 +276,10 @@ class AlignmentClassifier:
         return self.engine.classifier_forward(x, t, video_feat)
 
     forward = __call__
+
+    @torch.no_grad()
+    def log_prob_grad(self, x, t, video_feat):
+        """d sum(log p) / d x (unscaled), the quantity cal_classifier_loglikelihood_grad differentiates (ddim.py:333-341)."""
+        if self.engine is None:
+            raise RuntimeError("AlignmentClassifier.attach(ldm) first")
+        return self.engine.classifier_grad(x, t, video_feat)

@@ -30,7 +30,7 @@ COND_TINY = dict(origin_dim=64, embed_dim=128, seq_len=40)
 CLS_FULL = dict(in_channels=4, out_channels=1, model_channels=128, attention_resolutions=[2, 4],
                 num_res_blocks=1, channel_mult=[1, 2, 2], num_heads=8, context_dim=512)
 CLS_TINY = dict(in_channels=4, out_channels=1, model_channels=64, attention_resolutions=[2, 4],
-                num_res_blocks=1, channel_mult=[1, 2, 2], num_heads=2, context_dim=64)
+                num_res_blocks=1, channel_mult=[1, 2, 2], num_heads=4, context_dim=64)
 
 
 # ----------------------------------------------------------------------------- key layout

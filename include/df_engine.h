@@ -100,6 +100,12 @@ int df_vae_decode(df_ctx* ctx, const float* z_dev, float* out_dev, int B, int H,
 int df_classifier_forward(df_ctx* ctx, const float* x_dev, const float* t_dev, const float* feat_dev, float* prob_dev,
                           int B, int H, int W, int T, void* stream);
 
+/* Classifier guidance gradient (cal_classifier_loglikelihood_grad, ddim.py:333-341; cond_grad_fn_classifier,
+ * dpm_solver.py:1340-1349):  grad = d sum_b log p_b / d x  (UNSCALED), shape of x; prob (optional, may be NULL) [B][1].
+ * Forward and hand-written backward-data pass run natively (no autograd). */
+int df_classifier_grad(df_ctx* ctx, const float* x_dev, const float* t_dev, const float* feat_dev, float* prob_dev,
+                       float* grad_dev, int B, int H, int W, int T, void* stream);
+
 /* ---- sampler arithmetic on fp32 latents (n = number of elements) -------------------------------
  * e = e_u + scale*(e_c - e_u), e2 = [e_u ; e_c]                     (ddim.py:245, dpm_solver.py:1386) */
 int df_cfg_combine(const float* e2_dev, float* e_dev, int64_t n, float scale, void* stream);

@@ -161,6 +161,34 @@ def test_tiny_classifier_forward_vs_golden(P, tiny):
     assert torch.allclose(p, g["cls_p"], atol=2e-2)
 
 
+def test_tiny_classifier_grad_and_double_guidance_vs_golden(P, tiny):
+    """G6: input gradient of log p (native backward pass) and the two double-guidance samplers (ddim.py:344-396,
+    dpm_solver.py:1377-1393) against the reference's autograd run."""
+    from diff_foley_amd import synth
+    g = gold("g6_tiny_classifier.npz")
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_TINY)))
+    cls.load_state_dict(tiny_classifier_sd())
+    cls.attach(tiny)
+    x = rnd((2, 4, 16, 64), 105)
+    vf = synth.synthetic_cavp(2, 33, 64, seed=4321)
+    grad, prob = tiny.engine.classifier_grad(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda(), want_prob=True)
+    assert torch.allclose(prob.cpu(), g["cls_p"], atol=2e-2)
+    err = rel_l2(grad.cpu(), g["cls_grad"])
+    print(f"tiny classifier grad rel-L2 {err:.3e}")
+    assert err < 5e-2
+    B = 2
+    xT = synth.synthetic_xT(B, seed=21)
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+    uc = torch.zeros_like(c)
+    for name, S in (("DDIM", 10), ("DPM_Solver", 10)):
+        z, _ = tiny.sample_log_with_classifier_diff_sampler(
+            c, origin_cond=vf.cuda(), batch_size=B, sampler_name=name, ddim_steps=S, unconditional_guidance_scale=4.5,
+            unconditional_conditioning=uc, classifier=cls, classifier_guide_scale=50.0, x_T=xT.clone())
+        err = rel_l2(z.cpu(), g[f"{name}_{S}_cg_z"])
+        print(f"double guidance {name}-{S}: rel-L2 {err:.3e}")
+        assert err < TRAJ_TOL
+
+
 # ------------------------------------------------------------------------------------------- full config
 def test_full_unet_forward_vs_golden(full):
     g = gold("g4_full_unet.npz")
@@ -274,3 +302,7 @@ def test_full_classifier_forward_vs_golden(P, full):
     vf = synth.synthetic_cavp(2, 33, 512, seed=4321)
     p = cls(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda()).cpu()
     assert torch.allclose(p, g["cls_p"], atol=2e-2), (p, g["cls_p"])
+    grad = cls.log_prob_grad(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda()).cpu()
+    err = rel_l2(grad, g["cls_grad"])
+    print(f"full classifier grad rel-L2 {err:.3e} (|grad| mean {g['cls_grad'].abs().mean().item():.3e})")
+    assert err < 5e-2
