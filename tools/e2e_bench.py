@@ -33,3 +33,24 @@ for B in (1, 4, 8):
             t2 = time.perf_counter()
         print(f"B={B} {name}-{S}: sample {1e3 * (t1 - t0):8.1f} ms ({S / (t1 - t0):6.1f} steps/s)  "
               f"decode {1e3 * (t2 - t1):7.1f} ms  -> {B / (t2 - t0):6.2f} clips/s")
+
+# ---- BASELINE.json configs[2]: B = 8, 50-step DPM-Solver++ with the double-guidance classifier in the loop
+cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_FULL)))
+cls.load_state_dict(synth.make_state_dict(synth.classifier_spec(synth.CLS_FULL), 0))
+cls.attach(m)
+B = 8
+feats = synth.synthetic_cavp(B, 33).cuda()
+xT = synth.synthetic_xT(B).cuda()
+c = m.get_learned_conditioning(feats[:, :32])
+uc = torch.zeros_like(c)
+for it in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    z, _ = m.sample_log_with_classifier_diff_sampler(c, origin_cond=feats, batch_size=B, sampler_name="DPM_Solver",
+                                                     ddim_steps=50, unconditional_guidance_scale=4.5,
+                                                     unconditional_conditioning=uc, classifier=cls,
+                                                     classifier_guide_scale=50.0, x_T=xT)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+print(f"config[2] B=8 DPM-Solver++-50 + classifier guidance: {1e3 * (t1 - t0):8.1f} ms ({50 / (t1 - t0):6.1f} steps/s), "
+      f"finite={bool(torch.isfinite(z).all())}")
