@@ -499,6 +499,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 // Runtime-valued vmcnt wait (the immediate must be a literal): small switch over the values that occur.
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
   switch (n) {
+    case 1: wait_vmcnt<1>(); break;
     case 2: wait_vmcnt<2>(); break;
     case 3: wait_vmcnt<3>(); break;
     case 4: wait_vmcnt<4>(); break;
@@ -514,7 +515,31 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
     case 14: wait_vmcnt<14>(); break;
     case 15: wait_vmcnt<15>(); break;
     case 16: wait_vmcnt<16>(); break;
-    default: wait_vmcnt<2>(); break;   // conservative: waits for more than needed
+    case 17: wait_vmcnt<17>(); break;
+    case 18: wait_vmcnt<18>(); break;
+    case 19: wait_vmcnt<19>(); break;
+    case 20: wait_vmcnt<20>(); break;
+    case 21: wait_vmcnt<21>(); break;
+    case 22: wait_vmcnt<22>(); break;
+    case 23: wait_vmcnt<23>(); break;
+    case 24: wait_vmcnt<24>(); break;
+    case 25: wait_vmcnt<25>(); break;
+    case 26: wait_vmcnt<26>(); break;
+    case 27: wait_vmcnt<27>(); break;
+    case 28: wait_vmcnt<28>(); break;
+    case 29: wait_vmcnt<29>(); break;
+    case 30: wait_vmcnt<30>(); break;
+    case 31: wait_vmcnt<31>(); break;
+    case 32: wait_vmcnt<32>(); break;
+    case 33: wait_vmcnt<33>(); break;
+    case 34: wait_vmcnt<34>(); break;
+    case 35: wait_vmcnt<35>(); break;
+    case 36: wait_vmcnt<36>(); break;
+    case 37: wait_vmcnt<37>(); break;
+    case 38: wait_vmcnt<38>(); break;
+    case 39: wait_vmcnt<39>(); break;
+    case 40: wait_vmcnt<40>(); break;
+    default: wait_vmcnt<0>(); break;   // conservative: full drain
   }
 }
 
@@ -527,9 +552,9 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 // out of it: per slice the block fetches HR*128 B of activations + 9 * BN*128 B of weights for 9*2*BM*BN*64 FLOP.
 // Pipeline: A halo double-buffered (slice c+1 requested during slice c), weights in a 4-deep ring requested 3 taps
 // ahead; the 9 taps are unrolled so every wait is a compile-time `vmcnt` (loads retire in issue order):
-//   wait for W(c,t):  younger = W(+1), W(+2) and, for t in {1,2,3}, the A(c+1) request issued at tap 0.
+//   wait for W(c,t):  younger = W(+1) .. W(+NSTW-2) and, for t in 1..NSTW-1, the A(c+1) request issued at tap 0.
 // Zero padding and ragged edges come from out-of-bounds buffer offsets (hardware writes zeros to LDS).
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NSTW>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NT = 64 * WGM * WGN;          // threads
@@ -537,7 +562,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int WPASS = (BN + RPP - 1) / RPP; // weight passes per tap
-  constexpr int NSTW = 4;
+  static_assert(NSTW >= 3 && NSTW <= 8, "weight ring depth");
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -658,22 +683,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- prologue: A(0), W(0..2)
+  // ---- prologue: A(0), W(0 .. NSTW-2)
   DF_HALO_A(c0, 0);
-  DF_HALO_W(0, 0);
-  DF_HALO_W(1, 1);
-  DF_HALO_W(2, 2);
+#pragma unroll
+  for (int t = 0; t < NSTW - 1; ++t) DF_HALO_W(t, t);
 
   // One tap.  VM = loads of this wave allowed to be still in flight when W(c,t) must have landed.
-#define DF_TAP(T, VMEXTRA)                                                                        \
+#define DF_TAP(T)                                                                        \
   {                                                                                             \
-    if (VMEXTRA) wait_vmcnt_dyn(2 * WPASS + APASS);                                             \
-    else wait_vmcnt<2 * WPASS>();                                                               \
+    if ((T) >= 1 && (T) <= NSTW - 1) wait_vmcnt_dyn((NSTW - 2) * WPASS + APASS);               \
+    else wait_vmcnt<(NSTW - 2) * WPASS>();                                                      \
     __builtin_amdgcn_s_barrier();                                                               \
     const int it_ = cs * 9 + (T);                                                               \
     const bf16_t* a = sA + (cs & 1) * HRP * BK;                                                 \
-    const bf16_t* b = sW + (it_ & 3) * WROWS * BK;                                              \
-    DF_HALO_W(it_ + 3, (it_ + 3) & 3);                                                          \
+    const bf16_t* b = sW + (it_ % NSTW) * WROWS * BK;                                           \
+    DF_HALO_W(it_ + NSTW - 1, (it_ + NSTW - 1) % NSTW);                                         \
     if ((T) == 0) DF_HALO_A(c0 + cs + 1, (cs + 1) & 1);                                         \
     constexpr int dy_ = (T) / 3, dx_ = (T) - dy_ * 3;                                           \
     int ha_[TM], sa_[TM];                                                                       \
@@ -695,15 +719,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   }
 
   for (int cs = 0; cs < nc; ++cs) {
-    DF_TAP(0, 0)
-    DF_TAP(1, 1)
-    DF_TAP(2, 1)
-    DF_TAP(3, 1)
-    DF_TAP(4, 0)
-    DF_TAP(5, 0)
-    DF_TAP(6, 0)
-    DF_TAP(7, 0)
-    DF_TAP(8, 0)
+    DF_TAP(0)
+    DF_TAP(1)
+    DF_TAP(2)
+    DF_TAP(3)
+    DF_TAP(4)
+    DF_TAP(5)
+    DF_TAP(6)
+    DF_TAP(7)
+    DF_TAP(8)
   }
   wait_vmcnt<0>();
 
@@ -770,7 +794,7 @@ hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
 }
 
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NSTW>
 hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
   constexpr int NT = 64 * WGM * WGN, RPP = NT / 8;
   GemmParams p = pin;
@@ -782,18 +806,18 @@ hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
   const int APASS = (HR + RPP - 1) / RPP;
   if (APASS > 12) return hipErrorInvalidValue;
   constexpr int WPASS = (BN + RPP - 1) / RPP;
-  const size_t lds = ((size_t)2 * APASS * RPP + (size_t)4 * WPASS * RPP) * BK * 2;
+  const size_t lds = ((size_t)2 * APASS * RPP + (size_t)NSTW * WPASS * RPP) * BK * 2;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t attr = 0;
   if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WGM, WGN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WGM, WGN, NSTW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr = lds;
   }
   const int npatch = p.M / ppx;
   const int nbm = (npatch + PB - 1) / PB, nbn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WGM, WGN>), dim3(nbm * nbn, 1, zdim), dim3(NT), lds, stream, p);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WGM, WGN, NSTW>), dim3(nbm * nbn, 1, zdim), dim3(NT), lds, stream, p);
   return hipGetLastError();
 }
 
@@ -813,7 +837,8 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int hr = (bm / (th * tw)) * (th + 2) * (tw + 2);
   const int apass = (hr + rpp - 1) / rpp, wpass = (bn + rpp - 1) / rpp;
   if (apass > 12) return false;
-  if (((size_t)2 * apass * rpp + (size_t)4 * wpass * rpp) * 128 > 160 * 1024) return false;
+  const int nstw = 4;   // weight ring depth of the halo kernels (6 measured slower)
+  if (((size_t)2 * apass * rpp + (size_t)nstw * wpass * rpp) * 128 > 160 * 1024) return false;
   const int nchunk = p.Cin / 64;
   return splitk == 1 || nchunk / splitk >= 1;
 }
@@ -830,14 +855,14 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
                                : launch_cfg<BM, BN, WGM, WGN, NST, 2>(p, zdim, stream));              \
     break;
   switch (tile_cfg) {
-    DF_CASE(TILE_128x128, 128, 128, 2, 2, 3)
-    DF_CASE(TILE_128x64, 128, 64, 2, 2, 4)
-    DF_CASE(TILE_64x128, 64, 128, 2, 2, 4)
+    DF_CASE(TILE_128x128, 128, 128, 2, 2, 4)
+    DF_CASE(TILE_128x64, 128, 64, 2, 2, 5)
+    DF_CASE(TILE_64x128, 64, 128, 2, 2, 5)
     DF_CASE(TILE_64x64, 64, 64, 2, 2, 4)
     DF_CASE(TILE_32x128, 32, 128, 1, 4, 4)
-    case TILE_HALO_128x64: e = launch_halo<128, 64, 2, 2>(p, zdim, stream); break;
-    case TILE_HALO_256x64: e = launch_halo<256, 64, 4, 2>(p, zdim, stream); break;
-    case TILE_HALO_128x128: e = launch_halo<128, 128, 2, 2>(p, zdim, stream); break;
+    case TILE_HALO_128x64: e = launch_halo<128, 64, 2, 2, 4>(p, zdim, stream); break;
+    case TILE_HALO_256x64: e = launch_halo<256, 64, 4, 2, 4>(p, zdim, stream); break;
+    case TILE_HALO_128x128: e = launch_halo<128, 128, 2, 2, 4>(p, zdim, stream); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
