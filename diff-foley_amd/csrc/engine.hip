@@ -1465,7 +1465,7 @@ void autotune_plan(Plan* pl, hipStream_t s) {
     float best = 1e30f;
     int bt = o.tile, bs = g.splitk;
     for (int t = 0; t < TILE_ALL; ++t) {
-      for (int sk = 1; sk <= 16; sk *= 2) {
+      for (int sk = 1; sk <= 32; sk *= 2) {
         if (!gemm_tile_valid(g, t, o.batch, sk)) { if (sk > 1) break; else continue; }
         const size_t need = (size_t)sk * g.M * g.N * 4;
         if (sk > 1 && need > pl->partial_bytes) break;
@@ -1506,7 +1506,7 @@ Plan* get_plan(df_ctx* c, const std::string& key, const std::function<void(Plan*
     // tuning may try larger split-K factors than the cost model picked: give the scratch some head-room
     size_t want = 0;
     for (auto& o : p->ops)
-      if (o.is_gemm && o.batch == 1) want = std::max(want, (size_t)16 * o.gp.M * o.gp.N * 4);
+      if (o.is_gemm && o.batch == 1) want = std::max(want, (size_t)32 * o.gp.M * o.gp.N * 4);
     if (want > ((size_t)512 << 20)) want = (size_t)512 << 20;
     if (want > p->partial_bytes) p->partial_bytes = want;
   }
@@ -1816,22 +1816,29 @@ int df_profile_dump(df_ctx* c, const char* path) {
 }
 
 // ---- single-kernel entry points for unit tests
+// grow-only split-K scratch shared by the test entry points (no allocation inside timed loops)
+static float* test_partial(size_t bytes) {
+  static float* buf = nullptr;
+  static size_t cap = 0;
+  if (bytes > cap) {
+    if (buf) {
+      (void)hipDeviceSynchronize();
+      (void)hipFree(buf);
+    }
+    HIPCHK(hipMalloc((void**)&buf, bytes));
+    cap = bytes;
+  }
+  return buf;
+}
+
 int df_test_gemm(const uint16_t* A, const uint16_t* W, float* C, int M, int N, int K, int tile, int splitk, void* stream) {
   return guard([&] {
     GemmParams g = Builder::gp_linear(A, M, K, W, N);
     Builder::out_f32(g, C, N);
     g.dbg = getenv("DF_GEMM_DBG") ? atoi(getenv("DF_GEMM_DBG")) : 0;
     g.splitk = splitk;
-    float* part = nullptr;
-    if (splitk > 1) {
-      HIPCHK(hipMalloc((void**)&part, (size_t)splitk * M * N * 4));
-      g.partial = part;
-    }
+    if (splitk > 1) g.partial = test_partial((size_t)splitk * M * N * 4);
     HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
-    if (part) {
-      HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-      (void)hipFree(part);
-    }
   });
 }
 
@@ -1842,16 +1849,9 @@ int df_test_conv3x3(const uint16_t* A, const uint16_t* W, const float* bias, flo
     Builder::out_f32(g, C, Cout);
     g.bias = bias;
     g.splitk = splitk;
-    float* part = nullptr;
-    if (splitk > 1) {
-      HIPCHK(hipMalloc((void**)&part, (size_t)splitk * g.M * g.N * 4));
-      g.partial = part;
-    }
+    g.dbg = getenv("DF_GEMM_DBG") ? atoi(getenv("DF_GEMM_DBG")) : 0;
+    if (splitk > 1) g.partial = test_partial((size_t)splitk * g.M * g.N * 4);
     HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
-    if (part) {
-      HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-      (void)hipFree(part);
-    }
   });
 }
 

@@ -42,11 +42,14 @@ struct GemmParams {
 enum GemmTile {
   TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_COUNT = 5,   // generic
   // conv3x3 stride-1 kernels with an LDS-staged halo tile (BM output pixels = patches of th x tw, BN couts)
-  TILE_HALO_128x64 = 5, TILE_HALO_256x64 = 6, TILE_HALO_128x128 = 7, TILE_ALL = 8
+  TILE_HALO_128x64 = 5, TILE_HALO_256x64 = 6, TILE_HALO_128x128 = 7,
+  // generic kernel with 8 wavefronts (512 threads): high arithmetic intensity per LDS byte, for split-K streaming
+  TILE_128x256 = 8, TILE_256x128 = 9, TILE_ALL = 10
 };
 
 static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
-  static const int d[TILE_ALL][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}, {128, 64}, {256, 64}, {128, 128}};
+  static const int d[TILE_ALL][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
+                                     {128, 64},  {256, 64}, {128, 128}, {128, 256}, {256, 128}};
   *bm = d[cfg][0];
   *bn = d[cfg][1];
 }

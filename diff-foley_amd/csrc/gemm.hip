@@ -246,12 +246,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int WGM, int WGN, int NST, int MODE>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // host pass only needs the launch stub (LDS-DMA builtins do not parse there)
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int AP = BM / 32, BP = BN / 32;
-  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int NT = 64 * WGM * WGN;          // threads (4 or 8 wavefronts)
+  constexpr int RPP = NT / 8;                 // LDS rows filled per DMA pass of the block
+  constexpr int AP = BM / RPP, BP = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the DMA pass");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(NST >= 3 && NST <= 5, "ring depth");
 
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   const int UH = p.H << p.ups, UW = p.Wd << p.ups;
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
-    const int m = m0 + r0 + 32 * i;
+    const int m = m0 + r0 + RPP * i;
     const bool mv = m < p.M;
     a_msk[i] = 0;
     a_iy[i] = a_ix[i] = 0;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   unsigned b_off[BP];
 #pragma unroll
   for (int i = 0; i < BP; ++i) {
-    const int n = n0 + r0 + 32 * i;
+    const int n = n0 + r0 + RPP * i;
     b_off[i] = (n < p.N) ? (unsigned)(((long)n * p.K + c8) * 2) : OOB;
   }
 
@@ -355,14 +357,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     if (MODE == 0) {                                                                            \
       const unsigned kb = live ? k0b : OOB;                                                     \
       _Pragma("unroll") for (int i = 0; i < AP; ++i)                                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * 32) * (BK * 2)), 16, \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
                                                  a_off[i] + kb, 0, 0, 0);                       \
     } else if (MODE == 1) {                                                                     \
       const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                    \
       const unsigned delta = (unsigned)((((ky - 1) * p.Wd + (kx - 1)) * p.lda + d_cc) * 2);     \
       const unsigned bit = live ? (1u << d_tap) : 0u;                                           \
       _Pragma("unroll") for (int i = 0; i < AP; ++i)                                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * 32) * (BK * 2)), 16, \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
                                                  (a_msk[i] & bit) ? a_off[i] + delta : OOB, 0, 0, 0); \
     } else {                                                                                    \
       const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                    \
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
                        !(p.zstuff && ((uy | ux) & 1));                                          \
         const int sy = uy >> p.ups, sx = ux >> p.ups;                                           \
         const unsigned off = ((a_off[i] + (unsigned)(sy * p.Wd + sx)) * (unsigned)p.lda + (unsigned)(d_cc + c8)) * 2u; \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * 32) * (BK * 2)), 16, \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
                                                  v ? off : OOB, 0, 0, 0);                       \
       }                                                                                         \
     }                                                                                           \
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     {                                                                                           \
       const unsigned kb = live ? k0b : OOB;                                                     \
       _Pragma("unroll") for (int i = 0; i < BP; ++i)                                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(dmaB + ((ST) * BN + i * 32) * (BK * 2)), 16, \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(dmaB + ((ST) * BN + i * RPP) * (BK * 2)), 16, \
                                                  b_off[i] + kb, 0, 0, 0);                       \
     }                                                                                           \
   }
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
   const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
                       (p.ld_rowbias & 3) == 0 && (p.res_bs & 3) == 0 && (p.c_bs & 3) == 0;
   if (vec_ok) {
-    epilogue_block<BM, BN, 256, TM, TN>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid,
+    epilogue_block<BM, BN, NT, TM, TN>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid,
                                         [&](int r) { return m0 + r; });
     return;
   }
@@ -789,7 +791,7 @@ hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE>), dim3(nbm * nbn, 1, zdim), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE>), dim3(nbm * nbn, 1, zdim), dim3(64 * WGM * WGN), lds, stream, p);
   return hipGetLastError();
 }
 
@@ -825,7 +827,7 @@ hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
 
 bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int nk = p.K / 64;
-  if (tile < TILE_COUNT) {
+  if (tile < TILE_COUNT || tile == TILE_128x256 || tile == TILE_256x128) {
     if (p.geglu && ((p.N & 63) != 0 || (p.ldc & 3) != 0)) return false;   // GEGLU needs the vectorised block epilogue
     return splitk == 1 || (batch <= 1 && nk / splitk >= 2);
   }
@@ -860,6 +862,8 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
     DF_CASE(TILE_64x128, 64, 128, 2, 2, 5)
     DF_CASE(TILE_64x64, 64, 64, 2, 2, 4)
     DF_CASE(TILE_32x128, 32, 128, 1, 4, 4)
+    DF_CASE(TILE_128x256, 128, 256, 2, 4, 3)
+    DF_CASE(TILE_256x128, 256, 128, 4, 2, 3)
     case TILE_HALO_128x64: e = launch_halo<128, 64, 2, 2, 4>(p, zdim, stream); break;
     case TILE_HALO_256x64: e = launch_halo<256, 64, 4, 2, 4>(p, zdim, stream); break;
     case TILE_HALO_128x128: e = launch_halo<128, 128, 2, 2, 4>(p, zdim, stream); break;
