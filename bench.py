@@ -33,8 +33,10 @@ PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16 (MI355X_MICROARCH.md)
 
 def cpu_baseline(sd, nsteps):
     """The oracle (CPU restatement of the reference sampler, fp32) timed on this box's host cores:
-    BASELINE.json configs[0]: B=1, CFG 4.5 (UNet batch 2), DDIM.  Bounded sample: `nsteps` steps."""
+    BASELINE.json configs[0]: B=1, CFG 4.5 (UNet batch 2), DDIM.  Bounded sample: `nsteps` steps.
+    32 threads: measured fastest on the 128-core GPU box (8: 0.5, 16: 0.78, 32: 0.80, 64: 0.46, 128: 0.20 steps/s)."""
     from oracle import unet as ou, vae as ov, schedule as osch
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     usd = ou.sub_state_dict(sd, "model.diffusion_model.")
     csd = ou.sub_state_dict(sd, "cond_stage_model.")
     x = synth.synthetic_xT(1)
@@ -59,6 +61,18 @@ def cpu_baseline(sd, nsteps):
     return dict(value=nsteps / dt, unit="denoise_steps/s at B=1 (UNet batch 2)", cores=torch.get_num_threads(),
                 kind="port", sample=f"{nsteps} DDIM steps of BASELINE config[0] (B=1, CFG 4.5, fp32, oracle/unet.py), "
                                     f"{dt:.1f} s of CPU work")
+
+
+def pmc_traffic():
+    """HBM-side bytes per GEMM launch (FETCH_SIZE x2 per the gfx950 calibration + WRITE_SIZE, separate --pmc passes of
+    this same command; tools/pmc_traffic.sh).  rocprofv3 cannot run inside the timed process, so the number is read
+    from the committed profile of the current round; null when absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["gemm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def main():
@@ -165,7 +179,7 @@ def main():
             "step_tflops_algorithmic": round(GFLOP_PER_SAMPLE * N / ms_step, 2),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (implicit-GEMM conv3x3/1x1/linear, all tile shapes)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
                          "launches_per_step": int(gemm_launches), "avg_launch_us": round(gemm_ms * 1e3 / max(1, gemm_launches), 2),
                          "algorithmic_gflop_per_step": round(GEMM_GFLOP_PER_SAMPLE * N, 1)},
             "kernel_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in prof.items()},

@@ -142,29 +142,38 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
     }
     // ---- online softmax over this lane's 16 keys (+ partner half-wave)
     float mx = -INFINITY;
+    if (k0 + KT > Tk) {          // ragged last tile only: mask keys that do not exist
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      s[r] = (key < Tk) ? s[r] * scale_log2e : -INFINITY;
-      mx = fmaxf(mx, s[r]);
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        s[r] = (key < Tk) ? s[r] * scale_log2e : -INFINITY;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] *= scale_log2e;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 valid key
-    const float alpha = exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
-    m_run = m_new;
     float ps = 0.f;
     uint32_t pk[8];
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-      const float p0 = exp2f(s[r] - m_new), p1 = exp2f(s[r + 1] - m_new);
+      const float p0 = __builtin_amdgcn_exp2f(s[r] - m_new), p1 = __builtin_amdgcn_exp2f(s[r + 1] - m_new);
       ps += p0 + p1;
       pk[r >> 1] = pack_bf2(p0, p1);
     }
-    l_run = l_run * alpha + ps;
+    if (__any(m_new != m_run)) {                   // wave-uniform: rescale only when some row's running max moved
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
+      l_run *= alpha;
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+      for (int t = 0; t < DT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      m_run = m_new;
+    }
+    l_run += ps;
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
