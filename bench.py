@@ -186,7 +186,7 @@ def main():
             "kernel_launches_per_step": {k: int(v["launches"] // a.steps) for k, v in prof.items()},
             "plan": stats,
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:       # reported at N=1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(sd, a.cpu_steps)
         print(json.dumps(out))
     if world > 1:

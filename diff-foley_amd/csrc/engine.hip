@@ -886,7 +886,6 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
   const int mc = u.model_channels, temb = 4 * mc, HW = H * W, heads = u.num_heads, Dc = u.context_dim;
   if (u.out_channels != 1) fail("classifier gradient: out_channels must be 1");
 
-  auto cast_rows = [&](const F32& x) { return b.cast2d(x); };
   auto f32buf = [&](int rows, int C) { return F32{b.buf<float>((size_t)rows * C), rows, C, C}; };
   // dX = dY . W  for y = x W^T : plain GEMM against the transposed packing
   auto lin_bwd = [&](const bf16_t* dyb, int M, int O, const bf16_t* wt, int I, const char* tag) {
