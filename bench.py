@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
+                    help="MFMA operand type (bf16 = BASELINE config 2, the default; fp16 = libdfengine_f16.so)")
     ap.add_argument("--dump-ops", default="", help="write a per-op CSV of the instrumented pass")
     a = ap.parse_args()
 
@@ -103,7 +105,7 @@ def main():
     else:
         sd_dev = sd
     t_bcast = time.perf_counter() - t0
-    model = P.LatentDiffusion(**P.stage2_config())
+    model = P.LatentDiffusion(precision=a.precision, **P.stage2_config())
     model.load_state_dict(sd_dev)
     model.cuda(dev)
     if not a.no_autotune:
@@ -170,10 +172,10 @@ def main():
             "unit": "denoise_steps/s",
             "per_gpu": round(per_gpu, 3),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f16",
             "data": "synthetic (procedural weights of the full 859.5M-param UNet, unit-norm CAVP-like features, seeded x_T)",
             "config": {"workload": "BASELINE.json configs[1]: single MI355X, batch=4 (UNet batch 8), 25-step DDIM, "
-                                   "bf16 UNet, 32 CAVP context frames, latent 4x16x64, guidance 4.5",
+                                   + ("bf16" if a.precision == "bf16" else "fp16") + " UNet, 32 CAVP context frames, latent 4x16x64, guidance 4.5",
                        "batch_per_gpu": B, "global_batch": G, "parallelism": f"batch-shard x{world}, no step-loop collectives",
                        "weight_bcast_s": round(t_bcast, 3) if world > 1 else None},
             "step_tflops_algorithmic": round(GFLOP_PER_SAMPLE * N / ms_step, 2),

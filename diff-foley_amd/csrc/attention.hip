@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
 #pragma unroll
     for (int c = 0; c < DKC; ++c) {
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&cK[l31 * KROW + 16 * c + 8 * lh]);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], s, 0, 0, 0);
+      s = DF_MFMA_32x32x16(kf, qf[c], s);
     }
     // ---- online softmax over this lane's 16 keys (+ partner half-wave)
     float mx = -INFINITY;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
         const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
         uint4 vv = make_uint4(v0.x, v0.y, v1.x, v1.y);
         const bf16x8 vf = *reinterpret_cast<bf16x8*>(&vv);
-        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
+        o[t] = DF_MFMA_32x32x16(vf, pf, o[t]);
       }
     }
     if (kt + 1 < ntiles) sstore(buf ^ 1);   // the other buffer was last read in iteration kt-1

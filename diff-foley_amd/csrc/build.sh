@@ -1,17 +1,27 @@
 #!/bin/bash
-# Builds libdfengine.so (gfx950) in-tree: diff-foley_amd/libdfengine.so
+# Builds the engine (gfx950) in-tree, twice from the same sources:
+#   diff-foley_amd/libdfengine.so      bf16 MFMA operands (default)
+#   diff-foley_amd/libdfengine_f16.so  fp16 MFMA operands (-DDF_OPERAND_F16)
 set -e
 cd "$(dirname "$0")"
-OUT=../libdfengine.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-mkdir -p build
+SRCS="gemm elementwise attention backward diag engine"
+mkdir -p build/bf16 build/f16
 pids=()
-for f in gemm elementwise attention backward engine; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ ../../include/df_engine.h -nt build/$f.o ]; then
-    hipcc $FLAGS -c $f.hip -o build/$f.o &
-    pids+=($!)
-  fi
+for v in bf16 f16; do
+  DEF=""; [ $v = f16 ] && DEF="-DDF_OPERAND_F16"
+  for f in $SRCS; do
+    o=build/$v/$f.o
+    if [ ! -f $o ] || [ $f.hip -nt $o ] || [ common.h -nt $o ] || [ gemm.h -nt $o ] || [ kernels.h -nt $o ] || [ ../../include/df_engine.h -nt $o ] || [ build.sh -nt $o ]; then
+      hipcc $FLAGS $DEF -c $f.hip -o $o &
+      pids+=($!)
+    fi
+  done
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/gemm.o build/elementwise.o build/attention.o build/backward.o build/engine.o -o $OUT
-echo "built $(realpath $OUT)"
+for v in bf16 f16; do
+  OUT=../libdfengine.so; [ $v = f16 ] && OUT=../libdfengine_f16.so
+  objs=""; for f in $SRCS; do objs="$objs build/$v/$f.o"; done
+  hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $OUT
+  echo "built $(realpath $OUT)"
+done

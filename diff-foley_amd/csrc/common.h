@@ -3,22 +3,44 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint16_t bf16_t;  // raw bf16 bits
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// ---- MFMA operand type.  The library is compiled twice from the same sources: with bf16 operands (default,
+// libdfengine.so -- BASELINE config "bf16 UNet") and with -DDF_OPERAND_F16 (libdfengine_f16.so: fp16 operands, 3 more
+// mantissa bits at the same MFMA rate; out-of-range values saturate at +-65504).  Accumulation, the residual stream,
+// norm statistics and softmax are fp32 in both.  Names keep the historical "bf" prefix: bf16_t = raw operand bits,
+// f2bf/bf2f/pack_bf2 = float <-> operand conversions (round-to-nearest-even, native v_cvt_pk_{bf16,f16}_f32).
+typedef uint16_t bf16_t;  // raw operand bits (bf16 or fp16)
+#if defined(DF_OPERAND_F16)
+typedef _Float16 op_scalar;
+#define DF_OPERAND_NAME "f16"
+#define DF_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+__device__ __forceinline__ float op_clamp(float f) { return __builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f); }
+#else
+typedef __bf16 op_scalar;
+#define DF_OPERAND_NAME "bf16"
+#define DF_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+__device__ __forceinline__ float op_clamp(float f) { return f; }
+#endif
+typedef __attribute__((ext_vector_type(8))) op_scalar bf16x8;
+typedef __attribute__((ext_vector_type(2))) op_scalar op_x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define DF_WAVE 64
 
-__device__ __forceinline__ uint16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);  // round-to-nearest-even (inputs are finite on this path)
-  return (uint16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const f32x2 f = {op_clamp(lo), op_clamp(hi)};
+  const op_x2 v = __builtin_convertvector(f, op_x2);
+  return *reinterpret_cast<const uint32_t*>(&v);
+}
+__device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)(pack_bf2(f, 0.f) & 0xFFFFu); }
+__device__ __forceinline__ float bf2f(uint16_t h) {
+#if defined(DF_OPERAND_F16)
+  return (float)*reinterpret_cast<const _Float16*>(&h);
+#else
+  return __uint_as_float(((uint32_t)h) << 16);
+#endif
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off level): 1 rcp + 1 exp + 6 FMA instead of

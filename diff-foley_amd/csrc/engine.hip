@@ -1557,6 +1557,13 @@ int guard(F&& f) {
 extern "C" {
 
 int df_abi_version(void) { return 1; }
+const char* df_operand_dtype(void) {
+#if defined(DF_OPERAND_F16)
+  return "f16";
+#else
+  return "bf16";
+#endif
+}
 const char* df_last_error(void) { return g_err.c_str(); }
 
 int df_create(int device, df_ctx** out) {

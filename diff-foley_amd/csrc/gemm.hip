@@ -428,7 +428,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   {                                                                                             \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
       _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRCA[i], SRCB[j], acc[i][j], 0, 0, 0); \
+        acc[i][j] = DF_MFMA_32x32x16(SRCA[i], SRCB[j], acc[i][j]); \
   }
   // One K tile out of ring slot ST; refills the slot of the previous tile ((ST + NST - 1) % NST).
 #define DF_ITER(ST)                                                                               \
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
         bfr[j] = *reinterpret_cast<const bf16x8*>(b + fb[j] + (((2 * s + lh) ^ sb[j]) << 3));   \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0); \
+          acc[i][j] = DF_MFMA_32x32x16(af[i], bfr[j], acc[i][j]); \
     }                                                                                           \
   }
 

@@ -10,7 +10,17 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfengine.so")
+LIB_PATH = os.path.join(_HERE, "libdfengine.so")            # bf16 MFMA operands (default)
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libdfengine_f16.so")}   # same sources, -DDF_OPERAND_F16
+OPERAND_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def default_precision():
+    """MFMA operand type of engines created without an explicit ``precision``: env DF_PRECISION or "bf16"."""
+    p = os.environ.get("DF_PRECISION", "bf16")
+    if p not in LIB_PATHS:
+        raise RuntimeError(f"DF_PRECISION={p!r}: expected one of {sorted(LIB_PATHS)}")
+    return p
 
 
 class UNetConfig(C.Structure):
@@ -29,7 +39,7 @@ class CondConfig(C.Structure):
     _fields_ = [("origin_dim", C.c_int), ("embed_dim", C.c_int), ("seq_len", C.c_int)]
 
 
-_lib = None
+_libs = {}
 
 _SIGS = {
     "df_create": [C.c_int, C.POINTER(C.c_void_p)],
@@ -66,17 +76,21 @@ _SIGS = {
     "df_test_layernorm": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "df_test_attention": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
+    "df_test_peak": [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p],
 }
 
 
-def lib():
-    """Load libdfengine.so (built in-tree by __graft_entry__.build / csrc/build.sh).  Fails loudly."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} not found: build it with diff-foley_amd/csrc/build.sh "
+def lib(precision=None):
+    """Load libdfengine[_f16].so (built in-tree by __graft_entry__.build / csrc/build.sh).  Fails loudly."""
+    if precision is None and _libs:          # precision-independent entry points: any loaded build will do
+        return next(iter(_libs.values()))
+    precision = precision or default_precision()
+    if precision not in _libs:
+        path = LIB_PATHS[precision]
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: build it with diff-foley_amd/csrc/build.sh "
                                "(there is no CPU/torch fallback for the sampling path)")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, args in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes = args
@@ -85,17 +99,21 @@ def lib():
         L.df_destroy.argtypes = [C.c_void_p]
         L.df_destroy.restype = None
         L.df_abi_version.restype = C.c_int
-        _lib = L
-    return _lib
+        L.df_operand_dtype.restype = C.c_char_p
+        want = {"bf16": b"bf16", "fp16": b"f16"}[precision]
+        if L.df_operand_dtype() != want:
+            raise RuntimeError(f"{path} was built for {L.df_operand_dtype()!r} operands, expected {want!r}")
+        _libs[precision] = L
+    return _libs[precision]
 
 
 def exported_symbols():
-    return list(_SIGS.keys()) + ["df_last_error", "df_destroy", "df_abi_version"]
+    return list(_SIGS.keys()) + ["df_last_error", "df_destroy", "df_abi_version", "df_operand_dtype"]
 
 
-def _chk(rc):
+def _chk(rc, L=None):
     if rc != 0:
-        raise RuntimeError("libdfengine: " + lib().df_last_error().decode())
+        raise RuntimeError("libdfengine: " + (L or lib()).df_last_error().decode())
 
 
 def _stream():
@@ -134,18 +152,21 @@ def unet_config(cfg):
 class Engine:
     """One engine context per device per process (owns packed weights and plan workspaces)."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, precision=None):
         if not torch.cuda.is_available():
             raise RuntimeError("diff_foley_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.precision = precision or default_precision()
+        self.L = lib(self.precision)
+        self.operand_dtype = OPERAND_DTYPE[self.precision]
         h = C.c_void_p()
-        _chk(lib().df_create(self.device.index or 0, C.byref(h)))
+        _chk(self.L.df_create(self.device.index or 0, C.byref(h)), self.L)
         self._h = h
         self._keep = []
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().df_destroy(self._h)
+            self.L.df_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -156,10 +177,10 @@ class Engine:
 
     # ---- model definition
     def config_unet(self, cfg):
-        _chk(lib().df_config_unet(self._h, C.byref(unet_config(cfg))))
+        _chk(self.L.df_config_unet(self._h, C.byref(unet_config(cfg))), self.L)
 
     def config_classifier(self, cfg):
-        _chk(lib().df_config_classifier(self._h, C.byref(unet_config(cfg))))
+        _chk(self.L.df_config_classifier(self._h, C.byref(unet_config(cfg))), self.L)
 
     def config_vae(self, cfg, scale_factor):
         v = VaeConfig()
@@ -168,39 +189,39 @@ class Engine:
         v.ch_mult = _ilist(C.c_int, 8, cfg["ch_mult"])
         v.n_mult = len(cfg["ch_mult"])
         v.scale_factor = float(scale_factor)
-        _chk(lib().df_config_vae(self._h, C.byref(v)))
+        _chk(self.L.df_config_vae(self._h, C.byref(v)), self.L)
 
     def config_cond(self, cfg):
         k = CondConfig(cfg["origin_dim"], cfg["embed_dim"], cfg["seq_len"])
-        _chk(lib().df_config_cond(self._h, C.byref(k)))
+        _chk(self.L.df_config_cond(self._h, C.byref(k)), self.L)
 
     def load_tensor(self, name, t):
         shape = (C.c_int64 * t.dim())(*t.shape)
         if t.is_cuda:
             t = t.detach().to(torch.float32).contiguous()
-            _chk(lib().df_load_tensor_dev(self._h, name.encode(), _ptr(t), shape, t.dim()))
+            _chk(self.L.df_load_tensor_dev(self._h, name.encode(), _ptr(t), shape, t.dim()), self.L)
         else:
             t = t.detach().to(torch.float32).contiguous()
-            _chk(lib().df_load_tensor(self._h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()))
+            _chk(self.L.df_load_tensor(self._h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()), self.L)
 
     def finalize(self):
-        _chk(lib().df_finalize(self._h))
+        _chk(self.L.df_finalize(self._h), self.L)
 
     def autotune(self, enable=True):
-        _chk(lib().df_autotune(self._h, int(enable)))
+        _chk(self.L.df_autotune(self._h, int(enable)), self.L)
 
     # ---- network calls (all asynchronous on the current torch stream)
     def cond_encode(self, feats):
         feats = _dev_f32(feats, self.device)
         B, T, _ = feats.shape
         out = torch.empty(B, T, self.cond_embed_dim, device=self.device, dtype=torch.float32)
-        _chk(lib().df_cond_encode(self._h, _ptr(feats), _ptr(out), B, T, _stream()))
+        _chk(self.L.df_cond_encode(self._h, _ptr(feats), _ptr(out), B, T, _stream()), self.L)
         return out
 
     def set_context(self, ctx):
         ctx = _dev_f32(ctx, self.device)
         N, T, _ = ctx.shape
-        _chk(lib().df_unet_set_context(self._h, _ptr(ctx), N, T, _stream()))
+        _chk(self.L.df_unet_set_context(self._h, _ptr(ctx), N, T, _stream()), self.L)
 
     def unet_forward(self, x, t, out=None):
         x = _dev_f32(x, self.device)
@@ -208,7 +229,7 @@ class Engine:
         N, Cc, H, W = x.shape
         if out is None:
             out = torch.empty(N, self.unet_out_channels, H, W, device=self.device, dtype=torch.float32)
-        _chk(lib().df_unet_forward(self._h, _ptr(x), _ptr(t), _ptr(out), N, H, W, _stream()))
+        _chk(self.L.df_unet_forward(self._h, _ptr(x), _ptr(t), _ptr(out), N, H, W, _stream()), self.L)
         return out
 
     def unet_forward_cfg(self, x, t, scale, out=None):
@@ -217,7 +238,7 @@ class Engine:
         B, Cc, H, W = x.shape
         if out is None:
             out = torch.empty(B, self.unet_out_channels, H, W, device=self.device, dtype=torch.float32)
-        _chk(lib().df_unet_forward_cfg(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, float(scale), _stream()))
+        _chk(self.L.df_unet_forward_cfg(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, float(scale), _stream()), self.L)
         return out
 
     def vae_decode(self, z):
@@ -225,7 +246,7 @@ class Engine:
         B, Cc, H, W = z.shape
         up = 2 ** (self.vae_n_mult - 1)
         out = torch.empty(B, self.vae_out_ch, H * up, W * up, device=self.device, dtype=torch.float32)
-        _chk(lib().df_vae_decode(self._h, _ptr(z), _ptr(out), B, H, W, _stream()))
+        _chk(self.L.df_vae_decode(self._h, _ptr(z), _ptr(out), B, H, W, _stream()), self.L)
         return out
 
     def classifier_forward(self, x, t, feat):
@@ -234,8 +255,8 @@ class Engine:
         feat = _dev_f32(feat, self.device)
         B, Cc, H, W = x.shape
         out = torch.empty(B, self.cls_out_channels, device=self.device, dtype=torch.float32)
-        _chk(lib().df_classifier_forward(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(out), B, H, W, feat.shape[1],
-                                         _stream()))
+        _chk(self.L.df_classifier_forward(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(out), B, H, W, feat.shape[1],
+                                         _stream()), self.L)
         return out
 
     def classifier_grad(self, x, t, feat, want_prob=False):
@@ -245,25 +266,25 @@ class Engine:
         B, Cc, H, W = x.shape
         grad = torch.empty_like(x)
         prob = torch.empty(B, 1, device=self.device, dtype=torch.float32) if want_prob else None
-        _chk(lib().df_classifier_grad(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(prob) if want_prob else None,
-                                      _ptr(grad), B, H, W, feat.shape[1], _stream()))
+        _chk(self.L.df_classifier_grad(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(prob) if want_prob else None,
+                                      _ptr(grad), B, H, W, feat.shape[1], _stream()), self.L)
         return (grad, prob) if want_prob else grad
 
     def profile_begin(self):
-        _chk(lib().df_profile_begin(self._h))
+        _chk(self.L.df_profile_begin(self._h), self.L)
 
     def profile_end(self):
         ms, cnt = (C.c_double * 5)(), (C.c_int64 * 5)()
-        _chk(lib().df_profile_end(self._h, ms, cnt))
+        _chk(self.L.df_profile_end(self._h, ms, cnt), self.L)
         names = ("gemm", "attention", "groupnorm", "layernorm", "other")
         return {n: dict(ms=ms[i], launches=cnt[i]) for i, n in enumerate(names)}
 
     def profile_dump(self, path):
-        _chk(lib().df_profile_dump(self._h, path.encode()))
+        _chk(self.L.df_profile_dump(self._h, path.encode()), self.L)
 
     def plan_stats(self):
         n, f, w = C.c_int64(), C.c_double(), C.c_double()
-        _chk(lib().df_unet_plan_stats(self._h, C.byref(n), C.byref(f), C.byref(w)))
+        _chk(self.L.df_unet_plan_stats(self._h, C.byref(n), C.byref(f), C.byref(w)), self.L)
         return dict(launches=n.value, gemm_flops=f.value, weight_bytes=w.value)
 
 

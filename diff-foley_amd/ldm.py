@@ -60,7 +60,10 @@ class LatentDiffusion:
     def __init__(self, first_stage_config=None, cond_stage_config=None, unet_config=None, linear_start=1e-4,
                  linear_end=2e-2, timesteps=1000, beta_schedule="linear", channels=3, image_size=256,
                  scale_factor=1.0, conditioning_key=None, parameterization="eps", log_every_t=100,
-                 v_posterior=0.0, use_ema=True, clip_denoised=True, **ignored):
+                 v_posterior=0.0, use_ema=True, clip_denoised=True, precision=None, **ignored):
+        # precision: MFMA operand type of the engine, "bf16" (default; BASELINE config 2) or "fp16" (same speed, 8x
+        # smaller operand rounding; BASELINE config 5).  None -> env DF_PRECISION -> "bf16".  Not a reference kwarg.
+        self.precision = precision
         if parameterization != "eps":
             raise NotImplementedError("only eps-parameterisation is on the path")
         if conditioning_key not in (None, "crossattn"):
@@ -131,7 +134,7 @@ class LatentDiffusion:
             device = torch.device("cuda", torch.cuda.current_device())
         torch.cuda.set_device(device)
         self.device = device
-        self.engine = E.Engine(device)
+        self.engine = E.Engine(device, precision=self.precision)
         for k in BUFFER_NAMES:
             setattr(self, k, getattr(self, k).to(device))
         if self._state is not None:

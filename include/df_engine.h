@@ -18,6 +18,7 @@
  */
 #ifndef DF_ENGINE_H
 #define DF_ENGINE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -57,6 +58,9 @@ int df_create(int device, df_ctx** out);
 void df_destroy(df_ctx* ctx);
 const char* df_last_error(void);
 int df_abi_version(void);
+/* MFMA operand type this build was compiled for: "bf16" (libdfengine.so) or "f16" (libdfengine_f16.so, built from
+ * the same sources with -DDF_OPERAND_F16).  2-byte operand buffers passed to the df_test_* entry points use it. */
+const char* df_operand_dtype(void);
 
 /* ---- model definition: replaces instantiate_from_config(config.model) + load_state_dict()
  *      (inference/diff_foley_inference.ipynb:80-95; diff_foley/util.py:176-191).
@@ -139,6 +143,11 @@ int df_test_layernorm(const float* x_dev, int rows, int C, const float* gamma, c
                       void* stream);
 int df_test_attention(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt, uint16_t* O,
                       int ldo, int N, int heads, int D, int Tq, int Tk, float scale, void* stream);
+/* Device-peak microbenchmarks (tools/peaks.py; SURVEY.md 8d "peaks measured on the box").  kind 0: MFMA issue peak
+ * (n = iterations per wavefront of 4 independent v_mfma_f32_32x32x16_bf16; grid blocks x 256 threads); kind 1:
+ * streaming copy of n bytes; kind 2: streaming read of n bytes. */
+int df_test_peak(int kind, const void* src_dev, void* dst_dev, size_t n, int blocks, void* stream);
+
 
 #ifdef __cplusplus
 }

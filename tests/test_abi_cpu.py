@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module", autouse=True)
 def _built():
-    if not os.path.exists(E.LIB_PATH):
+    if not all(os.path.exists(p) for p in E.LIB_PATHS.values()):
         import __graft_entry__
         __graft_entry__.build()
 
@@ -24,11 +24,13 @@ def _built():
 def test_header_symbols_exported():
     hdr = open(os.path.join(ROOT, "include", "df_engine.h")).read()
     declared = set(re.findall(r"\b(df_[a-z0-9_]+)\s*\(", hdr))
-    lib = E.lib()
-    for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} declared in df_engine.h but not exported"
+    for prec, want in (("bf16", b"bf16"), ("fp16", b"f16")):      # both operand-type builds of the same sources
+        lib = E.lib(prec)
+        for name in sorted(declared):
+            assert hasattr(lib, name), f"{name} declared in df_engine.h but not exported by the {prec} build"
+        assert lib.df_abi_version() == 1
+        assert lib.df_operand_dtype() == want
     assert declared == set(E.exported_symbols()), declared ^ set(E.exported_symbols())
-    assert lib.df_abi_version() == 1
 
 
 def test_no_gpu_fails_loudly():

@@ -1,5 +1,6 @@
 """GPU: each HIP kernel family through the C ABI against a plain PyTorch fp32 reference of the same op
-(operands rounded to bf16 first, so the only difference is fp32 accumulation order): tolerance 2e-3 relative."""
+(operands rounded to the build's MFMA operand type first -- bf16 for libdfengine.so, fp16 for libdfengine_f16.so --
+so the only difference is fp32 accumulation order): tolerance 2e-3 relative.  Every test runs on both builds."""
 import ctypes as C
 
 import pytest
@@ -16,8 +17,23 @@ def _eng():
     return E
 
 
+PREC = "bf16"
+
+
+@pytest.fixture(params=["bf16", "fp16"], autouse=True)
+def prec(request):
+    global PREC
+    PREC = request.param
+    yield PREC
+    PREC = "bf16"
+
+
+def odt():
+    return _eng().OPERAND_DTYPE[PREC]
+
+
 def bf(t):
-    return t.to(torch.bfloat16)
+    return t.to(odt())
 
 
 def ptr(t):
@@ -38,8 +54,8 @@ def test_gemm(tile, M, N, K, splitk):
     a = bf(rnd((M, K), 1)).cuda()
     w = bf(rnd((N, K), 2)).cuda()
     c = torch.full((M, N), float("nan"), device="cuda")
-    rc = E.lib().df_test_gemm(ptr(a), ptr(w), ptr(c), M, N, K, tile, splitk, stream())
-    assert rc == 0, E.lib().df_last_error()
+    rc = E.lib(PREC).df_test_gemm(ptr(a), ptr(w), ptr(c), M, N, K, tile, splitk, stream())
+    assert rc == 0, E.lib(PREC).df_last_error()
     torch.cuda.synchronize()
     ref = a.float() @ w.float().t()
     assert torch.isfinite(c).all()
@@ -65,11 +81,11 @@ def test_conv3x3(tile, NB, H, W, Cin, Cout, stride, ups, splitk):
     OH, OW = ref.shape[2], ref.shape[3]
     c = torch.full((NB * OH * OW, Cout), float("nan"), device="cuda")
     bc = b.cuda()
-    rc = E.lib().df_test_conv3x3(ptr(a), ptr(wp), ptr(bc), ptr(c), NB, H, W, Cin, Cout, stride, ups, tile, splitk,
+    rc = E.lib(PREC).df_test_conv3x3(ptr(a), ptr(wp), ptr(bc), ptr(c), NB, H, W, Cin, Cout, stride, ups, tile, splitk,
                                  stream())
-    if rc != 0 and tile in (5, 6, 7) and b"invalid argument" in E.lib().df_last_error():
+    if rc != 0 and tile in (5, 6, 7) and b"invalid argument" in E.lib(PREC).df_last_error():
         pytest.skip("patch geometry of this halo tile does not fit LDS for this shape")
-    assert rc == 0, E.lib().df_last_error()
+    assert rc == 0, E.lib(PREC).df_last_error()
     torch.cuda.synchronize()
     got = c.cpu().reshape(NB, OH, OW, Cout).permute(0, 3, 1, 2)
     assert rel_l2(got, ref) < 2e-3
@@ -85,10 +101,10 @@ def test_groupnorm(N, HW, C, silu, eps):
     if silu:
         ref = F.silu(ref)
     xin = x.permute(0, 2, 1).contiguous().cuda()
-    out = torch.empty(N, HW, C, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(N, HW, C, dtype=odt(), device="cuda")
     gc, bc = g.cuda(), b.cuda()
-    rc = E.lib().df_test_groupnorm(ptr(xin), C, N, HW, C, ptr(gc), ptr(bc), eps, silu, ptr(out), stream())
-    assert rc == 0, E.lib().df_last_error()
+    rc = E.lib(PREC).df_test_groupnorm(ptr(xin), C, N, HW, C, ptr(gc), ptr(bc), eps, silu, ptr(out), stream())
+    assert rc == 0, E.lib(PREC).df_last_error()
     torch.cuda.synchronize()
     assert rel_l2(out.float().cpu().permute(0, 2, 1), ref) < 4e-3     # bf16 output rounding
 
@@ -100,9 +116,9 @@ def test_layernorm(rows, C):
     g, b = rnd((C,), 10), rnd((C,), 11)
     ref = F.layer_norm(x, (C,), g, b, 1e-5)
     xc, gc, bc = x.cuda(), g.cuda(), b.cuda()
-    out = torch.empty(rows, C, dtype=torch.bfloat16, device="cuda")
-    rc = E.lib().df_test_layernorm(ptr(xc), rows, C, ptr(gc), ptr(bc), ptr(out), stream())
-    assert rc == 0, E.lib().df_last_error()
+    out = torch.empty(rows, C, dtype=odt(), device="cuda")
+    rc = E.lib(PREC).df_test_layernorm(ptr(xc), rows, C, ptr(gc), ptr(bc), ptr(out), stream())
+    assert rc == 0, E.lib(PREC).df_last_error()
     torch.cuda.synchronize()
     assert rel_l2(out.float().cpu(), ref) < 4e-3
 
@@ -121,13 +137,13 @@ def test_attention(N, heads, D, Tq, Tk):
     att = torch.softmax(sp(q, Tq) @ sp(k, Tk).transpose(-1, -2) * scale, dim=-1)
     ref = (att @ sp(v, Tk)).permute(0, 2, 1, 3).reshape(N, Tq, C_)
     ldvt = (Tk + 31) // 32 * 32
-    vt = torch.full((N, C_, ldvt), float("nan"), dtype=torch.bfloat16)      # padding deliberately poisoned
+    vt = torch.full((N, C_, ldvt), float("nan"), dtype=odt())      # padding deliberately poisoned
     vt[:, :, :Tk] = v.permute(0, 2, 1)
     qc, kc, vc = q.cuda(), k.cuda(), vt.cuda()
-    o = torch.empty(N, Tq, C_, dtype=torch.bfloat16, device="cuda")
-    rc = E.lib().df_test_attention(ptr(qc), C_, ptr(kc), C_, ptr(vc), ldvt, ptr(o), C_, N, heads, D, Tq, Tk, scale,
+    o = torch.empty(N, Tq, C_, dtype=odt(), device="cuda")
+    rc = E.lib(PREC).df_test_attention(ptr(qc), C_, ptr(kc), C_, ptr(vc), ldvt, ptr(o), C_, N, heads, D, Tq, Tk, scale,
                                    stream())
-    assert rc == 0, E.lib().df_last_error()
+    assert rc == 0, E.lib(PREC).df_last_error()
     torch.cuda.synchronize()
     assert torch.isfinite(o.float()).all()
     assert rel_l2(o.float().cpu(), ref) < 1e-2      # P and O are rounded to bf16 inside the kernel
@@ -146,9 +162,9 @@ def test_attention_online_softmax_rescale():
     ref = att @ v.float()
     vt = v.permute(0, 2, 1).contiguous()
     qc, kc, vc = q.cuda(), k.cuda(), vt.cuda()
-    o = torch.empty(N, T, D, dtype=torch.bfloat16, device="cuda")
-    rc = E.lib().df_test_attention(ptr(qc), D, ptr(kc), D, ptr(vc), T, ptr(o), D, N, heads, D, T, T, scale, stream())
-    assert rc == 0, E.lib().df_last_error()
+    o = torch.empty(N, T, D, dtype=odt(), device="cuda")
+    rc = E.lib(PREC).df_test_attention(ptr(qc), D, ptr(kc), D, ptr(vc), T, ptr(o), D, N, heads, D, T, T, scale, stream())
+    assert rc == 0, E.lib(PREC).df_last_error()
     torch.cuda.synchronize()
     assert rel_l2(o.float().cpu(), ref) < 1e-2
 

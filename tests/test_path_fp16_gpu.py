@@ -1,0 +1,131 @@
+"""GPU parity of the fp16-operand build (libdfengine_f16.so, ``precision="fp16"``) against the same golden vectors.
+
+Same kernels, same speed; operands carry 11 significant bits instead of 8, so every tolerance is ~8x tighter than in
+test_path_gpu.py and the north-star bound -- decoded-mel MAE < 1e-3 vs the reference CPU sampler -- holds in ABSOLUTE
+mel units (the bf16 build meets it on the range-normalised mel only).  Tolerances are in the asserts."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (gold, rnd, rel_l2, tiny_state_dict, full_state_dict, tiny_classifier_sd, full_classifier_sd)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import diff_foley_amd
+    return diff_foley_amd
+
+
+@pytest.fixture(scope="module")
+def tiny(P):
+    from diff_foley_amd import synth
+    m = P.LatentDiffusion(precision="fp16", **P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
+    m.load_state_dict(tiny_state_dict())
+    m.cuda()
+    assert m.engine.precision == "fp16" and m.engine.L.df_operand_dtype() == b"f16"
+    return m
+
+
+@pytest.fixture(scope="module")
+def full(P):
+    m = P.LatentDiffusion(precision="fp16", **P.stage2_config())
+    m.load_state_dict(full_state_dict())
+    m.cuda()
+    return m
+
+
+def test_fp16_tiny_forward_and_samplers(tiny):
+    from diff_foley_amd import synth
+    g = gold("g3_tiny_unet.npz")
+    x, c = rnd((2, 4, 16, 64), 102), rnd((2, 32, 128), 101)
+    y = tiny.apply_model(x.cuda(), torch.tensor([500, 37]).cuda(), c.cuda()).cpu()
+    err = rel_l2(y, g["y_int"])
+    print(f"fp16 tiny UNet rel-L2 {err:.3e}")
+    assert err < 3e-3
+    d = tiny.decode_first_stage(rnd((2, 4, 16, 64), 103).cuda()).cpu()
+    assert rel_l2(d, g["decode"]) < 3e-3
+    g5 = gold("g5_tiny_samplers.npz")
+    B = 2
+    xT = synth.synthetic_xT(B, seed=21)
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+    uc = torch.zeros_like(c)
+    for name, S in (("DDIM", 25), ("DPM_Solver", 25), ("PLMS", 25)):
+        z, _ = tiny.sample_log_diff_sampler(c, B, name, S, unconditional_guidance_scale=4.5,
+                                            unconditional_conditioning=uc, x_T=xT.clone())
+        err = rel_l2(z.cpu(), g5[f"{name}_{S}_z"])
+        print(f"fp16 tiny {name}-{S}: rel-L2 {err:.3e}")
+        assert err < 1e-2
+
+
+def test_fp16_tiny_classifier_grad(P, tiny):
+    from diff_foley_amd import synth
+    g = gold("g6_tiny_classifier.npz")
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_TINY)))
+    cls.load_state_dict(tiny_classifier_sd())
+    cls.attach(tiny)
+    x = rnd((2, 4, 16, 64), 105)
+    vf = synth.synthetic_cavp(2, 33, 64, seed=4321)
+    grad, prob = tiny.engine.classifier_grad(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda(), want_prob=True)
+    assert torch.allclose(prob.cpu(), g["cls_p"], atol=3e-3)
+    err = rel_l2(grad.cpu(), g["cls_grad"])
+    print(f"fp16 tiny classifier grad rel-L2 {err:.3e}")
+    assert err < 1e-2
+
+
+def test_fp16_full_unet_and_vae(full):
+    g = gold("g4_full_unet.npz")
+    x, c = rnd((2, 4, 16, 64), 200), rnd((2, 32, 768), 201)
+    y = full.apply_model(x.cuda(), torch.tensor([961, 41]).cuda(), c.cuda()).cpu()
+    err = rel_l2(y, g["unet_y"])
+    print(f"fp16 full UNet forward: rel-L2 {err:.3e}  MAE {(y - g['unet_y']).abs().mean().item():.3e}")
+    assert err < 3e-3
+    d = full.decode_first_stage(rnd((1, 4, 16, 64), 202).cuda()).cpu()
+    err = rel_l2(d[:, 0], g["decode"])
+    print(f"fp16 full VAE decode: rel-L2 {err:.3e}")
+    assert err < 3e-3
+
+
+def test_fp16_full_ddim25_mel_mae_absolute(full):
+    """North-star: decoded mel MAE < 1e-3 (absolute) vs the reference CPU sampler, B=1, 25-step DDIM, CFG 4.5."""
+    from diff_foley_amd import synth
+    g = gold("g5_full_samplers.npz")
+    for seed in (21, 22):
+        xT = synth.synthetic_xT(1, seed=seed)
+        c = full.get_learned_conditioning(synth.synthetic_cavp(1, 32, 512, seed=1234 + seed - 21).cuda())
+        uc = torch.zeros_like(c)
+        z, _ = full.sample_log_diff_sampler(c, 1, "DDIM", 25, unconditional_guidance_scale=4.5,
+                                            unconditional_conditioning=uc, x_T=xT.clone())
+        mel = full.decode_first_stage(z)[:, 0].cpu()
+        mr = g[f"ddim25_mel_{seed}"]
+        mae = (mel - mr).abs().mean().item()
+        print(f"fp16 seed {seed}: z rel-L2 {rel_l2(z.cpu(), g[f'ddim25_z_{seed}']):.3e}; mel MAE {mae:.3e} "
+              f"(mel std {mr.std().item():.3f})")
+        assert mae < 1e-3
+
+
+def test_fp16_full_dpm50_and_classifier(P, full):
+    from diff_foley_amd import synth
+    g = gold("g5_full_samplers.npz")
+    xT = synth.synthetic_xT(1, seed=21)
+    c = full.get_learned_conditioning(synth.synthetic_cavp(1, 32, 512, seed=1234).cuda())
+    uc = torch.zeros_like(c)
+    z, _ = full.sample_log_diff_sampler(c, 1, "DPM_Solver", 50, unconditional_guidance_scale=4.5,
+                                        unconditional_conditioning=uc, x_T=xT.clone())
+    mel = full.decode_first_stage(z)[:, 0].cpu()
+    mae = (mel - g["dpm50_mel_21"]).abs().mean().item()
+    print(f"fp16 DPM-50: z rel-L2 {rel_l2(z.cpu(), g['dpm50_z_21']):.3e}; mel MAE {mae:.3e}")
+    assert mae < 1e-3
+    g6 = gold("g6_full_classifier.npz")
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_FULL)))
+    cls.load_state_dict(full_classifier_sd())
+    cls.attach(full)
+    x = rnd((2, 4, 16, 64), 205)
+    vf = synth.synthetic_cavp(2, 33, 512, seed=4321)
+    p = cls(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda()).cpu()
+    assert torch.allclose(p, g6["cls_p"], atol=3e-3), (p, g6["cls_p"])
+    grad = cls.log_prob_grad(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda()).cpu()
+    err = rel_l2(grad, g6["cls_grad"])
+    print(f"fp16 full classifier grad rel-L2 {err:.3e}")
+    assert err < 1e-2
