@@ -1443,27 +1443,35 @@ void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const
   }
 }
 
-// Time every tile candidate of every GEMM in the plan and keep the fastest ("measure, don't guess").
-void autotune_plan(Plan* pl, hipStream_t s) {
+// Autotune, stage 1: time every (tile, split-K) candidate of every distinct GEMM of the plan in isolation (3 launches
+// back to back, operands cache-warm) and rank them ("measure, don't guess").
+// Stage 2 (in situ): the isolated ranking mispredicts layers whose operands arrive cold from HBM/MALL or whose
+// neighbours leave the CUs half busy, so the best DF_TUNE_TOPK candidates of every GEMM are re-timed INSIDE the plan:
+// round r runs the whole plan with every GEMM on its r-th candidate (HIP events around each op), and each distinct
+// GEMM keeps the candidate with the smallest in-plan time summed over its instances.
+struct TuneCand { int tile, sk; float iso_ms; double situ_ms; };
+
+static std::string tune_key(const Op& o) {
+  const GemmParams& g = o.gp;
+  char key[160];
+  snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d_%d", g.M, g.N, g.K, g.taps, g.stride, g.ups, o.batch, g.geglu);
+  return key;
+}
+
+void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
-  std::map<std::string, std::pair<int, int>> memo;
+  std::map<std::string, std::vector<TuneCand>> cands;
+  static const int tile_cap = getenv("DF_TILE_CAP") ? atoi(getenv("DF_TILE_CAP")) : TILE_ALL;   // tools: A/B a tile family
+  static const int topk = getenv("DF_TUNE_TOPK") ? atoi(getenv("DF_TUNE_TOPK")) : 6;            // 1 = stage 1 only
   for (auto& o : pl->ops) {
     if (!o.is_gemm || o.c_ext) continue;
+    const std::string key = tune_key(o);
+    if (cands.count(key)) continue;
     GemmParams g = o.gp;
-    char key[160];
-    snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d_%d", g.M, g.N, g.K, g.taps, g.stride, g.ups, o.batch, g.geglu);
-    auto it = memo.find(key);
-    if (it != memo.end()) {
-      o.tile = it->second.first;
-      o.gp.splitk = it->second.second;
-      o.gp.partial = pl->partial;
-      continue;
-    }
-    float best = 1e30f;
-    int bt = o.tile, bs = g.splitk;
-    for (int t = 0; t < TILE_ALL; ++t) {
+    std::vector<TuneCand>& v = cands[key];
+    for (int t = 0; t < TILE_ALL && t < tile_cap; ++t) {
       for (int sk = 1; sk <= 32; sk *= 2) {
         if (!gemm_tile_valid(g, t, o.batch, sk)) { if (sk > 1) break; else continue; }
         const size_t need = (size_t)sk * g.M * g.N * 4;
@@ -1479,20 +1487,77 @@ void autotune_plan(Plan* pl, hipStream_t s) {
         HIPCHK(hipEventSynchronize(e1));
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-        if (ms < best) {
-          best = ms;
-          bt = t;
-          bs = sk;
-        }
+        v.push_back({t, sk, ms, 0.0});
       }
     }
-    o.tile = bt;
-    o.gp.splitk = bs;
-    o.gp.partial = pl->partial;
-    memo[key] = {bt, bs};
+    if (v.empty()) v.push_back({o.tile, g.splitk, 0.f, 0.0});
+    std::sort(v.begin(), v.end(), [](const TuneCand& a, const TuneCand& b) { return a.iso_ms < b.iso_ms; });
+    if ((int)v.size() > topk) v.resize(topk > 0 ? topk : 1);
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  auto apply = [&](int round) {   // round < 0: the best in-situ candidate
+    for (auto& o : pl->ops) {
+      if (!o.is_gemm || o.c_ext) continue;
+      const std::vector<TuneCand>& v = cands[tune_key(o)];
+      int idx = 0;
+      if (round >= 0) idx = std::min(round, (int)v.size() - 1);
+      else
+        for (int k = 1; k < (int)v.size(); ++k)
+          if (v[k].situ_ms < v[idx].situ_ms) idx = k;
+      o.tile = v[idx].tile;
+      o.gp.splitk = v[idx].sk;
+      o.gp.partial = pl->partial;
+    }
+  };
+  size_t rounds = 0;
+  for (auto& kv : cands) rounds = std::max(rounds, kv.second.size());
+  if (rounds <= 1) { apply(0); return; }
+  // stage 2: dummy external buffers (timing does not depend on the values)
+  const size_t slab = (size_t)32 << 20;
+  char* ext = nullptr;
+  HIPCHK(hipMalloc((void**)&ext, 5 * slab));
+  HIPCHK(hipMemsetAsync(ext, 0, 5 * slab, s));
+  RunArgs a;
+  a.x = (const float*)ext;
+  a.t = (const float*)(ext + slab);
+  a.aux = (const float*)(ext + 2 * slab);
+  a.out = (float*)(ext + 3 * slab);
+  a.out2 = (float*)(ext + 4 * slab);
+  const bool prof_was = c->prof_on;
+  const int reps = 3;
+  for (size_t r = 0; r < rounds; ++r) {
+    apply((int)r);
+    std::vector<float> best(pl->ops.size(), 1e30f);
+    for (int rep = 0; rep < reps + 1; ++rep) {   // first repetition warms up
+      c->prof_on = true;
+      c->prof_used = 0;
+      c->prof_fam.clear();
+      c->prof_op.clear();
+      run_ops(c, pl, 0, pl->ops.size(), s, a);
+      c->prof_on = false;
+      HIPCHK(hipStreamSynchronize(s));
+      if (rep == 0) continue;
+      for (size_t i = 0; i < pl->ops.size(); ++i) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+        best[i] = std::min(best[i], ms);
+      }
+    }
+    for (size_t i = 0; i < pl->ops.size(); ++i) {
+      const Op& o = pl->ops[i];
+      if (!o.is_gemm || o.c_ext) continue;
+      std::vector<TuneCand>& v = cands[tune_key(o)];
+      if (r < v.size()) v[r].situ_ms += best[i];
+    }
+  }
+  c->prof_on = prof_was;
+  c->prof_used = 0;
+  c->prof_fam.clear();
+  c->prof_op.clear();
+  apply(-1);
+  HIPCHK(hipStreamSynchronize(s));
+  (void)hipFree(ext);
 }
 
 Plan* get_plan(df_ctx* c, const std::string& key, const std::function<void(Plan*)>& build) {
@@ -1511,7 +1576,7 @@ Plan* get_plan(df_ctx* c, const std::string& key, const std::function<void(Plan*
   }
   finish_plan(c, p.get());
   if (c->autotune) {
-    autotune_plan(p.get(), c->pack_stream);
+    autotune_plan(c, p.get(), c->pack_stream);
     HIPCHK(hipStreamSynchronize(c->pack_stream));
   }
   Plan* r = p.get();

@@ -44,12 +44,17 @@ enum GemmTile {
   // conv3x3 stride-1 kernels with an LDS-staged halo tile (BM output pixels = patches of th x tw, BN couts)
   TILE_HALO_128x64 = 5, TILE_HALO_256x64 = 6, TILE_HALO_128x128 = 7,
   // generic kernel with 8 wavefronts (512 threads): high arithmetic intensity per LDS byte, for split-K streaming
-  TILE_128x256 = 8, TILE_256x128 = 9, TILE_ALL = 10
+  TILE_128x256 = 8, TILE_256x128 = 9,
+  // generic kernel, double-buffered (ring depth 2): less LDS -> 2-5 resident blocks per CU, for short-K layers
+  TILE_128x128_S = 10, TILE_128x64_S = 11, TILE_64x128_S = 12, TILE_64x64_S = 13, TILE_32x128_S = 14, TILE_ALL = 15
 };
+
+static inline bool gemm_tile_is_halo(int cfg) { return cfg >= TILE_HALO_128x64 && cfg <= TILE_HALO_128x128; }
 
 static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
   static const int d[TILE_ALL][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
-                                     {128, 64},  {256, 64}, {128, 128}, {128, 256}, {256, 128}};
+                                     {128, 64},  {256, 64}, {128, 128}, {128, 256}, {256, 128},
+                                     {128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}};
   *bm = d[cfg][0];
   *bn = d[cfg][1];
 }

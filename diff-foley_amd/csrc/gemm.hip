@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   constexpr int AP = BM / RPP, BP = BN / RPP;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the DMA pass");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(NST >= 3 && NST <= 5, "ring depth");
+  static_assert(NST >= 2 && NST <= 5, "ring depth");
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WGN, wn = wid % WGN;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
 
   // ---- prologue: fill NST-1 ring slots
   DF_DMA(0, 0);
-  DF_DMA(1, 1);
+  if (NST > 2) DF_DMA(1, 1);
   if (NST > 3) DF_DMA(2, 2);
   if (NST > 4) DF_DMA(3, 3);
 
@@ -459,8 +459,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     DF_ITER(0);
     if (it >= nt) break;
     DF_ITER(1);
-    if (it >= nt) break;
-    DF_ITER(2);
+    if (NST > 2) {
+      if (it >= nt) break;
+      DF_ITER(2 % NST);
+    }
     if (NST > 3) {
       if (it >= nt) break;
       DF_ITER(3 % NST);
@@ -783,7 +785,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 template <int BM, int BN, int WGM, int WGN, int NST, int MODE>
 hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const size_t lds = (size_t)(BM + BN) * BK * 2 * NST;
+  constexpr size_t ring = (size_t)(BM + BN) * BK * 2 * NST, stage = (size_t)BM * (BN + 4) * 4;   // operand ring | epilogue tile
+  const size_t lds = ring > stage ? ring : stage;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE>),
@@ -827,11 +830,12 @@ hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
 
 bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int nk = p.K / 64;
-  if (tile < TILE_COUNT || tile == TILE_128x256 || tile == TILE_256x128) {
+  if (!gemm_tile_is_halo(tile)) {
+    if (tile < 0 || tile >= TILE_ALL) return false;
     if (p.geglu && ((p.N & 63) != 0 || (p.ldc & 3) != 0)) return false;   // GEGLU needs the vectorised block epilogue
     return splitk == 1 || (batch <= 1 && nk / splitk >= 2);
   }
-  if (tile >= TILE_ALL || p.taps != 9 || p.stride != 1 || p.ups != 0 || p.geglu || batch > 1) return false;
+  if (p.taps != 9 || p.stride != 1 || p.ups != 0 || p.geglu || batch > 1) return false;
   int bm, bn, th, tw;
   gemm_tile_dims(tile, &bm, &bn);
   if (!halo_patch(p.H, p.Wd, bm, &th, &tw)) return false;
@@ -864,6 +868,12 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
     DF_CASE(TILE_32x128, 32, 128, 1, 4, 4)
     DF_CASE(TILE_128x256, 128, 256, 2, 4, 3)
     DF_CASE(TILE_256x128, 256, 128, 4, 2, 3)
+    // double-buffered variants: 2-5 blocks per CU instead of 1-2, for short-K layers (K = 320 is only 5 tiles)
+    DF_CASE(TILE_128x128_S, 128, 128, 2, 2, 2)
+    DF_CASE(TILE_128x64_S, 128, 64, 2, 2, 2)
+    DF_CASE(TILE_64x128_S, 64, 128, 2, 2, 2)
+    DF_CASE(TILE_64x64_S, 64, 64, 2, 2, 2)
+    DF_CASE(TILE_32x128_S, 32, 128, 1, 4, 2)
     case TILE_HALO_128x64: e = launch_halo<128, 64, 2, 2, 4>(p, zdim, stream); break;
     case TILE_HALO_256x64: e = launch_halo<256, 64, 4, 2, 4>(p, zdim, stream); break;
     case TILE_HALO_128x128: e = launch_halo<128, 128, 2, 2, 4>(p, zdim, stream); break;

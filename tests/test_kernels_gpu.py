@@ -44,7 +44,7 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-TILES = [0, 1, 2, 3, 4, 8, 9]
+TILES = [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13, 14]
 
 
 @pytest.mark.parametrize("tile", TILES)
@@ -62,7 +62,7 @@ def test_gemm(tile, M, N, K, splitk):
     assert rel_l2(c.cpu(), ref.cpu()) < 2e-3
 
 
-@pytest.mark.parametrize("tile", [0, 1, 3, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 3, 5, 6, 7, 8, 9, 10, 13, 14])
 @pytest.mark.parametrize("NB,H,W,Cin,Cout,stride,ups,splitk", [
     (2, 16, 64, 128, 96, 1, 0, 2), (8, 2, 8, 256, 64, 1, 0, 4), (3, 4, 16, 64, 192, 1, 0, 1), (1, 16, 16, 64, 64, 1, 0, 1),
     (2, 16, 64, 64, 64, 1, 0, 1), (2, 8, 32, 128, 192, 1, 0, 1), (1, 16, 64, 64, 64, 2, 0, 1),

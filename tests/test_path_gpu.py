@@ -306,3 +306,34 @@ def test_full_classifier_forward_vs_golden(P, full):
     err = rel_l2(grad, g["cls_grad"])
     print(f"full classifier grad rel-L2 {err:.3e} (|grad| mean {g['cls_grad'].abs().mean().item():.3e})")
     assert err < 5e-2
+
+
+def test_tiny_autotuned_plans_match_untuned(P):
+    """The on-device autotuner (isolated ranking + in-situ refinement, engine.hip autotune_plan) only changes tile /
+    split-K choices: an autotuned engine must reproduce the golden vectors for every plan type."""
+    from diff_foley_amd import synth
+    m = P.LatentDiffusion(**P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
+    m.load_state_dict(tiny_state_dict())
+    m.cuda()
+    m.autotune(True)
+    g = gold("g3_tiny_unet.npz")
+    x, c = rnd((2, 4, 16, 64), 102), rnd((2, 32, 128), 101)
+    y = m.apply_model(x.cuda(), torch.tensor([500, 37]).cuda(), c.cuda()).cpu()
+    assert rel_l2(y, g["y_int"]) < FWD_TOL
+    d = m.decode_first_stage(rnd((2, 4, 16, 64), 103).cuda()).cpu()
+    assert rel_l2(d, g["decode"]) < FWD_TOL
+    g5 = gold("g5_tiny_samplers.npz")
+    xT = synth.synthetic_xT(2, seed=21)
+    cc = m.get_learned_conditioning(synth.synthetic_cavp(2, 32, 64, seed=1234).cuda())
+    z, _ = m.sample_log_diff_sampler(cc, 2, "DDIM", 25, unconditional_guidance_scale=4.5,
+                                     unconditional_conditioning=torch.zeros_like(cc), x_T=xT.clone())
+    assert rel_l2(z.cpu(), g5["DDIM_25_z"]) < TRAJ_TOL
+    g6 = gold("g6_tiny_classifier.npz")
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_TINY)))
+    cls.load_state_dict(tiny_classifier_sd())
+    cls.attach(m)
+    vf = synth.synthetic_cavp(2, 33, 64, seed=4321)
+    grad, prob = m.engine.classifier_grad(rnd((2, 4, 16, 64), 105).cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda(),
+                                          want_prob=True)
+    assert torch.allclose(prob.cpu(), g6["cls_p"], atol=2e-2)
+    assert rel_l2(grad.cpu(), g6["cls_grad"]) < 5e-2

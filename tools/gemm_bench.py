@@ -11,7 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import diff_foley_amd  # noqa
 from diff_foley_amd import engine as E
 
-TILES = {0: "128x128", 1: "128x64", 2: "64x128", 3: "64x64", 4: "32x128", 5: "H128x64", 6: "H256x64", 7: "H128x128", 8: "128x256", 9: "256x128"}
+TILES = {0: "128x128", 1: "128x64", 2: "64x128", 3: "64x64", 4: "32x128", 5: "H128x64", 6: "H256x64", 7: "H128x128", 8: "128x256", 9: "256x128",
+         10: "128x128s", 11: "128x64s", 12: "64x128s", 13: "64x64s", 14: "32x128s"}
 # (name, kind, NB, H, W, Cin, Cout) for conv ; (name, 'lin', M, N, K)
 SHAPES = [
     ("conv 320->320 @16x64", "conv", 8, 16, 64, 320, 320),
