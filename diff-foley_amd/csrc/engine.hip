@@ -1551,11 +1551,53 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
       if (r < v.size()) v[r].situ_ms += best[i];
     }
   }
+  apply(-1);
+  // stage 3: tile walk order of the chosen tile (GemmParams::gm), again timed inside the plan
+  static const bool tune_walk = !(getenv("DF_TUNE_WALK") && atoi(getenv("DF_TUNE_WALK")) == 0);
+  if (tune_walk) {
+    static const int gms[] = {0, 1, 2, 4, 8, 16};
+    constexpr int NG = sizeof(gms) / sizeof(gms[0]);
+    std::map<std::string, std::vector<double>> score;
+    for (int r = 0; r < NG; ++r) {
+      for (auto& o : pl->ops)
+        if (o.is_gemm && !o.c_ext) o.gp.gm = gms[r];
+      std::vector<float> best(pl->ops.size(), 1e30f);
+      for (int rep = 0; rep < reps + 1; ++rep) {
+        c->prof_on = true;
+        c->prof_used = 0;
+        c->prof_fam.clear();
+        c->prof_op.clear();
+        run_ops(c, pl, 0, pl->ops.size(), s, a);
+        c->prof_on = false;
+        HIPCHK(hipStreamSynchronize(s));
+        if (rep == 0) continue;
+        for (size_t i = 0; i < pl->ops.size(); ++i) {
+          float ms = 0;
+          HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+          best[i] = std::min(best[i], ms);
+        }
+      }
+      for (size_t i = 0; i < pl->ops.size(); ++i) {
+        const Op& o = pl->ops[i];
+        if (!o.is_gemm || o.c_ext) continue;
+        std::vector<double>& v = score[tune_key(o)];
+        v.resize(NG, 0.0);
+        v[r] += best[i];
+      }
+    }
+    for (auto& o : pl->ops) {
+      if (!o.is_gemm || o.c_ext) continue;
+      const std::vector<double>& v = score[tune_key(o)];
+      int bi = 0;
+      for (int k = 1; k < NG; ++k)
+        if (v[k] < v[bi] * 0.99) bi = k;      // keep the default walk unless another is >1 % faster
+      o.gp.gm = gms[bi];
+    }
+  }
   c->prof_on = prof_was;
   c->prof_used = 0;
   c->prof_fam.clear();
   c->prof_op.clear();
-  apply(-1);
   HIPCHK(hipStreamSynchronize(s));
   (void)hipFree(ext);
 }
@@ -1866,21 +1908,21 @@ int df_profile_end(df_ctx* c, double* ms_by_family, int64_t* count_by_family) {
 }
 
 // Per-op CSV of the last profiled region (call between df_profile_begin and df_profile_end's sync is not needed:
-// call AFTER df_profile_end).  Columns: tag,M,N,K,taps,stride,ups,batch,tile,splitk,ms
+// call AFTER df_profile_end).  Columns: tag,M,N,K,taps,stride,ups,batch,tile,splitk,ms,gm
 int df_profile_dump(df_ctx* c, const char* path) {
   return guard([&] {
     FILE* f = fopen(path, "w");
     if (!f) fail("cannot open %s", path);
-    fprintf(f, "tag,M,N,K,taps,stride,ups,batch,tile,splitk,ms\n");
+    fprintf(f, "tag,M,N,K,taps,stride,ups,batch,tile,splitk,ms,gm\n");
     for (size_t i = 0; i < c->prof_fam.size(); ++i) {
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
       const Op* o = (const Op*)c->prof_op[i];
       if (o->is_gemm)
-        fprintf(f, "%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.5f\n", o->tag, o->gp.M, o->gp.N, o->gp.K, o->gp.taps, o->gp.stride,
-                o->gp.ups, o->batch, o->tile, o->gp.splitk, ms);
+        fprintf(f, "%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.5f,%d\n", o->tag, o->gp.M, o->gp.N, o->gp.K, o->gp.taps, o->gp.stride,
+                o->gp.ups, o->batch, o->tile, o->gp.splitk, ms, o->gp.gm);
       else
-        fprintf(f, "%s,0,0,0,0,0,0,0,0,0,%.5f\n", o->tag, ms);
+        fprintf(f, "%s,0,0,0,0,0,0,0,0,0,%.5f,0\n", o->tag, ms);
     }
     fclose(f);
   });

@@ -34,6 +34,8 @@ struct GemmParams {
   const float* res; long res_bs; int ldr;   // fp32 residual, may alias C
   int geglu;                         // columns come in (x:32 | gate:32) groups, output width N/2
   int store_nchw; int hw_out;        // write C as [batch][N][hw_out] instead of [rows][ldc]
+  int gm;      // tile walk: each XCD's contiguous tile range runs M-fastest inside row groups of `gm` M-tiles (0 = all rows:
+               // plain M-fastest; 1 = N-fastest).  Decides which operand panels an XCD's L2 can share; autotuned in situ.
   int dbg;     // tools only: 1 = every K tile re-reads tile 0 (cache-resident operands; isolates memory latency)
   // split-K
   int splitk; float* partial;
@@ -46,15 +48,21 @@ enum GemmTile {
   // generic kernel with 8 wavefronts (512 threads): high arithmetic intensity per LDS byte, for split-K streaming
   TILE_128x256 = 8, TILE_256x128 = 9,
   // generic kernel, double-buffered (ring depth 2): less LDS -> 2-5 resident blocks per CU, for short-K layers
-  TILE_128x128_S = 10, TILE_128x64_S = 11, TILE_64x128_S = 12, TILE_64x64_S = 13, TILE_32x128_S = 14, TILE_ALL = 15
+  TILE_128x128_S = 10, TILE_128x64_S = 11, TILE_64x128_S = 12, TILE_64x64_S = 13, TILE_32x128_S = 14,
+  // halo kernels with an 8-deep weight ring: more weight bytes in flight per CU for the weight-streaming layers
+  TILE_HALO_128x64_D = 15, TILE_HALO_256x64_D = 16, TILE_ALL = 17
 };
 
-static inline bool gemm_tile_is_halo(int cfg) { return cfg >= TILE_HALO_128x64 && cfg <= TILE_HALO_128x128; }
+static inline bool gemm_tile_is_halo(int cfg) {
+  return (cfg >= TILE_HALO_128x64 && cfg <= TILE_HALO_128x128) || cfg == TILE_HALO_128x64_D || cfg == TILE_HALO_256x64_D;
+}
+static inline int gemm_halo_ring(int cfg) { return (cfg == TILE_HALO_128x64_D || cfg == TILE_HALO_256x64_D) ? 8 : 4; }
 
 static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
   static const int d[TILE_ALL][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
                                      {128, 64},  {256, 64}, {128, 128}, {128, 256}, {256, 128},
-                                     {128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}};
+                                     {128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
+                                     {128, 64}, {256, 64}};
   *bm = d[cfg][0];
   *bn = d[cfg][1];
 }

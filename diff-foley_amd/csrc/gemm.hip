@@ -245,6 +245,19 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
+// Logical tile id -> (M tile, N tile): M-fastest inside row groups of `gm` M-tiles (gm <= 0: one group = plain M-fastest).
+__device__ __forceinline__ void tile_of(int lid, int nbm, int nbn, int gm, int& mt, int& nt) {
+  if (gm <= 0 || gm >= nbm) {
+    mt = lid % nbm;
+    nt = lid / nbm;
+    return;
+  }
+  const int per = gm * nbn, grp = lid / per, rem = lid - grp * per;
+  const int rows = min(gm, nbm - grp * gm);
+  nt = rem / rows;
+  mt = grp * gm + (rem - nt * rows);
+}
+
 template <int BM, int BN, int WGM, int WGN, int NST, int MODE>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // host pass only needs the launch stub (LDS-DMA builtins do not parse there)
@@ -269,9 +282,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  // each XCD owns a contiguous range of logical tiles, M fastest: every XCD streams its own slice of W once
-  // (walking N fastest for activation-heavy layers was measured slower)
-  const int m0 = (lid % nbm) * BM, n0 = (lid / nbm) * BN;
+  // each XCD owns a contiguous range of logical tiles, walked M-fastest inside row groups of p.gm M-tiles: the walk
+  // decides which A / W panels the XCD's 4 MB L2 gets to share (a miss is served by MALL at ~1/5 of the L2 rate)
+  int mt_, nt_;
+  tile_of(lid, nbm, nbn, p.gm, mt_, nt_);
+  const int m0 = mt_ * BM, n0 = nt_ * BN;
 
   int z = blockIdx.z;
   const int nk = p.K / BK;
@@ -593,7 +608,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
     const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int mt = lid % nbm, n0 = (lid / nbm) * BN;
+  int mt, nt_;
+  tile_of(lid, nbm, nbn, p.gm, mt, nt_);
+  const int n0 = nt_ * BN;
 
   const int z = blockIdx.z;
   const int nchunk = p.Cin / BK;
@@ -839,11 +856,11 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   int bm, bn, th, tw;
   gemm_tile_dims(tile, &bm, &bn);
   if (!halo_patch(p.H, p.Wd, bm, &th, &tw)) return false;
-  const int threads = (tile == TILE_HALO_256x64) ? 512 : 256, rpp = threads / 8;
+  const int threads = (tile == TILE_HALO_256x64 || tile == TILE_HALO_256x64_D) ? 512 : 256, rpp = threads / 8;
   const int hr = (bm / (th * tw)) * (th + 2) * (tw + 2);
   const int apass = (hr + rpp - 1) / rpp, wpass = (bn + rpp - 1) / rpp;
   if (apass > 12) return false;
-  const int nstw = 4;   // weight ring depth of the halo kernels (6 measured slower)
+  const int nstw = gemm_halo_ring(tile);   // weight ring depth (4; 8 for the weight-streaming variants)
   if (((size_t)2 * apass * rpp + (size_t)nstw * wpass * rpp) * 128 > 160 * 1024) return false;
   const int nchunk = p.Cin / 64;
   return splitk == 1 || nchunk / splitk >= 1;
@@ -877,6 +894,8 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
     case TILE_HALO_128x64: e = launch_halo<128, 64, 2, 2, 4>(p, zdim, stream); break;
     case TILE_HALO_256x64: e = launch_halo<256, 64, 4, 2, 4>(p, zdim, stream); break;
     case TILE_HALO_128x128: e = launch_halo<128, 128, 2, 2, 4>(p, zdim, stream); break;
+    case TILE_HALO_128x64_D: e = launch_halo<128, 64, 2, 2, 8>(p, zdim, stream); break;
+    case TILE_HALO_256x64_D: e = launch_halo<256, 64, 4, 2, 8>(p, zdim, stream); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;

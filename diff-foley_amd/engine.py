@@ -77,6 +77,7 @@ _SIGS = {
     "df_test_attention": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "df_test_peak": [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p],
+    "df_test_fill": [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p],
 }
 
 

@@ -147,6 +147,10 @@ int df_test_attention(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, co
  * (n = iterations per wavefront of 4 independent v_mfma_f32_32x32x16_bf16; grid blocks x 256 threads); kind 1:
  * streaming copy of n bytes; kind 2: streaming read of n bytes. */
 int df_test_peak(int kind, const void* src_dev, void* dst_dev, size_t n, int blocks, void* stream);
+/* L2 -> CU fill-rate probes: kind 3 LDS-DMA, 4 global_load_dwordx4 -> VGPR, 5 global_load + ds_write_b128.  Every block
+ * re-reads its span-byte window n times; stride_blk bytes between the windows of consecutive blocks. */
+int df_test_fill(int kind, const void* src_dev, void* dst_dev, size_t span, size_t stride_blk, int n, int blocks,
+                 void* stream);
 
 
 #ifdef __cplusplus

@@ -12,7 +12,7 @@ import diff_foley_amd  # noqa
 from diff_foley_amd import engine as E
 
 TILES = {0: "128x128", 1: "128x64", 2: "64x128", 3: "64x64", 4: "32x128", 5: "H128x64", 6: "H256x64", 7: "H128x128", 8: "128x256", 9: "256x128",
-         10: "128x128s", 11: "128x64s", 12: "64x128s", 13: "64x64s", 14: "32x128s"}
+         10: "128x128s", 11: "128x64s", 12: "64x128s", 13: "64x64s", 14: "32x128s", 15: "H128x64d", 16: "H256x64d"}
 # (name, kind, NB, H, W, Cin, Cout) for conv ; (name, 'lin', M, N, K)
 SHAPES = [
     ("conv 320->320 @16x64", "conv", 8, 16, 64, 320, 320),
@@ -20,6 +20,7 @@ SHAPES = [
     ("conv 640->640 @8x32", "conv", 8, 8, 32, 640, 640),
     ("conv 1280->1280 @4x16", "conv", 8, 4, 16, 1280, 1280),
     ("conv 2560->1280 @2x8", "conv", 8, 2, 8, 2560, 1280),
+    ("conv 1280->1280 @2x8", "conv", 8, 2, 8, 1280, 1280),
     ("lin ff1 8192x2560x320", "lin", 8192, 2560, 320),
     ("lin ff2 8192x320x1280", "lin", 8192, 320, 1280),
     ("lin proj 8192x320x320", "lin", 8192, 320, 320),
@@ -72,17 +73,18 @@ def main():
             call = lambda t, sk: L.df_test_gemm(ptr(a), ptr(w), ptr(c), M, N, K, t, sk, st)
         res = []
         for t in TILES:
-            if t in (5, 6, 7) and sh[1] != "conv":
+            if t in (5, 6, 7, 15, 16) and sh[1] != "conv":
                 continue
             for sk in (1, 2, 4, 8, 16, 32):
-                if sk > 1 and (nk // sk < 4 or (t in (5, 6, 7) and sh[5] // 64 // sk < 1)):
+                if sk > 1 and (nk // sk < 4 or (t in (5, 6, 7, 15, 16) and sh[5] // 64 // sk < 1)):
                     break
                 if call(t, sk) != 0:
                     continue
                 us = timeit(lambda: call(t, sk))
                 res.append((us, t, sk))
         res.sort()
-        best = ", ".join(f"{TILES[t]}/sk{sk}: {us:6.1f}us {flops / us / 1e6:6.0f}TF" for us, t, sk in res[:5])
+        top = len(res) if len(sys.argv) > 2 and sys.argv[2] == "all" else 5
+        best = ", ".join(f"{TILES[t]}/sk{sk}: {us:6.1f}us {flops / us / 1e6:6.0f}TF" for us, t, sk in res[:top])
         print(f"{sh[0]:26s} {flops / 1e9:6.1f} GF | {best}")
 
 
