@@ -7,7 +7,7 @@ this package is the Python host side mirroring the reference's interface.
 from . import synth  # noqa: F401
 from . import schedule  # noqa: F401
 from . import engine  # noqa: F401
-from .ldm import LatentDiffusion, AlignmentClassifier, instantiate_from_config  # noqa: F401
+from .ldm import LatentDiffusion, AlignmentClassifier, CAVPInference, instantiate_from_config  # noqa: F401
 from .samplers import DDIMSampler, PLMSSampler, DPMSolverSampler  # noqa: F401
 
 

@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-SRCS="gemm elementwise attention backward diag engine"
+SRCS="gemm elementwise attention backward cavp diag engine"
 mkdir -p build/bf16 build/f16
 pids=()
 for v in bf16 f16; do

@@ -32,6 +32,8 @@ struct GemmParams {
   const float* bias;                 // [N]
   const float* rowbias; int ld_rowbias; int rows_per_sample; int rowbias_mode;  // 1: by sample, 2: by position
   const float* res; long res_bs; int ldr;   // fp32 residual, may alias C
+  int relu;                          // max(v, 0) after bias / residual (CAVP encoder ConvModule activation)
+  uint16_t* aux; int ld_aux;         // optional second output: operand-type copy of the stored value, [row][ld_aux]
   int geglu;                         // columns come in (x:32 | gate:32) groups, output width N/2
   int store_nchw; int hw_out;        // write C as [batch][N][hw_out] instead of [rows][ldc]
   int gm;      // tile walk: each XCD's contiguous tile range runs M-fastest inside row groups of `gm` M-tiles (0 = all rows:

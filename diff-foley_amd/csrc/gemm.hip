@@ -40,6 +40,8 @@ __device__ __forceinline__ float epi_bias(const GemmParams& p, int row, int col,
 }
 
 __device__ __forceinline__ void epi_store(const GemmParams& p, int z, int row, int col, int nout, float v) {
+  if (p.relu) v = fmaxf(v, 0.f);
+  if (p.aux) p.aux[(long)row * p.ld_aux + col] = f2bf(v);
   long idx;
   if (p.store_nchw) {
     const int b = row / p.hw_out, px = row - b * p.hw_out;
@@ -210,34 +212,43 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
     return;
   }
   constexpr int CPR = BN / 4;
-#pragma unroll 4
-  for (int e = tid; e < BM * CPR; e += NT) {
-    const int r = e / CPR, c4 = (e - r * CPR) * 4;
-    const int row = rowmap(r), col = n0 + c4;
-    const int rc = min(row, p.M - 1), cc = min(col, p.N - 4);
-    float4 v = *reinterpret_cast<const float4*>(&sC[r * LDC + c4]);
-    v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
-    if (has_bias) {
-      const float4 b = *reinterpret_cast<const float4*>(&p.bias[cc]);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    }
-    if (has_rb) {
-      const int ri = (p.rowbias_mode == 1) ? (rc / p.rows_per_sample) : (rc % p.rows_per_sample);
-      const float4 b = *reinterpret_cast<const float4*>(&p.rowbias[(long)ri * p.ld_rowbias + cc]);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    }
-    if (has_res) {
-      const float4 b = *reinterpret_cast<const float4*>(&p.res[(long)batch * p.res_bs + (long)rc * p.ldr + cc]);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    }
-    if (row < p.M && col < p.N) {
-      const long idx = (long)batch * p.c_bs + (long)row * p.ldc + col;
-      if (p.out_bf16)
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-      else
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;
-    }
+  // EXTRA = ReLU and/or the second (operand-type) output of the CAVP encoder; kept out of the UNet's loop body
+#define DF_EPI_LOOP(EXTRA)                                                                                          \
+  _Pragma("unroll 4") for (int e = tid; e < BM * CPR; e += NT) {                                                    \
+    const int r = e / CPR, c4 = (e - r * CPR) * 4;                                                                  \
+    const int row = rowmap(r), col = n0 + c4;                                                                       \
+    const int rc = min(row, p.M - 1), cc = min(col, p.N - 4);                                                       \
+    float4 v = *reinterpret_cast<const float4*>(&sC[r * LDC + c4]);                                                 \
+    v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;                                                 \
+    if (has_bias) {                                                                                                 \
+      const float4 b = *reinterpret_cast<const float4*>(&p.bias[cc]);                                               \
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
+    }                                                                                                               \
+    if (has_rb) {                                                                                                   \
+      const int ri = (p.rowbias_mode == 1) ? (rc / p.rows_per_sample) : (rc % p.rows_per_sample);                   \
+      const float4 b = *reinterpret_cast<const float4*>(&p.rowbias[(long)ri * p.ld_rowbias + cc]);                  \
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
+    }                                                                                                               \
+    if (has_res) {                                                                                                  \
+      const float4 b = *reinterpret_cast<const float4*>(&p.res[(long)batch * p.res_bs + (long)rc * p.ldr + cc]);    \
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
+    }                                                                                                               \
+    if ((EXTRA) && p.relu) {                                                                                        \
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);                   \
+    }                                                                                                               \
+    if (row < p.M && col < p.N) {                                                                                   \
+      const long idx = (long)batch * p.c_bs + (long)row * p.ldc + col;                                              \
+      if (p.out_bf16)                                                                                               \
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
+      else                                                                                                          \
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;                                        \
+      if ((EXTRA) && p.aux)                                                                                         \
+        *reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
+    }                                                                                                               \
   }
+  if (p.relu || p.aux) DF_EPI_LOOP(true)
+  else DF_EPI_LOOP(false)
+#undef DF_EPI_LOOP
 }
 
 template <int N_>
@@ -498,7 +509,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     return;
   }
   const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
-                      (p.ld_rowbias & 3) == 0 && (p.res_bs & 3) == 0 && (p.c_bs & 3) == 0;
+                      (p.ld_rowbias & 3) == 0 && (p.res_bs & 3) == 0 && (p.c_bs & 3) == 0 && (p.ld_aux & 3) == 0;
   if (vec_ok) {
     epilogue_block<BM, BN, NT, TM, TN>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid,
                                         [&](int r) { return m0 + r; });
@@ -761,7 +772,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
     return (g < npatch) ? (n * p.H + (gr / npx) * TH + y) * p.Wd + (gr % npx) * TW + x : p.M;
   };
   const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
-                      (p.ld_rowbias & 3) == 0;
+                      (p.ld_rowbias & 3) == 0 && (p.ld_aux & 3) == 0;
   if (vec_ok) {
     epilogue_block<BM, BN, NT, TM, TN>(p, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap);
     return;

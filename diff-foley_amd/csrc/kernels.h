@@ -79,3 +79,16 @@ hipError_t launch_cls_head_bwd(const float* prob, const float* w, float* dh, uin
 // Linear weight [O][I] fp32 -> transposed bf16 written at out[i*ldo + off + o]  (ldo >= off + O)
 hipError_t launch_pack_linear_t(const float* w, uint16_t* out, int O, int I, int ldo, int off, hipStream_t s);
 hipError_t launch_pack_conv_bwd(const float* w, uint16_t* out, int O, int I, int Opad, hipStream_t s);
+
+// ---- CAVP video encoder data movement (csrc/cavp.hip) ----------------------------------------------------------
+// fp32 NCHW frames [F][3][H][W] -> im2col rows [F*OH*OW][KP] of the (1,7,7) stride-2 pad-3 stem (k = (ky*7+kx)*3 + c)
+hipError_t launch_stem_im2col(const float* x, uint16_t* out, int F, int H, int W, int OH, int OW, int KP, hipStream_t s);
+hipError_t launch_maxpool3x3s2(const uint16_t* x, uint16_t* out, int F, int H, int W, int OH, int OW, int C, hipStream_t s);
+hipError_t launch_subsample2(const uint16_t* x, uint16_t* out, int F, int H, int W, int C, hipStream_t s);
+// [F][HW][C] -> [F][HW][3C] = (x[t-1] | x[t] | x[t+1]) with zeros outside each clip of T frames
+hipError_t launch_tcat3(const uint16_t* x, uint16_t* out, int F, int T, int HW, int C, hipStream_t s);
+// Conv3d weight with eval BatchNorm folded: operand [O][KP] (k = tap*I + i) + fp32 bias [O]
+hipError_t launch_pack_conv3d_bn(const float* w, const float* gamma, const float* beta, const float* mean,
+                                 const float* var, float eps, uint16_t* out, float* bias, int O, int I, int KT, int KH,
+                                 int KW, int KP, hipStream_t s);
+hipError_t launch_l2norm_rows(float* x, int rows, int C, hipStream_t s);

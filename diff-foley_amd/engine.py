@@ -39,6 +39,10 @@ class CondConfig(C.Structure):
     _fields_ = [("origin_dim", C.c_int), ("embed_dim", C.c_int), ("seq_len", C.c_int)]
 
 
+class CavpConfig(C.Structure):
+    _fields_ = [("stage_blocks", C.c_int * 4), ("base_channels", C.c_int), ("embed_dim", C.c_int)]
+
+
 _libs = {}
 
 _SIGS = {
@@ -46,6 +50,8 @@ _SIGS = {
     "df_config_unet": [C.c_void_p, C.POINTER(UNetConfig)],
     "df_config_vae": [C.c_void_p, C.POINTER(VaeConfig)],
     "df_config_cond": [C.c_void_p, C.POINTER(CondConfig)],
+    "df_config_cavp": [C.c_void_p, C.POINTER(CavpConfig)],
+    "df_cavp_encode": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "df_config_classifier": [C.c_void_p, C.POINTER(UNetConfig)],
     "df_load_tensor": [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int],
     "df_load_tensor_dev": [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int],
@@ -195,6 +201,21 @@ class Engine:
     def config_cond(self, cfg):
         k = CondConfig(cfg["origin_dim"], cfg["embed_dim"], cfg["seq_len"])
         _chk(self.L.df_config_cond(self._h, C.byref(k)), self.L)
+
+    def config_cavp(self, cfg):
+        k = CavpConfig((C.c_int * 4)(*cfg["stage_blocks"]), cfg["base_channels"], cfg["embed_dim"])
+        self.cavp_embed_dim = cfg["embed_dim"]
+        _chk(self.L.df_config_cavp(self._h, C.byref(k)), self.L)
+
+    def cavp_encode(self, video, normalize=True):
+        """video (B,T,3,H,W) fp32 RGB in [0,1] -> (B,T,embed) (CAVP_Inference.encode_video, pool=False)."""
+        video = _dev_f32(video, self.device)
+        B, T, c3, H, W = video.shape
+        if c3 != 3:
+            raise RuntimeError("cavp_encode: video must be (B,T,3,H,W)")
+        out = torch.empty(B, T, self.cavp_embed_dim, device=self.device, dtype=torch.float32)
+        _chk(self.L.df_cavp_encode(self._h, _ptr(video), _ptr(out), B, T, H, W, int(bool(normalize)), _stream()), self.L)
+        return out
 
     def load_tensor(self, name, t):
         shape = (C.c_int64 * t.dim())(*t.shape)

@@ -41,6 +41,7 @@ def instantiate_from_config(config):
         "diff_foley.models.diffusion.ddpm.LatentDiffusion": LatentDiffusion,
         "diff_foley.modules.double_guidance.alignment_classifier.Alignment_Classifier_Double_Guidance": AlignmentClassifier,
     }
+    alias["model.cavp_model.CAVP_Inference"] = CAVPInference      # inference/config/Stage1_CAVP.yaml:2
     if target in alias:
         return alias[target](**dict(config.get("params", dict())))
     module, cls = target.rsplit(".", 1)
@@ -286,3 +287,67 @@ class AlignmentClassifier:
         if self.engine is None:
             raise RuntimeError("AlignmentClassifier.attach(ldm) first")
         return self.engine.classifier_grad(x, t, video_feat)
+
+
+class CAVPInference:
+    """Mirror of the reference ``CAVP_Inference`` (inference/model/cavp_model.py:9-65) for the VIDEO branch only, the
+    part Stage-2 inference uses (Extract_CAVP_Features, inference/demo_util.py:80-170): SlowOnly-R50 backbone +
+    ``video_project_head``.  ``encode_video(video, normalize, pool=False)`` runs entirely in libdfengine.so
+    (df_cavp_encode); the spectrogram branch (training-time contrastive partner) is not on the path."""
+
+    def __init__(self, video_encode="Slowonly_pool", spec_encode="cnn14_pool", embed_dim=512, video_pretrained=False,
+                 audio_pretrained=False, stage_blocks=(3, 4, 6, 3), precision=None, **ignored):
+        if video_encode != "Slowonly_pool":
+            raise NotImplementedError("only video_encode='Slowonly_pool' exists in the reference (cavp_model.py:25)")
+        self.cfg = dict(stage_blocks=[int(v) for v in stage_blocks], base_channels=64, embed_dim=int(embed_dim))
+        self.precision = precision
+        self._state = None
+        self.engine = None
+        self.device = torch.device("cpu")
+
+    def load_state_dict(self, state_dict, strict=False):
+        keep = ("video_encoder.", "video_project_head.")
+        self._state = {k: v for k, v in state_dict.items() if k.startswith(keep) and "num_batches_tracked" not in k}
+        missing = [] if self._state else ["video_encoder.*"]
+        return missing, [k for k in state_dict if not k.startswith(keep)]
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("diff_foley_amd.CAVPInference runs on a ROCm GPU only (no CPU path)")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(device)
+        self.device = device
+        self.engine = E.Engine(device, precision=self.precision)
+        self.engine.config_cavp(self.cfg)
+        if self._state is not None:
+            for k, v in self._state.items():
+                self.engine.load_tensor("cavp." + k, v)
+            self.engine.finalize()
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def eval(self):
+        return self
+
+    def autotune(self, enable=True):
+        self._require().autotune(enable)
+        return self
+
+    def _require(self):
+        if self.engine is None or self._state is None:
+            raise RuntimeError("CAVPInference: call load_state_dict() and .cuda() first (the encoder runs in "
+                               "libdfengine.so on a ROCm GPU; there is no CPU fallback)")
+        return self.engine
+
+    @torch.no_grad()
+    def encode_video(self, video, normalize=False, train=False, pool=True):
+        """video (B,T,3,H,W) -> (B,T,embed_dim) for pool=False (cavp_model.py:47-65).  pool=True is the training-time
+        MaxPool1d(16) contrastive head (cavp_model.py:58-59), not used by Stage-2 inference."""
+        if pool:
+            raise NotImplementedError("encode_video(pool=True) is the contrastive-training head; inference calls "
+                                      "pool=False (inference/demo_util.py:161)")
+        return self._require().cavp_encode(video, normalize=normalize)

@@ -177,6 +177,56 @@ def state_dict_spec(unet=UNET_FULL, vae=VAE_FULL, cond=COND_FULL):
     return spec
 
 
+CAVP_FULL = dict(stage_blocks=[3, 4, 6, 3], base_channels=64, embed_dim=512)
+CAVP_TINY = dict(stage_blocks=[1, 1, 1, 1], base_channels=64, embed_dim=64)
+
+
+def _cm3d(spec, p, cin, cout, k):
+    spec[p + ".conv.weight"] = (cout, cin) + tuple(k)
+    for n in ("weight", "bias", "running_mean", "running_var"):
+        spec[p + ".bn." + n] = (cout,)
+
+
+def cavp_spec(cfg=CAVP_FULL):
+    """CAVP_Inference.state_dict() keys of the video branch: SlowOnly-R50 backbone (inference/model/cavp_modules.py:
+    1233-1268, 757-779, 484-518, 167-330) + video_project_head (inference/model/cavp_model.py:27-29)."""
+    spec = OrderedDict()
+    base = cfg["base_channels"]
+    _cm3d(spec, "video_encoder.conv1", 3, base, (1, 7, 7))
+    inplanes = base
+    for li, nb in enumerate(cfg["stage_blocks"]):
+        planes = base * 2 ** li
+        inflate = li >= 2                                   # SlowOnly: inflate=(0,0,1,1)
+        for bi in range(nb):
+            p = f"video_encoder.layer{li + 1}.{bi}"
+            _cm3d(spec, p + ".conv1", inplanes, planes, (3, 1, 1) if inflate else (1, 1, 1))
+            _cm3d(spec, p + ".conv2", planes, planes, (1, 3, 3))
+            _cm3d(spec, p + ".conv3", planes, planes * 4, (1, 1, 1))
+            if bi == 0:                                     # stride != 1 or inplanes != planes*4 holds for every stage
+                _cm3d(spec, p + ".downsample", inplanes, planes * 4, (1, 1, 1))
+            inplanes = planes * 4
+    spec["video_project_head.weight"] = (cfg["embed_dim"], inplanes)
+    spec["video_project_head.bias"] = (cfg["embed_dim"],)
+    return spec
+
+
+def synthetic_video(batch, frames=32, size=224, seed=77):
+    """Frames as Extract_CAVP_Features feeds them (inference/demo_util.py:100-103,150-161): RGB in [0,1], (B,T,3,H,W).
+    Smooth random fields (a few low-frequency sinusoids per channel) so that the 7x7 stem sees image-like input."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, size), torch.linspace(0, 1, size), indexing="ij")
+    out = torch.zeros(batch, frames, 3, size, size)
+    for b in range(batch):
+        for c in range(3):
+            k = torch.rand(4, 5, generator=g)
+            for j in range(4):
+                fx, fy, ph, sp, am = (k[j, 0] * 6, k[j, 1] * 6, k[j, 2] * 6.28, k[j, 3] * 2, 0.1 + 0.15 * k[j, 4])
+                t = torch.arange(frames).view(-1, 1, 1) / 4.0
+                out[b, :, c] += am * torch.sin(6.28 * (fx * xx + fy * yy) + ph + sp * t)
+    out = out + 0.03 * torch.randn(out.shape, generator=g)
+    return (out + 0.5).clamp_(0, 1)
+
+
 def classifier_spec(cfg=CLS_FULL):
     """Alignment_Classifier_Double_Guidance.state_dict() keys for the backbone (``model.*``)."""
     return unet_spec(cfg, "model.", encoder_only=True)
@@ -188,7 +238,8 @@ def make_tensor(name, shape, seed=0):
 
     ndim>=2: U(-1,1)*sqrt(3/fan_in)  (unit-gain, also for the reference's zero-initialised
     modules, which would otherwise make the whole network output exactly 0);
-    1-D '.weight' (norm scales): 1 + 0.1*U;  1-D '.bias': 0.05*U;  pos_emb: 0.05*U."""
+    1-D '.weight' (norm scales): 1 + 0.1*U;  1-D '.bias' / running_mean: 0.05*U;  running_var: 1 + 0.2*U;
+    pos_emb: 0.05*U;  CAVP backbone convs: He-uniform U*sqrt(6/fan_in)."""
     key = [int(seed) & 0xFFFFFFFFFFFFFFFF, zlib.crc32(name.encode())]
     g = np.random.Generator(np.random.Philox(key=key))
     n = int(np.prod(shape))
@@ -198,8 +249,13 @@ def make_tensor(name, shape, seed=0):
     if len(shape) >= 2:
         if name.endswith("pos_emb.weight"):
             u *= 0.05
+        elif name.startswith("video_encoder."):      # ReLU network: He-uniform; the residual branch's last conv at 1/2
+            u *= np.float32(np.sqrt(6.0 / float(np.prod(shape[1:]))) * (0.5 if ".conv3." in name else 1.0))
         else:
             u *= np.float32(np.sqrt(3.0 / float(np.prod(shape[1:]))))
+    elif name.endswith("running_var"):
+        u *= 0.2
+        u += 1.0
     elif name.endswith(".weight"):
         u *= 0.1
         u += 1.0

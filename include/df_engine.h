@@ -53,6 +53,14 @@ typedef struct {
   int origin_dim, embed_dim, seq_len;
 } df_cond_config;
 
+/* CAVP video encoder = ResNet3dSlowOnly(depth 50) + video_project_head (inference/model/cavp_model.py:21-29,
+ * inference/model/cavp_modules.py:1233-1268): blocks per stage (3,4,6,3), stem width 64, feature width embed_dim. */
+typedef struct {
+  int stage_blocks[4];
+  int base_channels;
+  int embed_dim;
+} df_cavp_config;
+
 /* ---- lifetime ------------------------------------------------------------------------------ */
 int df_create(int device, df_ctx** out);
 void df_destroy(df_ctx* ctx);
@@ -71,6 +79,10 @@ int df_config_unet(df_ctx* ctx, const df_unet_config* cfg);
 int df_config_vae(df_ctx* ctx, const df_vae_config* cfg);
 int df_config_cond(df_ctx* ctx, const df_cond_config* cfg);
 int df_config_classifier(df_ctx* ctx, const df_unet_config* cfg);
+/* Tensors of the CAVP video branch are loaded under "cavp." + the CAVP_Inference state_dict key
+ * ("cavp.video_encoder.conv1.conv.weight", "cavp.video_encoder.layer1.0.conv1.bn.running_var",
+ * "cavp.video_project_head.weight", ...). */
+int df_config_cavp(df_ctx* ctx, const df_cavp_config* cfg);
 int df_load_tensor(df_ctx* ctx, const char* name, const float* host, const int64_t* shape, int ndim);
 /* Same, but the fp32 source already lives on the device (used after an RCCL weight broadcast). */
 int df_load_tensor_dev(df_ctx* ctx, const char* name, const float* dev, const int64_t* shape, int ndim);
@@ -82,6 +94,13 @@ int df_autotune(df_ctx* ctx, int enable);
 /* ---- LatentDiffusion.get_learned_conditioning (ddpm.py:568-579 -> video_feat_encoder.py:12-18)
  * feats [B][T][origin_dim] fp32 -> out [B][T][embed_dim] fp32 */
 int df_cond_encode(df_ctx* ctx, const float* feats_dev, float* out_dev, int B, int T, void* stream);
+
+/* ---- CAVP_Inference.encode_video(video, normalize, pool=False) (inference/model/cavp_model.py:47-65), as called by
+ * Extract_CAVP_Features.forward (inference/demo_util.py:150-167): video [B][T][3][H][W] fp32 RGB in [0,1] (H, W
+ * multiples of 32; the reference uses 224) -> out [B][T][embed_dim] fp32, rows L2-normalised when normalize != 0.
+ * Clips are independent; the temporal (3,1,1) convolutions zero-pad inside each clip of T frames. */
+int df_cavp_encode(df_ctx* ctx, const float* video_dev, float* out_dev, int B, int T, int H, int W, int normalize,
+                   void* stream);
 
 /* ---- UNetModel.forward (openai_unetmodel.py:710-742) through LatentDiffusion.apply_model (ddpm.py:925-1026).
  * The cross-attention context is step-invariant, so it is set once per sample() call: K/V projections of

@@ -141,3 +141,61 @@ def build_reference_classifier(cls_cfg, state_dict):
     n = len("model.")
     missing, unexpected = m.load_state_dict({k[n:]: v for k, v in state_dict.items()}, strict=True)
     return m.eval()
+
+
+def import_reference_cavp():
+    """Import the reference's ``CAVP_Inference`` (inference/model/cavp_model.py) on CPU.
+
+    ``mmcv`` 1.7.1 is a third-party dependency that is neither under /root/reference nor installed, so the few names
+    cavp_modules.py:8-18 imports from it are provided by a DECLARED STAND-IN: ``ConvModule`` = Conv3d(bias as given) ->
+    BatchNorm3d (registered as ``.bn``) -> ReLU when ``act_cfg`` is not None, which is mmcv's documented behaviour for
+    ``conv_cfg=dict(type='Conv3d'), norm_cfg=dict(type='BN3d')`` with the default order ('conv','norm','act').  The
+    reference's own code then decides every kernel size, stride, inflation and downsample (the topology the oracle
+    restates); the numerical behaviour of ConvModule itself is NOT pinned by the reference (parity unpinned at the
+    mmcv boundary).  Used only by tests/golden/make_golden.py --cavp."""
+    cnn = types.ModuleType("mmcv.cnn")
+
+    class ConvModule(nn.Module):
+        def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                     bias="auto", conv_cfg=None, norm_cfg=None, act_cfg=dict(type="ReLU"), **kw):
+            super().__init__()
+            assert conv_cfg is not None and conv_cfg["type"] == "Conv3d"
+            with_norm = norm_cfg is not None
+            if bias == "auto":
+                bias = not with_norm
+            self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                  dilation=dilation, groups=groups, bias=bias)
+            if with_norm:
+                assert norm_cfg["type"] == "BN3d"
+                self.bn = nn.BatchNorm3d(out_channels)
+            self.with_norm = with_norm
+            self.act = nn.ReLU() if act_cfg is not None else None
+
+        @property
+        def norm(self):
+            return self.bn
+
+        def forward(self, x):
+            x = self.conv(x)
+            if self.with_norm:
+                x = self.bn(x)
+            return self.act(x) if self.act is not None else x
+
+    cnn.ConvModule = ConvModule
+    cnn.NonLocal3d = None
+    cnn.build_activation_layer = lambda cfg: nn.ReLU()
+    cnn.constant_init = lambda *a, **k: None
+    cnn.kaiming_init = lambda *a, **k: None
+    runner = types.ModuleType("mmcv.runner")
+    runner._load_checkpoint = runner.load_checkpoint = lambda *a, **k: None
+    utils = types.ModuleType("mmcv.utils")
+    utils.print_log = lambda *a, **k: None
+    utils._BatchNorm = nn.modules.batchnorm._BatchNorm
+    mm = types.ModuleType("mmcv")
+    mm.cnn, mm.runner, mm.utils = cnn, runner, utils
+    sys.modules.update({"mmcv": mm, "mmcv.cnn": cnn, "mmcv.runner": runner, "mmcv.utils": utils})
+    inf = os.path.join(REF, "inference")
+    if inf not in sys.path:
+        sys.path.insert(0, inf)
+    from model.cavp_model import CAVP_Inference
+    return CAVP_Inference

@@ -250,13 +250,46 @@ def full(seed=0):
     save("g6_full_classifier.npz", cls_p=p, cls_grad=g)
 
 
+def cavp():
+    """G7: CAVP video encoder.  The reference's ResNet3dSlowOnly / CAVP_Inference code runs with the
+    declared mmcv.ConvModule stand-in of oracle/ref_import.py (mmcv itself is absent): pins topology and key layout."""
+    from oracle import cavp as ocavp
+    CAVP_Inference = ref_import.import_reference_cavp()
+    import model.cavp_modules as cm
+    t0 = time.time()
+    for tag, cfg, T, size in (("tiny", synth.CAVP_TINY, 4, 64), ("full", synth.CAVP_FULL, 8, 224)):
+        m = CAVP_Inference("Slowonly_pool", "cnn14_pool", cfg["embed_dim"])
+        if tag == "tiny":          # same classes, fewer blocks per stage
+            m.video_encoder = cm.ResNet3dSlowOnly(depth=50, pretrained=None, stage_blocks=tuple(cfg["stage_blocks"]))
+        m.eval()
+        spec = synth.cavp_spec(cfg)
+        ref = {k: tuple(v.shape) for k, v in m.state_dict().items()
+               if (k.startswith("video_encoder.") or k.startswith("video_project_head.")) and "num_batches" not in k}
+        assert ref == {k: tuple(v) for k, v in spec.items()}, set(ref.items()) ^ set((k, tuple(v)) for k, v in spec.items())
+        sd = synth.make_state_dict(spec)
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all(not k.startswith("video_") or "num_batches" in k for k in missing), (missing, unexpected)
+        video = synth.synthetic_video(1, T, size, seed=77)
+        with torch.no_grad():
+            f = m.encode_video(video, normalize=True, pool=False)
+            f_raw = m.encode_video(video, normalize=False, pool=False)
+        o = ocavp.encode_video(sd, video, stage_blocks=tuple(cfg["stage_blocks"]))
+        err = (o - f).abs().max().item()
+        print(f"cavp {tag}: feats {tuple(f.shape)}  oracle-vs-reference max|d| = {err:.2e}  ({time.time() - t0:.1f}s)")
+        assert err < 1e-5
+        save(f"g7_cavp_{tag}.npz", feats=f, feats_raw=f_raw)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiny", action="store_true")
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--cavp", action="store_true", help="CAVP video encoder vectors (reference topology, mmcv stand-in)")
     a = ap.parse_args()
     torch.set_num_threads(8)
     if a.tiny:
         tiny()
     if a.full:
         full()
+    if a.cavp:
+        cavp()

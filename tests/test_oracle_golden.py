@@ -166,3 +166,23 @@ def test_g6_full_classifier():
     tt = torch.tensor([500, 37])
     close(cls(x, tt, vf), g["cls_p"], 1e-5)
     close(osamp.classifier_grad(cls, x, tt, vf), g["cls_grad"], 1e-4)
+
+
+def test_g7_cavp_oracle_matches_reference_vectors():
+    """CAVP video encoder restatement (oracle/cavp.py) against vectors produced by the reference's own
+    ResNet3dSlowOnly / CAVP_Inference code (mmcv.ConvModule stand-in declared in oracle/ref_import.py)."""
+    from oracle import cavp as ocavp
+    from diff_foley_amd import synth
+    g = gold("g7_cavp_tiny.npz")
+    sd = synth.make_state_dict(synth.cavp_spec(synth.CAVP_TINY))
+    v = synth.synthetic_video(1, 4, 64, seed=77)
+    f = ocavp.encode_video(sd, v, stage_blocks=tuple(synth.CAVP_TINY["stage_blocks"]))
+    assert torch.allclose(f, g["feats"], atol=1e-5)
+    f = ocavp.encode_video(sd, v, normalize=False, stage_blocks=tuple(synth.CAVP_TINY["stage_blocks"]))
+    assert torch.allclose(f, g["feats_raw"], atol=1e-4, rtol=1e-4)
+    g = gold("g7_cavp_full.npz")
+    sd = synth.make_state_dict(synth.cavp_spec())
+    v = synth.synthetic_video(1, 8, 224, seed=77)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    f = ocavp.encode_video(sd, v)
+    assert torch.allclose(f, g["feats"], atol=1e-5)

@@ -54,3 +54,39 @@ for it in range(2):
     t1 = time.perf_counter()
 print(f"config[2] B=8 DPM-Solver++-50 + classifier guidance: {1e3 * (t1 - t0):8.1f} ms ({50 / (t1 - t0):6.1f} steps/s), "
       f"finite={bool(torch.isfinite(z).all())}")
+
+# ---- BASELINE.json configs[4] (per GPU): on-device CAVP encoder -> cond stage -> sampler -> VAE decode, fp16 operands,
+# one 8 s video (32 frames at 4 fps, 224x224) x 8 candidates
+del m, cls
+torch.cuda.empty_cache()
+for prec in ("fp16", "bf16"):
+    cavp = P.CAVPInference(embed_dim=512, precision=prec)
+    cavp.load_state_dict(synth.make_state_dict(synth.cavp_spec(), 0))
+    cavp.cuda()
+    cavp.autotune(True)
+    m = P.LatentDiffusion(precision=prec, **P.stage2_config())
+    m.load_state_dict(sd)
+    m.cuda()
+    m.autotune(True)
+    video = synth.synthetic_video(1, 32, 224).cuda()
+    B = 8
+    xT = synth.synthetic_xT(B).cuda()
+    for it in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        feats = cavp.encode_video(video, normalize=True, pool=False)            # (1,32,512)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        c = m.get_learned_conditioning(feats.repeat(B, 1, 1))
+        z, _ = m.sample_log_diff_sampler(c, B, "DDIM", 25, unconditional_guidance_scale=4.5,
+                                         unconditional_conditioning=torch.zeros_like(c), x_T=xT)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        mel = m.decode_first_stage(z)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+    print(f"config[4]/GPU [{prec}] 1 video x 8 candidates: CAVP(32x224x224) {1e3 * (t1 - t0):6.2f} ms "
+          f"({32 / (t1 - t0):7.0f} frames/s)  sample {1e3 * (t2 - t1):7.1f} ms  decode {1e3 * (t3 - t2):6.1f} ms  "
+          f"-> {B / (t3 - t0):6.2f} candidate-clips/s, finite={bool(torch.isfinite(mel).all())}")
+    del cavp, m
+    torch.cuda.empty_cache()
