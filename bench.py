@@ -75,6 +75,15 @@ def pmc_traffic():
         return None
 
 
+def measured_peak():
+    """MFMA issue peak measured on an MI355X by tools/peaks.py (profiles/peaks.json), next to the nominal one."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "peaks.json")) as f:
+            return json.load(f)["mfma_bf16_tflops"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +202,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (implicit-GEMM conv3x3/1x1/linear, all tile shapes)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
+                         "peak_measured": measured_peak(),
                          "launches_per_step": int(gemm_launches), "avg_launch_us": round(gemm_ms * 1e3 / max(1, gemm_launches), 2),
                          "algorithmic_gflop_per_step": round(GEMM_GFLOP_PER_SAMPLE * N, 1)},
             "kernel_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in prof.items()},

@@ -93,7 +93,7 @@ def lib(precision=None):
         return next(iter(_libs.values()))
     precision = precision or default_precision()
     if precision not in _libs:
-        path = LIB_PATHS[precision]
+        path = os.environ.get("DF_LIB_OVERRIDE") or LIB_PATHS[precision]      # tools: A/B against another build
         if not os.path.exists(path):
             raise RuntimeError(f"{path} not found: build it with diff-foley_amd/csrc/build.sh "
                                "(there is no CPU/torch fallback for the sampling path)")

@@ -26,7 +26,7 @@ for name, span, stride in (("shared 1MB window (L2 hot, every block same lines)"
                            ("private 64KB windows (L2 hot)", 65536, 65536),
                            ("private 256KB windows (L2/MALL)", 262144, 262144)):
     print(name)
-    for kind, kn in ((3, "lds-dma"), (4, "vgpr"), (5, "vgpr+ds_write")):
+    for kind, kn in ((3, "lds-dma"), (4, "vgpr")):     # kind 5 (vgpr+ds_write) is hoisted by the compiler: not reported
         row = []
         for blocks in (256, 512, 768, 1024):
             n = max(1, (64 << 20) // span)
