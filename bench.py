@@ -164,19 +164,31 @@ def main():
     for i in range(a.steps):
         x = step(a.warmup + i, x)
     prof = eng.profile_end()
-    if a.dump_ops and rank == 0:
-        eng.profile_dump(a.dump_ops)
-        # the dump holds every launch of the K instrumented steps; fold it to ONE step (mean ms per op position)
+    sub = None
+    if rank == 0:
         import csv
-        rows = list(csv.DictReader(open(a.dump_ops)))
+        import tempfile
+        dump = a.dump_ops or os.path.join(tempfile.gettempdir(), f"df_ops_{os.getpid()}.csv")
+        eng.profile_dump(dump)
+        # the dump holds every launch of the K instrumented steps; fold it to ONE step (mean ms per op position)
+        rows = list(csv.DictReader(open(dump)))
         if rows and len(rows) % a.steps == 0:
             n = len(rows) // a.steps
             for i in range(n):
                 rows[i]["ms"] = "%.5f" % (sum(float(rows[i + k * n]["ms"]) for k in range(a.steps)) / a.steps)
-            with open(a.dump_ops, "w", newline="") as f:
-                w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
-                w.writeheader()
-                w.writerows(rows[:n])
+            rows = rows[:n]
+            if a.dump_ops:
+                with open(dump, "w", newline="") as f:
+                    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+                    w.writeheader()
+                    w.writerows(rows)
+            # the two family metrics the north star names: SpatialTransformer MFMA rate over every op of
+            # the 16 transformers (GEMMs, attention, LayerNorm) and ResBlock-conv HBM rate over the 44 conv3x3 launches
+            st_ms = sum(float(r["ms"]) for r in rows if r["tag"].startswith(("st.", "attn.")) or r["tag"] == "layernorm")
+            rc_ms = sum(float(r["ms"]) for r in rows if r["tag"] in ("res.conv1", "res.conv2"))
+            sub = {"st_ms": st_ms, "rc_ms": rc_ms}
+        if not a.dump_ops:
+            os.remove(dump)
     stats = eng.plan_stats()
 
     if rank == 0:
@@ -205,6 +217,14 @@ def main():
                          "peak_measured": measured_peak(),
                          "launches_per_step": int(gemm_launches), "avg_launch_us": round(gemm_ms * 1e3 / max(1, gemm_launches), 2),
                          "algorithmic_gflop_per_step": round(GEMM_GFLOP_PER_SAMPLE * N, 1)},
+            "north_star_families": None if not sub else {
+                "spatial_transformer": {"algorithmic_gflop_per_step": round(73.22 * N, 1), "ms_per_step": round(sub["st_ms"], 4),
+                                        "tflops": round(73.22 * N / sub["st_ms"], 1),
+                                        "frac_of_mfma_peak": round(73.22 * N / sub["st_ms"] / PEAK_BF16_TFLOPS, 4)},
+                "resblock_conv3x3": {"algorithmic_gb_per_step": round(1.0235 + 0.0403 * N, 4), "ms_per_step": round(sub["rc_ms"], 4),
+                                     "gb_per_s": round((1.0235 + 0.0403 * N) / sub["rc_ms"] * 1e3, 1),
+                                     "frac_of_hbm_peak": round((1.0235 + 0.0403 * N) / sub["rc_ms"] * 1e3 / 8000.0, 4),
+                                     "tflops": round(81.62 * N / sub["rc_ms"], 1)}},
             "kernel_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in prof.items()},
             "kernel_launches_per_step": {k: int(v["launches"] // a.steps) for k, v in prof.items()},
             "plan": stats,
