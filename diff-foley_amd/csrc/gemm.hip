@@ -787,7 +787,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
 #endif
 }
 
-// Sums the split-K partial slabs and applies the same epilogue.  One thread per output element.
+// Sums the split-K partial slabs and applies the same epilogue.  One thread per output element (scalar fallback:
+// GEGLU, NCHW stores, unaligned leading dimensions).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   const int nout = p.geglu ? (p.N >> 1) : p.N;
   const long total = (long)p.M * nout;
@@ -807,6 +808,52 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
       for (int s = 0; s < p.splitk; ++s) v += p.partial[((long)s * p.M + row) * p.N + oc];
       epi_out(p, 0, row, oc, epi_bias(p, row, oc, v));
     }
+  }
+}
+
+// Vectorised reduce: one thread per 4 consecutive output columns; the SK slab loads of a thread are independent and
+// issued together (compile-time split count), then alpha / bias / FiLM bias / residual / ReLU and one 16-B (fp32) or
+// 8-B (operand type) store.  Summation order s = 0..SK-1 is fixed, so results are deterministic.
+template <int SK>
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
+  const int n4 = p.N >> 2;
+  const long total = (long)p.M * n4;
+  const long slab = (long)p.M * p.N;
+  const bool has_bias = p.bias != nullptr, has_rb = p.rowbias != nullptr, has_res = p.res != nullptr;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(e / n4), col = (int)(e - (long)row * n4) * 4;
+    const float* src = p.partial + (long)row * p.N + col;
+    float4 t[SK];
+#pragma unroll
+    for (int s = 0; s < SK; ++s) t[s] = *reinterpret_cast<const float4*>(src + s * slab);
+    float4 v = t[0];
+#pragma unroll
+    for (int s = 1; s < SK; ++s) {
+      v.x += t[s].x; v.y += t[s].y; v.z += t[s].z; v.w += t[s].w;
+    }
+    v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+    if (has_bias) {
+      const float4 b = *reinterpret_cast<const float4*>(&p.bias[col]);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (has_rb) {
+      const int ri = (p.rowbias_mode == 1) ? (row / p.rows_per_sample) : (row % p.rows_per_sample);
+      const float4 b = *reinterpret_cast<const float4*>(&p.rowbias[(long)ri * p.ld_rowbias + col]);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (has_res) {
+      const float4 b = *reinterpret_cast<const float4*>(&p.res[(long)row * p.ldr + col]);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (p.relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    const long idx = (long)row * p.ldc + col;
+    if (p.out_bf16)
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    else
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;
+    if (p.aux) *reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
   }
 }
 
@@ -911,11 +958,25 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
   }
   if (e != hipSuccess) return e;
   if (p.splitk > 1) {
-    const int nout = p.geglu ? (p.N >> 1) : p.N;
-    const long total = (long)p.M * nout;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    const bool vec = !p.geglu && !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
+                     (p.ld_rowbias & 3) == 0 && (p.ld_aux & 3) == 0;
+    if (vec) {
+      const long total = (long)p.M * (p.N >> 2);
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+#define DF_RED(SK) case SK: hipLaunchKernelGGL(splitk_reduce_vec_kernel<SK>, dim3(blocks), dim3(256), 0, stream, p); break;
+      switch (p.splitk) {
+        DF_RED(2) DF_RED(4) DF_RED(8) DF_RED(16) DF_RED(32)
+        default: hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p); break;
+      }
+#undef DF_RED
+    } else {
+      const int nout = p.geglu ? (p.N >> 1) : p.N;
+      const long total = (long)p.M * nout;
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    }
     e = hipGetLastError();
   }
   return e;
