@@ -337,3 +337,24 @@ def test_tiny_autotuned_plans_match_untuned(P):
                                           want_prob=True)
     assert torch.allclose(prob.cpu(), g6["cls_p"], atol=2e-2)
     assert rel_l2(grad.cpu(), g6["cls_grad"]) < 5e-2
+
+
+def test_tune_cache_round_trip(P, tmp_path, monkeypatch):
+    """DF_TUNE_CACHE: the first engine tunes and saves its (tile, split-K, walk) choices, a second one configures its
+    plans from the file without trial launches and produces bit-identical results."""
+    from diff_foley_amd import synth
+    cache = tmp_path / "tune.txt"
+    monkeypatch.setenv("DF_TUNE_CACHE", str(cache))
+    x, c = rnd((2, 4, 16, 64), 102), rnd((2, 32, 128), 101)
+    t = torch.tensor([500, 37])
+    outs = []
+    for _ in range(2):
+        m = P.LatentDiffusion(**P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
+        m.load_state_dict(tiny_state_dict())
+        m.cuda()
+        m.autotune(True)
+        outs.append(m.apply_model(x.cuda(), t.cuda(), c.cuda()).cpu())
+        assert cache.exists() and len(cache.read_text().splitlines()) > 5
+        del m
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[0], gold("g3_tiny_unet.npz")["y_int"]) < FWD_TOL
