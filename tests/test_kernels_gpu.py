@@ -110,7 +110,8 @@ def test_groupnorm(N, HW, C, silu, eps):
     assert rel_l2(out.float().cpu().permute(0, 2, 1), ref) < 4e-3     # bf16 output rounding
 
 
-@pytest.mark.parametrize("rows,C", [(1024, 320), (77, 640), (16, 1280), (128, 64)])
+@pytest.mark.parametrize("rows,C", [(1024, 320), (77, 640), (16, 1280), (128, 64), (8192, 320), (3, 128), (5, 256),
+                                    (7, 512), (513, 1280)])
 def test_layernorm(rows, C):
     E = _eng()
     x = rnd((rows, C), 9) * 3 - 1
