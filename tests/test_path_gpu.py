@@ -358,3 +358,32 @@ def test_tune_cache_round_trip(P, tmp_path, monkeypatch):
         del m
     assert torch.equal(outs[0], outs[1])
     assert rel_l2(outs[0], gold("g3_tiny_unet.npz")["y_int"]) < FWD_TOL
+
+
+def test_tiny_ragged_context_lengths_and_latent_sizes(tiny):
+    """Edge shapes the reference API admits: context of 1 / 17 / 40 frames (pos_emb holds 40, video_feat_encoder.py:10),
+    latent widths other than 64 (``size_len`` of sample_log_diff_sampler, ddpm.py:1287-1314) and the error path for a
+    context longer than pos_emb."""
+    usd, vsd, csd, synth = _oracle_tiny()
+    from oracle import unet as ou
+    for T in (1, 17, 40):
+        feats = rnd((2, T, 64), 500 + T)
+        c = tiny.get_learned_conditioning(feats.cuda())
+        assert c.shape == (2, T, 128)
+        x = rnd((2, 4, 16, 64), 600 + T)
+        t = torch.tensor([999, 1])
+        ref = ou.unet_forward(usd, synth.UNET_TINY, x, t, c.cpu())
+        y = tiny.apply_model(x.cuda(), t.cuda(), c).cpu()
+        assert rel_l2(y, ref) < FWD_TOL, T
+    with pytest.raises(RuntimeError):
+        tiny.get_learned_conditioning(rnd((1, 41, 64), 1).cuda())
+    for (H, W) in ((16, 32), (16, 128), (8, 8)):
+        x, c = rnd((1, 4, H, W), 700 + W), rnd((1, 32, 128), 701)
+        t = torch.tensor([500])
+        ref = ou.unet_forward(usd, synth.UNET_TINY, x, t, c)
+        y = tiny.apply_model(x.cuda(), t.cuda(), c.cuda()).cpu()
+        assert y.shape == ref.shape and rel_l2(y, ref) < FWD_TOL, (H, W)
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(1, 32, 64, seed=3).cuda())
+    z, _ = tiny.sample_log_diff_sampler(c, 1, "DDIM", 5, size_len=32, unconditional_guidance_scale=4.5,
+                                        unconditional_conditioning=torch.zeros_like(c))
+    assert z.shape == (1, 4, 16, 32) and torch.isfinite(z).all()
