@@ -2,6 +2,7 @@
 // ddim.py:333-341 / dpm_solver.py:1340-1349).  Only gradients w.r.t. activations are computed; the backward
 // data GEMMs (conv^T, Linear^T) reuse gemm_bf16_kernel with transposed / flipped weight packings.
 // Gradients travel as fp32 NHWC; every kernel that feeds a GEMM also emits the bf16 copy the GEMM consumes.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -244,6 +245,214 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const bf16_t* __rest
   }
 }
 
+// ------------------------------------------------------------------ attention backward, MFMA (D = 32, Tk <= 256)
+// One block per (head, sample); wavefront w owns the 32-key tile w (NKT = ceil(Tk/32) <= 8 wavefronts) and keeps
+// dK^T / dV^T of its keys in MFMA accumulators while the block walks the query tiles.  Per (query tile, key tile):
+//   S^T = K Q^T, dP^T = V dO^T   (keys x queries; lane = query: softmax statistics are lane-local + one shfl)
+//   S   = Q K^T, dP   = dO V^T   (queries x keys; lane = key: the orientation whose C layout is a valid B operand
+//                                 for contractions over QUERIES -- recomputing beats transposing, D is only 32)
+//   row max / sum / delta = sum_j p dp are reduced over the key tiles through LDS in wavefront order (deterministic)
+//   dV^T += dO^T P,  dK^T += Q^T dS   (contraction over the 32 queries, in the row order of the C layout)
+//   dQ^T  = sum_w K_w^T dS_w^T        (contraction over keys; per-wavefront partials summed in LDS in fixed order)
+// P and dS are rounded to the operand type before the second MFMAs, exactly like the forward kernel.
+// LDS: Q, K, V, dO row-major [T][40] in operand type; "transposed" A fragments are gathered with 2-byte reads.
+__global__ __launch_bounds__(512) void attention_bwd_mfma_kernel(const bf16_t* __restrict__ Q, int ldq,
+                                                                 const bf16_t* __restrict__ K, int ldk,
+                                                                 const bf16_t* __restrict__ Vt, int ldvt,
+                                                                 const float* __restrict__ dO, int lddo,
+                                                                 bf16_t* __restrict__ dQ, int lddq,
+                                                                 bf16_t* __restrict__ dK, int lddk,
+                                                                 bf16_t* __restrict__ dV, int lddv, int heads, int Tq,
+                                                                 int Tk, float scale) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int D = 32, DP = 40;
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  const int NKT = (Tk + 31) >> 5, NQT = (Tq + 31) >> 5;
+  const int TkP = NKT * 32, TqP = NQT * 32;
+  bf16_t* sK = reinterpret_cast<bf16_t*>(smraw);           // [TkP][DP]
+  bf16_t* sV = sK + TkP * DP;                              // [TkP][DP]
+  bf16_t* sQ = sV + TkP * DP;                              // [TqP][DP]
+  bf16_t* sD = sQ + TqP * DP;                              // [TqP][DP]  dO
+  float* red = reinterpret_cast<float*>(sD + TqP * DP);    // [3][8][32]  per-wave max / sum / sum(e*dp)
+  float* stat = red + 3 * 8 * 32;                          // [3][32]     row max, 1/sum, delta of the query tile
+  float* part = stat + 3 * 32;                             // [8][32][33] dQ^T partials (d, q)
+  const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const float c2 = scale * 1.44269504088896340736f;
+
+  // ---- stage (zero padded to whole tiles)
+  for (int i = tid; i < TkP * D; i += nthr) {
+    const int j = i >> 5, d = i & 31;
+    bf16_t kv = 0, vv = 0;
+    if (j < Tk) {
+      kv = K[((long)n * Tk + j) * ldk + h * D + d];
+      vv = Vt[((long)n * heads + h) * D * ldvt + (long)d * ldvt + j];
+    }
+    sK[j * DP + d] = kv;
+    sV[j * DP + d] = vv;
+  }
+  for (int i = tid; i < TqP * D; i += nthr) {
+    const int q = i >> 5, d = i & 31;
+    bf16_t qv = 0, dv = 0;
+    if (q < Tq) {
+      qv = Q[((long)n * Tq + q) * ldq + h * D + d];
+      dv = f2bf(dO[((long)n * Tq + q) * lddo + h * D + d]);
+    }
+    sQ[q * DP + d] = qv;
+    sD[q * DP + d] = dv;
+  }
+  __syncthreads();
+
+  const int k0 = wid * 32;                                 // this wavefront's key tile
+  // row-major fragments (A or B operand: row = l31, 8 consecutive d at 16*s + 8*lh)
+  auto frag = [&](const bf16_t* base, int row0, int s2) {
+    return *reinterpret_cast<const bf16x8*>(&base[(row0 + l31) * DP + 16 * s2 + 8 * lh]);
+  };
+  // "transposed" A fragment: row m = d (l31), contraction index = tile rows in C-layout order of k-step s2:
+  // rows {0..3, 8..11} + 4*lh + 16*s2
+  auto fragT = [&](const bf16_t* base, int row0, int s2) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ra = row0 + 16 * s2 + 4 * lh + ((2 * i) & 3) + 8 * ((2 * i) >> 2);
+      const uint32_t lo = base[ra * DP + l31], hi = base[(ra + 1) * DP + l31];
+      w[i] = lo | (hi << 16);
+    }
+    uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
+    return *reinterpret_cast<bf16x8*>(&v);
+  };
+  const bf16x8 kf0 = frag(sK, k0, 0), kf1 = frag(sK, k0, 1), vf0 = frag(sV, k0, 0), vf1 = frag(sV, k0, 1);
+  const bf16x8 kt0 = fragT(sK, k0, 0), kt1 = fragT(sK, k0, 1);
+
+  f32x16 dkT, dvT;                                         // (d x keys): lane key = l31, rows d
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dkT[r] = dvT[r] = 0.f;
+  const f32x16 zero16 = dkT;
+
+  for (int qt = 0; qt < NQT; ++qt) {
+    const int q0 = qt * 32;
+    const bf16x8 qf0 = frag(sQ, q0, 0), qf1 = frag(sQ, q0, 1), df0 = frag(sD, q0, 0), df1 = frag(sD, q0, 1);
+    // keys x queries
+    f32x16 st = DF_MFMA_32x32x16(kf0, qf0, zero16);
+    st = DF_MFMA_32x32x16(kf1, qf1, st);
+    f32x16 dpt = DF_MFMA_32x32x16(vf0, df0, zero16);
+    dpt = DF_MFMA_32x32x16(vf1, df1, dpt);
+    // queries x keys
+    f32x16 ss = DF_MFMA_32x32x16(qf0, kf0, zero16);
+    ss = DF_MFMA_32x32x16(qf1, kf1, ss);
+    f32x16 dps = DF_MFMA_32x32x16(df0, vf0, zero16);
+    dps = DF_MFMA_32x32x16(df1, vf1, dps);
+
+    // ---- statistics of query l31 over this wavefront's keys (S^T orientation), then over all key tiles
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      st[r] = (key < Tk) ? st[r] * c2 : -INFINITY;
+      mx = fmaxf(mx, st[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (lh == 0) red[wid * 32 + l31] = mx;
+    __syncthreads();
+    float m = red[l31];
+    for (int w = 1; w < NKT; ++w) m = fmaxf(m, red[w * 32 + l31]);
+    float ls = 0.f, le = 0.f;
+    float et[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      et[r] = __builtin_amdgcn_exp2f(st[r] - m);           // masked keys: exp2(-inf) = 0
+      ls += et[r];
+      le += et[r] * dpt[r];
+    }
+    ls += __shfl_xor(ls, 32);
+    le += __shfl_xor(le, 32);
+    if (lh == 0) {
+      red[256 + wid * 32 + l31] = ls;
+      red[512 + wid * 32 + l31] = le;
+    }
+    __syncthreads();
+    float lsum = 0.f, esum = 0.f;
+    for (int w = 0; w < NKT; ++w) {
+      lsum += red[256 + w * 32 + l31];
+      esum += red[512 + w * 32 + l31];
+    }
+    const bool qv = (q0 + l31) < Tq;
+    const float inv = qv ? 1.0f / lsum : 0.f;              // padded queries contribute nothing
+    const float del = esum * inv;
+    if (wid == 0 && lh == 0) {
+      stat[l31] = m;
+      stat[32 + l31] = inv;
+      stat[64 + l31] = del;
+    }
+    // dS^T as B operand (contraction over this tile's keys, C-layout row order)
+    uint32_t dst[8];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float a = et[r] * inv * (dpt[r] - del) * scale, b = et[r + 1] * inv * (dpt[r + 1] - del) * scale;
+      dst[r >> 1] = pack_bf2(a, b);
+    }
+    __syncthreads();                                        // stat visible; red free for the next tile
+    // ---- P and dS in the (queries x keys) orientation: lane = key, rows = queries
+    uint32_t pp[8], dsp[8];
+    const bool kv = (k0 + l31) < Tk;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      float pv[2], dv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int qi = ((r + u) & 3) + 8 * ((r + u) >> 2) + 4 * lh;
+        const float e = kv ? __builtin_amdgcn_exp2f(ss[r + u] * c2 - stat[qi]) * stat[32 + qi] : 0.f;
+        pv[u] = e;
+        dv[u] = e * (dps[r + u] - stat[64 + qi]) * scale;
+      }
+      pp[r >> 1] = pack_bf2(pv[0], pv[1]);
+      dsp[r >> 1] = pack_bf2(dv[0], dv[1]);
+    }
+    // ---- dV^T += dO^T P ; dK^T += Q^T dS   (two k-steps of 16 queries)
+    if (dK) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        uint4 pb = make_uint4(pp[4 * s2], pp[4 * s2 + 1], pp[4 * s2 + 2], pp[4 * s2 + 3]);
+        uint4 db = make_uint4(dsp[4 * s2], dsp[4 * s2 + 1], dsp[4 * s2 + 2], dsp[4 * s2 + 3]);
+        dvT = DF_MFMA_32x32x16(fragT(sD, q0, s2), *reinterpret_cast<bf16x8*>(&pb), dvT);
+        dkT = DF_MFMA_32x32x16(fragT(sQ, q0, s2), *reinterpret_cast<bf16x8*>(&db), dkT);
+      }
+    }
+    // ---- dQ^T partial of this key tile: K_w^T dS_w^T  -> (d x queries), lane = query
+    {
+      uint4 b0 = make_uint4(dst[0], dst[1], dst[2], dst[3]), b1 = make_uint4(dst[4], dst[5], dst[6], dst[7]);
+      f32x16 dq = DF_MFMA_32x32x16(kt0, *reinterpret_cast<bf16x8*>(&b0), zero16);
+      dq = DF_MFMA_32x32x16(kt1, *reinterpret_cast<bf16x8*>(&b1), dq);
+      float* pw = part + wid * (32 * 33);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pw[((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + l31] = dq[r];
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * 32; i += nthr) {            // (q, d): sum the key tiles in fixed order
+      const int q = i >> 5, d = i & 31;
+      float acc = 0.f;
+      for (int w = 0; w < NKT; ++w) acc += part[w * (32 * 33) + d * 33 + q];
+      if (q0 + q < Tq) dQ[((long)n * Tq + q0 + q) * lddq + h * D + d] = f2bf(acc);
+    }
+    // (the next iteration's first __syncthreads orders these reads of `part` before its next writes)
+  }
+  if (dK) {                                                 // lane (key = l31 + k0, lh) holds d = (r&3) + 8(r>>2) + 4lh
+    const int key = k0 + l31;
+    if (key < Tk) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 8 * g + 4 * lh;
+        uint2 a, b;
+        a.x = pack_bf2(dkT[4 * g], dkT[4 * g + 1]); a.y = pack_bf2(dkT[4 * g + 2], dkT[4 * g + 3]);
+        b.x = pack_bf2(dvT[4 * g], dvT[4 * g + 1]); b.y = pack_bf2(dvT[4 * g + 2], dvT[4 * g + 3]);
+        *reinterpret_cast<uint2*>(&dK[((long)n * Tk + key) * lddk + h * D + d0]) = a;
+        *reinterpret_cast<uint2*>(&dV[((long)n * Tk + key) * lddv + h * D + d0]) = b;
+      }
+    }
+  }
+#endif
+}
+
 // ------------------------------------------------------------------ classifier head backward
 // p = sigmoid(z), objective sum log p  ->  dz = 1 - p;  pooled = mean_px(h);  z = w . pooled + b
 //   dh[n][px][c] = (1 - p_n) * w[c] / HW          (out_channels == 1)
@@ -318,6 +527,23 @@ hipError_t launch_geglu_bwd(const uint16_t* u, const float* dy, uint16_t* du, lo
 hipError_t launch_attention_bwd(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt,
                                 const float* dO, int lddo, uint16_t* dQ, int lddq, uint16_t* dK, int lddk, uint16_t* dV,
                                 int lddv, int N, int heads, int D, int Tq, int Tk, float scale, hipStream_t s) {
+  static const bool valu_only = getenv("DF_ATTN_BWD_VALU") != nullptr;       // tools: A/B against the VALU kernel
+  if (!valu_only && D == 32 && Tk <= 256 && (lddk & 3) == 0 && (lddv & 3) == 0) {
+    const int nkt = (Tk + 31) / 32, nqt = (Tq + 31) / 32;
+    const size_t ldm = (size_t)(2 * nkt + 2 * nqt) * 32 * 40 * 2 + (size_t)(3 * 8 * 32 + 3 * 32 + 8 * 32 * 33) * 4;
+    if (ldm <= 160 * 1024) {
+      static size_t attr_m = 0;
+      if (ldm > attr_m) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_mfma_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm);
+        if (e != hipSuccess) return e;
+        attr_m = ldm;
+      }
+      hipLaunchKernelGGL(attention_bwd_mfma_kernel, dim3(heads, N), dim3(64 * nkt), ldm, s, Q, ldq, K, ldk, Vt, ldvt, dO,
+                         lddo, dQ, lddq, dK, lddk, dV, lddv, heads, Tq, Tk, scale);
+      return hipGetLastError();
+    }
+  }
   const size_t lds = ((size_t)(2 * Tk + 2 * Tq) * (D + 1) + 3 * (size_t)Tq) * 4;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
 #define DF_ABWD(DD)                                                                                                   \
