@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
     for (int r = 0; r < 16; r += 2) {
       const float p0 = __builtin_amdgcn_exp2f(s[r] - m_new), p1 = __builtin_amdgcn_exp2f(s[r + 1] - m_new);
       ps += p0 + p1;
-      pk[r >> 1] = pack_bf2(p0, p1);
+      pk[r >> 1] = pack_bf2_bounded(p0, p1);      // p in [0, 1]
     }
     if (__any(m_new != m_run)) {                   // wave-uniform: rescale only when some row's running max moved
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0

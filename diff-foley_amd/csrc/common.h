@@ -34,6 +34,12 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   const op_x2 v = __builtin_convertvector(f, op_x2);
   return *reinterpret_cast<const uint32_t*>(&v);
 }
+// same without the fp16 saturation, for values known to be bounded (softmax probabilities in the attention loops)
+__device__ __forceinline__ uint32_t pack_bf2_bounded(float lo, float hi) {
+  const f32x2 f = {lo, hi};
+  const op_x2 v = __builtin_convertvector(f, op_x2);
+  return *reinterpret_cast<const uint32_t*>(&v);
+}
 __device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)(pack_bf2(f, 0.f) & 0xFFFFu); }
 __device__ __forceinline__ float bf2f(uint16_t h) {
 #if defined(DF_OPERAND_F16)
