@@ -76,31 +76,55 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
   constexpr int VCH = (DT * 32 * 8 + NT - 1) / NT;         // 8-B V^T chunks per thread
   uint4 kreg[KCH];
   uint2 vreg[VCH];
+  // Raw buffer loads: the per-thread byte offset is fixed (computed once), the tile advances through the scalar
+  // offset, and everything that does not exist -- keys >= Tk (past the end of this sample's K rows), chunks beyond D,
+  // threads without a chunk -- is an out-of-range offset that the hardware answers with zeros: no address VALU and
+  // no predicates in the loop.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsK =
+      __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (int)(((long)(Tk - 1) * ldk + D) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV =
+      __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)(((long)(D - 1) * ldvt + ldvt) * 2), 0x00020000);
+  unsigned k_off[KCH], v_off[VCH];
+#pragma unroll
+  for (int i = 0; i < KCH; ++i) {
+    const int c = tid + i * NT;
+    const int key = c / (DKP / 8), ch = c - key * (DKP / 8);
+    const bool ok = (c < KT * (DKP / 8)) && (ch * 8 < D);
+    k_off[i] = ok ? (unsigned)((key * ldk + ch * 8) * 2) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < VCH; ++i) {
+    const int c = tid + i * NT;
+    const int d = c >> 3, ch = c & 7;
+    const bool ok = (c < DT * 32 * 8) && (d < D);
+    v_off[i] = ok ? (unsigned)((d * ldvt + ch * 4) * 2) : OOB;
+  }
   auto gfetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < KCH; ++i) {
-      const int c = tid + i * NT;
-      const int key = c / (DKP / 8), ch = c - key * (DKP / 8);
-      const bool ok = (c < KT * (DKP / 8)) && (k0 + key < Tk) && (ch * 8 < D);
-      const bf16_t* src = Kb + (long)(ok ? (k0 + key) : 0) * ldk + (ok ? ch * 8 : 0);
-      uint4 v = *reinterpret_cast<const uint4*>(src);
-      if (!ok) v = make_uint4(0, 0, 0, 0);
-      kreg[i] = v;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsK, (int)k_off[i], k0 * ldk * 2, 0);
+      kreg[i] = make_uint4(v[0], v[1], v[2], v[3]);
     }
 #pragma unroll
     for (int i = 0; i < VCH; ++i) {
-      const int c = tid + i * NT;
-      const int d = c >> 3, ch = c & 7;
-      const int nvalid = Tk - (k0 + ch * 4);   // keys of this 4-key chunk that exist
-      const bool ok = (c < DT * 32 * 8) && (d < D) && (nvalid > 0);
-      const bf16_t* src = Vb + (long)(ok ? d : 0) * ldvt + (ok ? k0 + ch * 4 : 0);   // ldvt padded to 32
-      uint2 v = *reinterpret_cast<const uint2*>(src);
-      if (!ok) v = make_uint2(0, 0);
-      if (nvalid < 4) {   // ragged tail (e.g. 33 context tokens): padding may hold stale bits
-        if (nvalid < 3) v.y = 0; else v.y &= 0xFFFFu;
-        if (nvalid < 2) v.x &= 0xFFFFu;
+      typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsV, (int)v_off[i], k0 * 2, 0);
+      vreg[i] = make_uint2(v[0], v[1]);
+    }
+    if (k0 + KT > Tk) {   // ragged last tile only (e.g. 33 context tokens): the row padding may hold stale bits
+#pragma unroll
+      for (int i = 0; i < VCH; ++i) {
+        const int ch = (tid + i * NT) & 7;
+        const int nvalid = Tk - (k0 + ch * 4);   // keys of this 4-key chunk that exist
+        uint2 v = vreg[i];
+        if (nvalid < 4) {
+          if (nvalid < 3) v.y = 0; else v.y &= 0xFFFFu;
+          if (nvalid < 2) v.x &= 0xFFFFu;
+          if (nvalid < 1) v.x = 0;
+        }
+        vreg[i] = v;
       }
-      vreg[i] = v;
     }
   };
   auto sstore = [&](int buf) {
