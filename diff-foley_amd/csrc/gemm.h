@@ -26,6 +26,7 @@ struct GemmParams {
   int ups;     // 1: conv runs on the nearest-x2 upsampled input
   int zstuff;  // with ups=1: the x2 input is ZERO-stuffed (transposed stride-2 conv, backward of Downsample), not nearest
   int th, tw;  // halo kernels: spatial patch of output pixels owned per block (th*tw divides BM)
+  int halo_ring_bytes;   // halo kernels (set by the launcher): LDS bytes of the operand ring; the epilogue row table follows
   // epilogue
   void* C; long c_bs; int ldc; int out_bf16;
   float alpha;

@@ -212,6 +212,9 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
     return;
   }
   constexpr int CPR = BN / 4;
+  // rows_per_sample is a power of two for every latent this model is used with: shift instead of a 25-instruction divide
+  const int rps_sh = (has_rb && p.rows_per_sample > 0 && (p.rows_per_sample & (p.rows_per_sample - 1)) == 0)
+                         ? (31 - __builtin_clz(p.rows_per_sample)) : -1;
   // EXTRA = ReLU and/or the second (operand-type) output of the CAVP encoder; kept out of the UNet's loop body
 #define DF_EPI_LOOP(EXTRA)                                                                                          \
   _Pragma("unroll 4") for (int e = tid; e < BM * CPR; e += NT) {                                                    \
@@ -225,7 +228,8 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
     }                                                                                                               \
     if (has_rb) {                                                                                                   \
-      const int ri = (p.rowbias_mode == 1) ? (rc / p.rows_per_sample) : (rc % p.rows_per_sample);                   \
+      const int ri = (rps_sh >= 0) ? ((p.rowbias_mode == 1) ? (rc >> rps_sh) : (rc & (p.rows_per_sample - 1)))      \
+                                   : ((p.rowbias_mode == 1) ? (rc / p.rows_per_sample) : (rc % p.rows_per_sample)); \
       const float4 b = *reinterpret_cast<const float4*>(&p.rowbias[(long)ri * p.ld_rowbias + cc]);                  \
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
     }                                                                                                               \
@@ -763,14 +767,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   }
   wait_vmcnt<0>();
 
-  // ---- epilogue: tile row -> NHWC pixel index of its output pixel
-  auto rowmap = [&](int rr) {
+  // ---- epilogue: tile row -> NHWC pixel index of its output pixel.  Five integer divisions per row: computed once per
+  // row into a BM-entry LDS table behind the operand ring instead of once per 4-column chunk of the epilogue loop.
+  auto rowmap_calc = [&](int rr) {
     const int pi = rr / PPX, rem = rr - pi * PPX;
     const int y = rem / TW, x = rem - y * TW;
     const int g = mt * PB + pi;
     const int n = g / (npy * npx), gr = g - n * (npy * npx);
     return (g < npatch) ? (n * p.H + (gr / npx) * TH + y) * p.Wd + (gr % npx) * TW + x : p.M;
   };
+  int* srow = reinterpret_cast<int*>(smem + p.halo_ring_bytes);
+  for (int rr = tid; rr < BM; rr += NT) srow[rr] = rowmap_calc(rr);
+  __syncthreads();
+  auto rowmap = [&](int rr) { return srow[rr]; };
   const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
                       (p.ld_rowbias & 3) == 0 && (p.ld_aux & 3) == 0;
   if (vec_ok) {
@@ -886,7 +895,9 @@ hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
   const int APASS = (HR + RPP - 1) / RPP;
   if (APASS > 12) return hipErrorInvalidValue;
   constexpr int WPASS = (BN + RPP - 1) / RPP;
-  const size_t lds = ((size_t)2 * APASS * RPP + (size_t)NSTW * WPASS * RPP) * BK * 2;
+  const size_t ring = ((size_t)2 * APASS * RPP + (size_t)NSTW * WPASS * RPP) * BK * 2;
+  const size_t lds = ring + (size_t)BM * 4;          // + the epilogue's row table
+  p.halo_ring_bytes = (int)ring;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t attr = 0;
   if (lds > attr) {
@@ -919,7 +930,7 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int apass = (hr + rpp - 1) / rpp, wpass = (bn + rpp - 1) / rpp;
   if (apass > 12) return false;
   const int nstw = gemm_halo_ring(tile);   // weight ring depth (4; 8 for the weight-streaming variants)
-  if (((size_t)2 * apass * rpp + (size_t)nstw * wpass * rpp) * 128 > 160 * 1024) return false;
+  if (((size_t)2 * apass * rpp + (size_t)nstw * wpass * rpp) * 128 + (size_t)bm * 4 > 160 * 1024) return false;
   const int nchunk = p.Cin / 64;
   return splitk == 1 || nchunk / splitk >= 1;
 }
