@@ -85,6 +85,7 @@ struct Plan {
   float* partial = nullptr;      // shared split-K scratch
   size_t partial_bytes = 0;
   double gemm_flops = 0, weight_bytes = 0;
+  size_t ext_hint = 0;           // largest external (caller-owned) buffer the plan touches, when above 32 MB (autotune dummies)
   ~Plan() {
     for (auto& b : owned) (void)hipFree(b.p);
     if (partial) (void)hipFree(partial);
@@ -370,11 +371,16 @@ struct Builder {
     return pl->ops.back();
   }
 
+  // operands are addressed through 32-bit buffer offsets: one operand of one GEMM must stay below 2 GiB
+  static unsigned op_bytes(size_t b) {
+    if (b >= ((size_t)1 << 31)) fail("GEMM operand of %zu bytes exceeds the 2 GiB buffer-addressing limit (split the batch)", b);
+    return (unsigned)b;
+  }
   static GemmParams gp_linear(const bf16_t* A, int M, int K, const bf16_t* W, int N) {
     GemmParams g{};
     g.A = A; g.lda = K; g.W = W; g.M = M; g.N = N; g.K = K;
     g.taps = 1; g.Cin = K; g.alpha = 1.f; g.stride = 1;
-    g.a_bytes = (unsigned)((size_t)M * K * 2); g.w_bytes = (unsigned)((size_t)N * K * 2);
+    g.a_bytes = op_bytes((size_t)M * K * 2); g.w_bytes = op_bytes((size_t)N * K * 2);
     return g;
   }
   static GemmParams gp_conv3(const bf16_t* A, int NB, int H, int Wd, int Cin, const bf16_t* W, int Cout, int stride,
@@ -386,7 +392,7 @@ struct Builder {
     g.OW = ups ? 2 * Wd : (stride == 2 ? Wd / 2 : Wd);
     g.M = NB * g.OH * g.OW; g.N = Cout; g.K = 9 * Cin;
     g.taps = 9; g.Cin = Cin; g.alpha = 1.f;
-    g.a_bytes = (unsigned)((size_t)NB * H * Wd * Cin * 2); g.w_bytes = (unsigned)((size_t)Cout * 9 * Cin * 2);
+    g.a_bytes = op_bytes((size_t)NB * H * Wd * Cin * 2); g.w_bytes = op_bytes((size_t)Cout * 9 * Cin * 2);
     return g;
   }
   static void out_f32(GemmParams& g, float* C, int ldc) { g.C = C; g.ldc = ldc; g.out_bf16 = 0; }
@@ -1428,6 +1434,7 @@ void build_cavp(df_ctx* c, Plan* pl, int T, int H, int W) {
   if (H % 32 || W % 32) fail("cavp: frame size %dx%d must be a multiple of 32", H, W);
   const int F = T;
   const int base = k.base_channels;
+  pl->ext_hint = (size_t)F * 3 * H * W * 4;
   // ---- stem
   const int OH = H / 2, OW = W / 2, KP = 192;
   bf16_t* col = b.buf<bf16_t>((size_t)F * OH * OW * KP);
@@ -1735,7 +1742,7 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
   for (auto& kv : cands) rounds = std::max(rounds, kv.second.size());
   if (rounds <= 1) { apply(0); return; }
   // stage 2: dummy external buffers (timing does not depend on the values)
-  const size_t slab = (size_t)32 << 20;
+  const size_t slab = std::max((size_t)32 << 20, (pl->ext_hint + 4095) & ~(size_t)4095);
   char* ext = nullptr;
   HIPCHK(hipMalloc((void**)&ext, 5 * slab));
   HIPCHK(hipMemsetAsync(ext, 0, 5 * slab, s));

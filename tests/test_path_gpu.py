@@ -387,3 +387,14 @@ def test_tiny_ragged_context_lengths_and_latent_sizes(tiny):
     z, _ = tiny.sample_log_diff_sampler(c, 1, "DDIM", 5, size_len=32, unconditional_guidance_scale=4.5,
                                         unconditional_conditioning=torch.zeros_like(c))
     assert z.shape == (1, 4, 16, 32) and torch.isfinite(z).all()
+
+
+def test_tiny_decode_large_batch_is_chunked(tiny):
+    """decode_first_stage on more than 16 samples runs in chunks of 16 with identical per-sample results."""
+    z = rnd((19, 4, 16, 64), 808)
+    full = tiny.decode_first_stage(z.cuda()).cpu()
+    assert full.shape[0] == 19
+    part = tiny.decode_first_stage(z[16:].cuda()).cpu()
+    assert rel_l2(full[16:], part) < 2e-2          # different batch -> different plan/tiles: operand-rounding noise only
+    one = tiny.decode_first_stage(z[:16].cuda()).cpu()
+    assert torch.equal(full[:16], one)
