@@ -193,6 +193,77 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
   }
 }
 
+// Same contraction with the activations staged ONCE per block in LDS (M <= 16 rows x K fp32) and two weight rows per
+// wave pass: the weight stream (16-B loads, read once) is the only global traffic in the loop, so the kernel runs at
+// the HBM rate instead of being bound by 16 L1 activation loads per weight load.  With `tvals` the activations are the
+// sinusoidal timestep embedding of tvals[m % t_B] (util.py:151-171, [cos | sin]) generated in place: the copy,
+// embedding and first MLP layer of the time-embedding path are one launch.
+template <int MR>
+__global__ __launch_bounds__(256) void linear_rows_lds_kernel(const float* __restrict__ a, int lda,
+                                                              const float* __restrict__ tvals, int t_B,
+                                                              const bf16_t* __restrict__ W,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int ldo, int M, int N, int K, int act_out) {
+  extern __shared__ __attribute__((aligned(16))) float sA[];   // [MR][K]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tvals) {
+    const int half = K >> 1;
+    for (int i = tid; i < M * half; i += 256) {
+      const int m = i / half, k = i - m * half;
+      const float f = expf(-9.210340371976184f * (float)k / (float)half);
+      const float ang = tvals[m % t_B] * f;
+      sA[m * K + k] = cosf(ang);
+      sA[m * K + half + k] = sinf(ang);
+    }
+  } else {
+    for (int i = tid * 4; i < M * K; i += 1024) {
+      const int m = i / K, k = i - m * K;
+      *reinterpret_cast<float4*>(&sA[i]) = *reinterpret_cast<const float4*>(a + (long)m * lda + k);
+    }
+  }
+  for (int i = M * K + tid; i < MR * K; i += 256) sA[i] = 0.f;
+  __syncthreads();
+  const int col0 = blockIdx.x * 64 + wid * 16;
+#pragma unroll 1
+  for (int pass = 0; pass < 8; ++pass) {
+    const int n0 = col0 + pass * 2;
+    if (n0 >= N) break;
+    const int n1 = min(n0 + 1, N - 1);
+    float acc0[MR], acc1[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc0[m] = acc1[m] = 0.f;
+    const bf16_t* w0 = W + (long)n0 * K;
+    const bf16_t* w1 = W + (long)n1 * K;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+      const uint4 u0 = *reinterpret_cast<const uint4*>(w0 + k);
+      const uint4 u1 = *reinterpret_cast<const uint4*>(w1 + k);
+      float x0[8], x1[8];
+      x0[0] = bf2f(u0.x & 0xFFFF); x0[1] = bf2f(u0.x >> 16); x0[2] = bf2f(u0.y & 0xFFFF); x0[3] = bf2f(u0.y >> 16);
+      x0[4] = bf2f(u0.z & 0xFFFF); x0[5] = bf2f(u0.z >> 16); x0[6] = bf2f(u0.w & 0xFFFF); x0[7] = bf2f(u0.w >> 16);
+      x1[0] = bf2f(u1.x & 0xFFFF); x1[1] = bf2f(u1.x >> 16); x1[2] = bf2f(u1.y & 0xFFFF); x1[3] = bf2f(u1.y >> 16);
+      x1[4] = bf2f(u1.z & 0xFFFF); x1[5] = bf2f(u1.z >> 16); x1[6] = bf2f(u1.w & 0xFFFF); x1[7] = bf2f(u1.w >> 16);
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const float4 a0 = *reinterpret_cast<const float4*>(&sA[m * K + k]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&sA[m * K + k + 4]);
+        acc0[m] += a0.x * x0[0] + a0.y * x0[1] + a0.z * x0[2] + a0.w * x0[3] + a1.x * x0[4] + a1.y * x0[5] + a1.z * x0[6] + a1.w * x0[7];
+        acc1[m] += a0.x * x1[0] + a0.y * x1[1] + a0.z * x1[2] + a0.w * x1[3] + a1.x * x1[4] + a1.y * x1[5] + a1.z * x1[6] + a1.w * x1[7];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const float v0 = wave_sum(acc0[m]), v1 = wave_sum(acc1[m]);
+      if (lane == 0 && m < M) {
+        float r0 = v0 + (bias ? bias[n0] : 0.f), r1 = v1 + (bias ? bias[n1] : 0.f);
+        if (act_out == 1) { r0 = silu_f(r0); r1 = silu_f(r1); }
+        else if (act_out == 2) { r0 = 1.0f / (1.0f + __expf(-r0)); r1 = 1.0f / (1.0f + __expf(-r1)); }
+        out[(long)m * ldo + n0] = r0;
+        if (n0 + 1 < N) out[(long)m * ldo + n0 + 1] = r1;
+      }
+    }
+  }
+}
+
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int N, int dim) {
   const int half = dim >> 1;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -268,6 +339,37 @@ __global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __re
     const int src = (r < 32) ? (blk * 32 + r) : (half_rows + blk * 32 + (r - 32));
     wout[e] = f2bf(w[(long)src * K + k]);
     if (k == 0) bout[prow] = b[src];
+  }
+}
+
+// LayerNorm folded into the consuming Linear (attention_openai.py:211-215 pre-norms): one wave per weight row.
+//   wout[dst][k] = operand(gamma[k] * w[r][k]);  cs[dst] = sum_k wout[dst][k] (as rounded);  bb[dst] = beta . w[r] + bias[r]
+// dst = row_off + r, or the GEGLU (32 x | 32 gate) interleave of r when geglu_half > 0.
+__global__ __launch_bounds__(256) void pack_ln_linear_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, bf16_t* __restrict__ wout,
+                                                             float* __restrict__ cs, float* __restrict__ bb, int rows,
+                                                             int K, int row_off, int geglu_half) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  int dst = row_off + r;
+  if (geglu_half > 0) {
+    const int rr = r < geglu_half ? r : r - geglu_half;
+    dst = (rr >> 5) * 64 + (rr & 31) + (r < geglu_half ? 0 : 32);
+  }
+  float s = 0.f, b = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float wv = w[(long)r * K + k];
+    const bf16_t o = f2bf(gamma[k] * wv);
+    wout[(long)dst * K + k] = o;
+    s += bf2f(o);
+    b += beta[k] * wv;
+  }
+  s = wave_sum(s);
+  b = wave_sum(b);
+  if (lane == 0) {
+    cs[dst] = s;
+    bb[dst] = b + (bias ? bias[r] : 0.f);
   }
 }
 
@@ -385,6 +487,30 @@ hipError_t launch_linear_rows(const float* a, int lda, const uint16_t* W, const 
   return hipGetLastError();
 }
 
+hipError_t launch_linear_rows_lds(const float* a, int lda, const float* tvals, int t_B, const uint16_t* W,
+                                  const float* bias, float* out, int ldo, int M, int N, int K, int act_out, hipStream_t s) {
+  if (K % 8 != 0 || (a && lda % 4 != 0) || M < 1 || M > 16 || (size_t)16 * K * 4 > 96 * 1024) return hipErrorInvalidValue;
+  const int blocks = (N + 63) / 64;
+#define DF_LRL(MR)                                                                                                  \
+  {                                                                                                                 \
+    const size_t lds = (size_t)MR * K * 4;                                                                          \
+    static size_t attr = 0;                                                                                         \
+    if (lds > attr) {                                                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_rows_lds_kernel<MR>),                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+      if (e != hipSuccess) return e;                                                                                \
+      attr = lds;                                                                                                   \
+    }                                                                                                               \
+    hipLaunchKernelGGL(linear_rows_lds_kernel<MR>, dim3(blocks), dim3(256), lds, s, a, lda, tvals, t_B, W, bias, out, ldo, \
+                       M, N, K, act_out);                                                                           \
+  }
+  if (M <= 4) DF_LRL(4)
+  else if (M <= 8) DF_LRL(8)
+  else DF_LRL(16)
+#undef DF_LRL
+  return hipGetLastError();
+}
+
 hipError_t launch_timestep_embedding(const float* t, float* out, int N, int dim, hipStream_t s) {
   const int n = N * (dim / 2);
   hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, out, N, dim);
@@ -423,6 +549,15 @@ hipError_t launch_pack_geglu(const float* w, const float* b, uint16_t* wout, flo
   if (half_rows % 32 != 0) return hipErrorInvalidValue;
   const long n = (long)2 * half_rows * K;
   hipLaunchKernelGGL(pack_geglu_kernel, dim3(grid_for(n)), dim3(256), 0, s, w, b, wout, bout, half_rows, K);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_ln_linear(const float* w, const float* bias, const float* gamma, const float* beta,
+                                 uint16_t* wout, float* cs, float* bb, int rows, int K, int row_off, int geglu_half,
+                                 hipStream_t s) {
+  if (geglu_half > 0 && (geglu_half % 32 != 0 || rows != 2 * geglu_half || row_off != 0)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_ln_linear_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, w, bias, gamma, beta, wout, cs, bb, rows,
+                     K, row_off, geglu_half);
   return hipGetLastError();
 }
 

@@ -143,6 +143,7 @@ struct df_ctx {
   float* ctx_copy = nullptr;
   size_t ctx_copy_bytes = 0;
   bool autotune = false;
+  bool reloaded = false;          // a tensor that already existed was loaded again: packed operand copies are stale
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;      // pairs (start, stop) per executed op while profiling
   std::vector<int> prof_fam;
@@ -274,6 +275,38 @@ struct df_ctx {
     *b = (const float*)packed[kb];
   }
 
+  // LayerNorm `norm` folded into the Linear(s) `names` stacked along the output dim (biases[i] may be empty):
+  // operand rows gamma*W, their column sums and the folded bias beta.W + b.  geglu: ONE matrix, rows GEGLU-interleaved.
+  void w_ln_stack(const std::string& key, const std::string& norm, const std::vector<std::string>& names,
+                  const std::vector<std::string>& biases, bool geglu, const bf16_t** w, const float** cs, const float** bb) {
+    const std::string kw = key + "#lnw", kc = key + "#lncs", kb = key + "#lnbb";
+    if (!packed.count(kw)) {
+      int rows = 0;
+      const int K = (int)rt(names[0]).shape[1];
+      for (auto& n : names) rows += (int)rt(n).shape[0];
+      bf16_t* wo = (bf16_t*)pmalloc((size_t)rows * K * 2);
+      float* co = (float*)pmalloc((size_t)rows * 4);
+      float* bo = (float*)pmalloc((size_t)rows * 4);
+      const float* g = f32(norm + ".weight");
+      const float* be = f32(norm + ".bias");
+      int off = 0;
+      for (size_t i = 0; i < names.size(); ++i) {
+        const RawT& t = rt(names[i]);
+        if ((int)t.shape[1] != K) fail("w_ln_stack %s: input dims differ", key.c_str());
+        const float* bias = (i < biases.size() && !biases[i].empty()) ? f32(biases[i]) : nullptr;
+        const int r = (int)t.shape[0];
+        HIPCHK(launch_pack_ln_linear(t.d, bias, g, be, wo, co, bo, r, K, off, geglu ? r / 2 : 0, pack_stream));
+        off += r;
+      }
+      packed[kw] = wo;
+      packed[kc] = co;
+      packed[kb] = bo;
+    }
+    *w = (const bf16_t*)packed[kw];
+    *cs = (const float*)packed[kc];
+    *bb = (const float*)packed[kb];
+  }
+
   void w_geglu(const std::string& prefix, const bf16_t** w, const float** b) {
     const std::string kw = prefix + ".weight#geglu", kb = prefix + ".bias#geglu";
     auto it = packed.find(kw);
@@ -332,6 +365,20 @@ struct Builder {
   int which = 0;       // 0 = unet, 1 = classifier (emb offset table)
 
   std::string nm(const std::string& s) const { return pre + s; }
+
+  // A consumer that needs the operand-type copy of a block's fp32 output (Downsample / Upsample convs) sets
+  // want_aux before the block is built; the block's last GEMM then writes the copy from its epilogue (no cast pass)
+  // and leaves the buffer in last_aux.
+  bool want_aux = false;
+  bf16_t* last_aux = nullptr;
+  void attach_aux(GemmParams& g, int rows, int C) {
+    last_aux = nullptr;
+    if (!want_aux) return;
+    last_aux = buf<bf16_t>((size_t)rows * C);
+    g.aux = last_aux;
+    g.ld_aux = C;
+    want_aux = false;
+  }
 
   template <class T>
   T* buf(size_t n) {
@@ -464,6 +511,7 @@ struct Builder {
       out_f32(g, out.p, out.ld);
       g.bias = c->f32(nm(c2 + ".bias"));
       if (has_skip) { g.res = out.p; g.ldr = out.ld; } else { g.res = x.p; g.ldr = x.ld; }
+      attach_aux(g, M, cout);
       gemm(g, 1, "res.conv2");
     }
     pl->release(a2);
@@ -478,49 +526,64 @@ struct Builder {
     const std::string tb = p + ".transformer_blocks.0";
     const float scale = 1.0f / sqrtf((float)D);
     bf16_t* a = groupnorm(x, NB, p + ".norm", 1e-6f, 0, nullptr);
-    float* t0 = buf<float>((size_t)M * C);
-    F32 t0v{t0, M, C, C};
+    float* t0 = buf<float>((size_t)M * C);        // fp32 residual stream of the transformer block
+    bf16_t* xb = buf<bf16_t>((size_t)M * C);      // its operand-type copy (A operand of the LayerNorm-folded GEMMs)
+    const int slots = C / 64;
+    float2* st = buf<float2>((size_t)M * slots);  // per-row (sum, sumsq) partials per 64-column slot of t0
+    // The three pre-norm LayerNorms (attention_openai.py:211-215) never run as kernels: the producer of t0 emits the
+    // row statistics from its epilogue, the consumer GEMM multiplies the RAW operand copy by gamma-scaled weights and
+    // its epilogue applies  rstd * (acc - mean * colsum) + (beta.W + b).
+    auto produces_t0 = [&](GemmParams& g) {
+      out_f32(g, t0, C);
+      g.aux = xb; g.ld_aux = C;
+      g.stats = st; g.stats_slots = slots;
+    };
+    auto ln_fold = [&](GemmParams& g, const float* cs, const float* bb) {
+      g.ln_stats = st; g.ln_slots = slots; g.ln_C = C; g.ln_eps = 1e-5f; g.ln_cs = cs;
+      g.bias = bb;
+    };
     {
       GemmParams g = gp_linear(a, M, C, c->w_linear(nm(p + ".proj_in.weight")), C);
-      out_f32(g, t0, C);
+      produces_t0(g);
       g.bias = c->f32(nm(p + ".proj_in.bias"));
       gemm(g, 1, "st.proj_in");
     }
-    // ---- self attention
-    layernorm(t0v, tb + ".norm1", a);
+    // ---- self attention: one GEMM for Q | K | V; the V third leaves transposed (V^T[n][c][t]) from the epilogue
     bf16_t* qk = buf<bf16_t>((size_t)M * 2 * C);
-    {
-      const bf16_t* w = c->w_stack(nm(tb + ".attn1.qk"), {nm(tb + ".attn1.to_q.weight"), nm(tb + ".attn1.to_k.weight")});
-      GemmParams g = gp_linear(a, M, C, w, 2 * C);
-      out_b16(g, qk, 2 * C);
-      gemm(g, 1, "st.qk");
-    }
     const int ldvt = rup(T, 32);
     bf16_t* vt = buf<bf16_t>((size_t)NB * C * ldvt);
-    {  // V^T[n] = Wv . a[n]^T  (batched: A = Wv shared, "W" operand = this sample's tokens)
-      GemmParams g = gp_linear(c->w_linear(nm(tb + ".attn1.to_v.weight")), C, C, a, T);
-      g.w_bs = (long)T * C;
-      out_b16(g, vt, ldvt);
-      g.c_bs = (long)C * ldvt;
-      gemm(g, NB, "st.vT");
+    {
+      const bf16_t* w;
+      const float *cs, *bb;
+      c->w_ln_stack(nm(tb + ".attn1.qkv"), nm(tb + ".norm1"),
+                    {nm(tb + ".attn1.to_q.weight"), nm(tb + ".attn1.to_k.weight"), nm(tb + ".attn1.to_v.weight")}, {}, false,
+                    &w, &cs, &bb);
+      GemmParams g = gp_linear(xb, M, C, w, 3 * C);
+      out_b16(g, qk, 2 * C);
+      ln_fold(g, cs, bb);
+      g.vt = vt; g.vt_col0 = 2 * C; g.vt_T = T; g.ldvt = ldvt;
+      gemm(g, 1, "st.qkv");
     }
-    bf16_t* o = buf<bf16_t>((size_t)M * C);
+    bf16_t* o = a;                                 // GroupNorm output is dead after proj_in
     other("attn.self", [=](hipStream_t s, const RunArgs&) {
       return launch_attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, o, C, NB, heads, D, T, T, scale, s);
     });
     {
       GemmParams g = gp_linear(o, M, C, c->w_linear(nm(tb + ".attn1.to_out.0.weight")), C);
-      out_f32(g, t0, C);
+      produces_t0(g);
       g.bias = c->f32(nm(tb + ".attn1.to_out.0.bias"));
       g.res = t0; g.ldr = C;
       gemm(g, 1, "st.attn1.out");
     }
     // ---- cross attention (K / V^T of the context were computed by set_context)
-    layernorm(t0v, tb + ".norm2", a);
     bf16_t* q2 = qk;
     {
-      GemmParams g = gp_linear(a, M, C, c->w_linear(nm(tb + ".attn2.to_q.weight")), C);
+      const bf16_t* w;
+      const float *cs, *bb;
+      c->w_ln_stack(nm(tb + ".attn2.q"), nm(tb + ".norm2"), {nm(tb + ".attn2.to_q.weight")}, {}, false, &w, &cs, &bb);
+      GemmParams g = gp_linear(xb, M, C, w, C);
       out_b16(g, q2, C);
+      ln_fold(g, cs, bb);
       gemm(g, 1, "st.q2");
     }
     other("attn.cross", [=](hipStream_t s, const RunArgs&) {
@@ -528,24 +591,23 @@ struct Builder {
     });
     {
       GemmParams g = gp_linear(o, M, C, c->w_linear(nm(tb + ".attn2.to_out.0.weight")), C);
-      out_f32(g, t0, C);
+      produces_t0(g);
       g.bias = c->f32(nm(tb + ".attn2.to_out.0.bias"));
       g.res = t0; g.ldr = C;
       gemm(g, 1, "st.attn2.out");
     }
     pl->release(qk);
     pl->release(vt);
-    pl->release(o);
     // ---- GEGLU feed-forward
-    layernorm(t0v, tb + ".norm3", a);
     bf16_t* gl = buf<bf16_t>((size_t)M * 4 * C);
     {
       const bf16_t* w;
-      const float* b;
-      c->w_geglu(nm(tb + ".ff.net.0.proj"), &w, &b);
-      GemmParams g = gp_linear(a, M, C, w, 8 * C);
+      const float *cs, *bb;
+      c->w_ln_stack(nm(tb + ".ff.net.0.proj"), nm(tb + ".norm3"), {nm(tb + ".ff.net.0.proj.weight")},
+                    {nm(tb + ".ff.net.0.proj.bias")}, true, &w, &cs, &bb);
+      GemmParams g = gp_linear(xb, M, C, w, 8 * C);
       out_b16(g, gl, 4 * C);
-      g.bias = b;
+      ln_fold(g, cs, bb);
       g.geglu = 1;
       gemm(g, 1, "st.ff1");
     }
@@ -562,10 +624,13 @@ struct Builder {
       out_f32(g, out.p, out.ld);
       g.bias = c->f32(nm(p + ".proj_out.bias"));
       g.res = x.p; g.ldr = x.ld;
+      attach_aux(g, M, C);
       gemm(g, 1, "st.proj_out");
     }
     pl->release(a);
     pl->release(t0);
+    pl->release(xb);
+    pl->release(st);
   }
 
   // context -> per-ST K [NB*Tc][C] and V^T [NB][C][ldvt]
@@ -731,29 +796,15 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
 
   // ---- time embedding MLP and the fused emb projection of every ResBlock
   const int B_ext = cfg_mode ? N / 2 : N;
-  float* tbuf = b.buf<float>(N);
-  b.other("t.copy", [=](hipStream_t s, const RunArgs& a) {
-    hipError_t e = hipMemcpyAsync(tbuf, a.t, (size_t)B_ext * 4, hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return e;
-    if (cfg_mode) e = hipMemcpyAsync(tbuf + B_ext, a.t, (size_t)B_ext * 4, hipMemcpyDeviceToDevice, s);
-    return e;
-  });
-  float* te = b.buf<float>((size_t)N * mc);
-  b.other("t.embed", [=](hipStream_t s, const RunArgs&) { return launch_timestep_embedding(tbuf, te, N, mc, s); });
   float* e1 = b.buf<float>((size_t)N * temb);
   float* semb = b.buf<float>((size_t)N * temb);
+  const int etot = c->emb_total[which];
+  float* E = b.buf<float>((size_t)N * etot);
   {
     const bf16_t* w0 = c->w_linear(pre + "time_embed.0.weight");
     const float* b0 = c->f32(pre + "time_embed.0.bias");
     const bf16_t* w2 = c->w_linear(pre + "time_embed.2.weight");
     const float* b2 = c->f32(pre + "time_embed.2.bias");
-    b.other("t.mlp0", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(te, mc, w0, b0, e1, temb, N, temb, mc, 1, s); });
-    // emb is only ever consumed through SiLU (emb_layers = SiLU -> Linear), so SiLU is applied here once
-    b.other("t.mlp2", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(e1, temb, w2, b2, semb, temb, N, temb, temb, 1, s); });
-  }
-  const int etot = c->emb_total[which];
-  float* E = b.buf<float>((size_t)N * etot);
-  {
     std::vector<std::string> wn, bn;
     for (auto& r : topo_resblocks(topo)) {
       wn.push_back(pre + r + ".emb_layers.1.weight");
@@ -761,7 +812,33 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
     }
     const bf16_t* w = c->w_stack(pre + "#embw", wn);
     const float* bb = c->b_stack(pre + "#embb", bn);
-    b.other("t.embproj", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(semb, temb, w, bb, E, etot, N, etot, temb, 0, s); });
+    if (N <= 16) {
+      // three weight-streaming launches: [timestep embedding (CFG duplication folded in) -> Linear -> SiLU],
+      // [Linear -> SiLU] (emb is only ever consumed through SiLU: emb_layers = SiLU -> Linear), and the stacked
+      // emb_layers projections of all ResBlocks
+      b.other("t.mlp0", [=](hipStream_t s, const RunArgs& a) {
+        return launch_linear_rows_lds(nullptr, 0, a.t, B_ext, w0, b0, e1, temb, N, temb, mc, 1, s);
+      });
+      b.other("t.mlp2", [=](hipStream_t s, const RunArgs&) {
+        return launch_linear_rows_lds(e1, temb, nullptr, 0, w2, b2, semb, temb, N, temb, temb, 1, s);
+      });
+      b.other("t.embproj", [=](hipStream_t s, const RunArgs&) {
+        return launch_linear_rows_lds(semb, temb, nullptr, 0, w, bb, E, etot, N, etot, temb, 0, s);
+      });
+    } else {
+      float* tbuf = b.buf<float>(N);
+      b.other("t.copy", [=](hipStream_t s, const RunArgs& a) {
+        hipError_t e = hipMemcpyAsync(tbuf, a.t, (size_t)B_ext * 4, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return e;
+        if (cfg_mode) e = hipMemcpyAsync(tbuf + B_ext, a.t, (size_t)B_ext * 4, hipMemcpyDeviceToDevice, s);
+        return e;
+      });
+      float* te = b.buf<float>((size_t)N * mc);
+      b.other("t.embed", [=](hipStream_t s, const RunArgs&) { return launch_timestep_embedding(tbuf, te, N, mc, s); });
+      b.other("t.mlp0", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(te, mc, w0, b0, e1, temb, N, temb, mc, 1, s); });
+      b.other("t.mlp2", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(e1, temb, w2, b2, semb, temb, N, temb, temb, 1, s); });
+      b.other("t.embproj", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(semb, temb, w, bb, E, etot, N, etot, temb, 0, s); });
+    }
     pl->weight_bytes += 2.0 * etot * temb + 2.0 * (temb * mc + temb * temb);
   }
 
@@ -794,12 +871,18 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
     return F32{ct.p + ct.ch, ct.rows, ct.ich, ct.ch + ct.ich};
   };
 
-  auto run_block = [&](const std::vector<BlockDesc>& blk, F32 h, int ds, F32 final_dst) -> F32 {
+  bf16_t* h_aux = nullptr;        // operand-type copy of the current h, when its producer was asked for one
+  auto run_block = [&](const std::vector<BlockDesc>& blk, F32 h, int ds, F32 final_dst, bool tail_aux) -> F32 {
     for (size_t li = 0; li < blk.size(); ++li) {
       const BlockDesc& d = blk[li];
       const bool last = (li + 1 == blk.size());
       int hh = H / ds, ww = W / ds;
       F32 dst;
+      // the conv of a following Downsample / Upsample reads the operand-type copy of this op's output
+      b.want_aux = (d.kind == BlockDesc::RES || d.kind == BlockDesc::ST) &&
+                   (last ? tail_aux : blk[li + 1].kind == BlockDesc::UP);
+      bf16_t* in_aux = h_aux;
+      h_aux = nullptr;
       auto mk = [&](int rows, int C) {
         if (last && final_dst.p) return final_dst;
         return F32{b.buf<float>((size_t)rows * C), rows, C, C};
@@ -820,7 +903,7 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
         b.spatial_transformer(h, dst, N, hh * ww, d.prefix, heads, kv[d.prefix].first, kv[d.prefix].second, Tc, ldvtc);
       } else if (d.kind == BlockDesc::DOWN) {
         dst = mk(h.rows / 4, d.cout);
-        bf16_t* hb = b.cast2d(h);
+        bf16_t* hb = in_aux ? in_aux : b.cast2d(h);
         GemmParams g = Builder::gp_conv3(hb, N, hh, ww, d.cin, c->w_conv3(pre + d.prefix + ".op.weight", d.cin), d.cout, 2, 0);
         Builder::out_f32(g, dst.p, dst.ld);
         g.bias = c->f32(pre + d.prefix + ".op.bias");
@@ -828,13 +911,16 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
         pl->release(hb);
       } else {  // UP: nearest x2 then conv3x3 (openai_unetmodel.py:100-119)
         dst = mk(h.rows * 4, d.cout);
-        bf16_t* hb = b.cast2d(h);
+        bf16_t* hb = in_aux ? in_aux : b.cast2d(h);
         GemmParams g = Builder::gp_conv3(hb, N, hh, ww, d.cin, c->w_conv3(pre + d.prefix + ".conv.weight", d.cin), d.cout, 1, 1);
         Builder::out_f32(g, dst.p, dst.ld);
         g.bias = c->f32(pre + d.prefix + ".conv.bias");
         b.gemm(g, 1, "up");
         pl->release(hb);
       }
+      if (d.kind == BlockDesc::RES || d.kind == BlockDesc::ST) h_aux = b.last_aux;
+      b.last_aux = nullptr;
+      b.want_aux = false;
       // the previous intermediate is dead unless it lives in a concat buffer
       bool in_cat = false;
       for (auto& ct : cats)
@@ -848,11 +934,12 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
   F32 h{};
   for (int k = 0; k < nin; ++k) {
     const int ds_run = (topo.input[k][0].kind == BlockDesc::DOWN) ? topo.in_ds[k] / 2 : topo.in_ds[k];
-    h = run_block(topo.input[k], h, ds_run, skip_slot(k));
+    const bool next_down = (k + 1 < nin) && topo.input[k + 1][0].kind == BlockDesc::DOWN;
+    h = run_block(topo.input[k], h, ds_run, skip_slot(k), next_down);
   }
   const int ds_mid = topo.in_ds.back();
   if (which) {
-    h = run_block(topo.middle, h, ds_mid, F32{});
+    h = run_block(topo.middle, h, ds_mid, F32{}, false);
     // classifier head: GN -> SiLU -> conv3x3 -> global avg-pool -> Linear -> sigmoid (alignment_backbone.py:630-638)
     const int hh = H / ds_mid, ww = W / ds_mid, co = topo.final_ch / 2;
     bf16_t* a = b.groupnorm(h, N, "out.0", 1e-5f, 1, nullptr);
@@ -870,13 +957,13 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
     return;
   }
   // middle block output goes into the first concat buffer's leading columns
-  h = run_block(topo.middle, h, ds_mid, F32{cats[0].p, cats[0].rows, cats[0].ch, cats[0].ch + cats[0].ich});
+  h = run_block(topo.middle, h, ds_mid, F32{cats[0].p, cats[0].rows, cats[0].ch, cats[0].ch + cats[0].ich}, false);
   const int nout = (int)topo.output.size();
   for (int j = 0; j < nout; ++j) {
     F32 cat{cats[j].p, cats[j].rows, cats[j].ch + cats[j].ich, cats[j].ch + cats[j].ich};
     F32 dst{};
     if (j + 1 < nout) dst = F32{cats[j + 1].p, cats[j + 1].rows, cats[j + 1].ch, cats[j + 1].ch + cats[j + 1].ich};
-    h = run_block(topo.output[j], cat, topo.out_ds[j], dst);
+    h = run_block(topo.output[j], cat, topo.out_ds[j], dst, false);
   }
   // ---- out: GN -> SiLU -> conv3x3 -> NCHW fp32 (openai_unetmodel.py:682-686)
   bf16_t* a = b.groupnorm(h, N, "out.0", 1e-5f, 1, nullptr);
@@ -1625,7 +1712,8 @@ struct TuneCand { int tile, sk; float iso_ms; double situ_ms; };
 static std::string tune_key(const Op& o) {
   const GemmParams& g = o.gp;
   char key[160];
-  snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d_%d", g.M, g.N, g.K, g.taps, g.stride, g.ups, o.batch, g.geglu);
+  const int epi = (g.ln_stats ? 1 : 0) | (g.stats ? 2 : 0) | (g.vt ? 4 : 0) | (g.aux ? 8 : 0) | (g.res ? 16 : 0);
+  snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d_%d_e%d", g.M, g.N, g.K, g.taps, g.stride, g.ups, o.batch, g.geglu, epi);
   return key;
 }
 
@@ -1660,7 +1748,7 @@ static void tune_cache_save() {
 
 void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
   {
-    auto& tc = tune_cache();
+    auto& tc = tune_cache();      // in-memory for the life of the process (+ the file when DF_TUNE_CACHE is set)
     bool all = !tc.empty();
     for (auto& o : pl->ops)
       if (o.is_gemm && !o.c_ext && !tc.count(tune_key(o))) all = false;
@@ -1681,7 +1769,6 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
   struct SaveOnExit {
     Plan* pl;
     ~SaveOnExit() {
-      if (!getenv("DF_TUNE_CACHE")) return;
       for (auto& o : pl->ops)
         if (o.is_gemm && !o.c_ext) tune_cache()[tune_key(o)] = {o.tile, o.gp.splitk, o.gp.gm};
       tune_cache_save();
@@ -1935,8 +2022,10 @@ static void load_common(df_ctx* c, const char* name, const float* src, const int
   }
   auto it = c->raw.find(name);
   if (it != c->raw.end()) {
+    HIPCHK(hipDeviceSynchronize());       // plans of the old weights may still be running
     (void)hipFree(it->second.d);
     c->raw.erase(it);
+    c->reloaded = true;
   }
   HIPCHK(hipMalloc((void**)&t.d, ((t.n * 4) + 255) & ~(size_t)255));
   HIPCHK(hipMemcpy(t.d, src, t.n * 4, kind));
@@ -1955,7 +2044,17 @@ int df_finalize(df_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     if (c->has_unet) build_emb_table(c, 0);
     if (c->has_cls) build_emb_table(c, 1);
+    HIPCHK(hipDeviceSynchronize());
     c->plans.clear();
+    if (c->reloaded) {     // every packed operand copy (casts, GEGLU / LN-folded / BN-folded / stacked packings) is rebuilt
+      for (void* p : c->packed_blocks) (void)hipFree(p);
+      c->packed_blocks.clear();
+      c->packed.clear();
+      c->ctx_copy = nullptr;
+      c->ctx_copy_bytes = 0;
+      c->ctx_N = c->ctx_T = 0;
+      c->reloaded = false;
+    }
     c->last_unet = nullptr;
     c->finalized = true;
   });
@@ -2196,6 +2295,66 @@ int df_test_gemm(const uint16_t* A, const uint16_t* W, float* C, int M, int N, i
     g.splitk = splitk;
     if (splitk > 1) g.partial = test_partial((size_t)splitk * M * N * 4);
     HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
+  });
+}
+
+// Producer GEMM (t0 = A0 W0^T + b0 [+ t0_in], fp32 + operand copy + per-row partial statistics) followed by a
+// LayerNorm-folded consumer GEMM (y = LN(t0; gamma, beta) W1^T + b1), exactly the pair the SpatialTransformer plan uses.
+// mode 0: y fp32 [M][N1];  mode 1: GEGLU (W1 = [x ; gate] rows, y operand-type [M][N1/2]);  mode 2: fused QKV --
+// N1 = 3C, y operand-type [M][2C] and vt operand-type [M/T][C][ldvt] (V columns transposed per sample of T rows).
+int df_test_ln_chain(const uint16_t* A0, const uint16_t* W0, const float* b0, const float* res_in, const float* gamma,
+                     const float* beta, const float* W1, const float* b1, float* t0, void* y, uint16_t* vt, int M, int C,
+                     int N1, int mode, int T, int ldvt, int tile0, int sk0, int tile1, int sk1, void* stream) {
+  return guard([&] {
+    hipStream_t s = (hipStream_t)stream;
+    const int slots = C / 64;
+    uint16_t *xb = nullptr, *w1p = nullptr;
+    float2* st = nullptr;
+    float *cs = nullptr, *bb = nullptr;
+    HIPCHK(hipMalloc((void**)&xb, (size_t)M * C * 2));
+    HIPCHK(hipMalloc((void**)&st, (size_t)M * slots * sizeof(float2)));
+    HIPCHK(hipMalloc((void**)&w1p, (size_t)N1 * C * 2));
+    HIPCHK(hipMalloc((void**)&cs, (size_t)N1 * 4));
+    HIPCHK(hipMalloc((void**)&bb, (size_t)N1 * 4));
+    HIPCHK(hipMemsetAsync(st, 0xFF, (size_t)M * slots * sizeof(float2), s));      // NaN poison: every slot must be written
+    HIPCHK(launch_pack_ln_linear(W1, b1, gamma, beta, w1p, cs, bb, N1, C, 0, mode == 1 ? N1 / 2 : 0, s));
+    {
+      GemmParams g = Builder::gp_linear(A0, M, C, W0, C);
+      Builder::out_f32(g, t0, C);
+      g.bias = b0;
+      if (res_in) { g.res = res_in; g.ldr = C; }
+      g.aux = xb; g.ld_aux = C;
+      g.stats = st; g.stats_slots = slots;
+      g.splitk = sk0;
+      if (sk0 > 1) g.partial = test_partial((size_t)sk0 * M * C * 4);
+      if (!gemm_tile_valid(g, tile0, 1, sk0)) fail("producer: tile %d / split-K %d not valid here", tile0, sk0);
+      HIPCHK(launch_gemm(g, tile0, 1, s));
+    }
+    {
+      GemmParams g = Builder::gp_linear(xb, M, C, w1p, N1);
+      g.ln_stats = st; g.ln_slots = slots; g.ln_C = C; g.ln_eps = 1e-5f; g.ln_cs = cs;
+      g.bias = bb;
+      if (mode == 0) Builder::out_f32(g, (float*)y, N1);
+      else if (mode == 1) { Builder::out_b16(g, (bf16_t*)y, N1 / 2); g.geglu = 1; }
+      else {
+        Builder::out_b16(g, (bf16_t*)y, 2 * C);
+        g.vt = vt; g.vt_col0 = 2 * C; g.vt_T = T; g.ldvt = ldvt;
+      }
+      g.splitk = sk1;
+      if (sk1 > 1) g.partial = test_partial((size_t)sk1 * M * N1 * 4);
+      if (!gemm_tile_valid(g, tile1, 1, sk1)) fail("consumer: tile %d / split-K %d not valid here", tile1, sk1);
+      HIPCHK(launch_gemm(g, tile1, 1, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    for (void* p : {(void*)xb, (void*)st, (void*)w1p, (void*)cs, (void*)bb}) (void)hipFree(p);
+  });
+}
+
+int df_test_linear_rows(const float* a, int lda, const float* tvals, int t_B, const uint16_t* W, const float* bias,
+                        float* out, int ldo, int M, int N, int K, int act, int lds_variant, void* stream) {
+  return guard([&] {
+    if (lds_variant) HIPCHK(launch_linear_rows_lds(a, lda, tvals, t_B, W, bias, out, ldo, M, N, K, act, (hipStream_t)stream));
+    else HIPCHK(launch_linear_rows(a, lda, W, bias, out, ldo, M, N, K, act, (hipStream_t)stream));
   });
 }
 

@@ -36,6 +36,17 @@ struct GemmParams {
   int relu;                          // max(v, 0) after bias / residual (CAVP encoder ConvModule activation)
   uint16_t* aux; int ld_aux;         // optional second output: operand-type copy of the stored value, [row][ld_aux]
   int geglu;                         // columns come in (x:32 | gate:32) groups, output width N/2
+  // LayerNorm folded into this GEMM (A = raw operand copy of x, W = gamma-scaled weights):
+  //   out[m][n] = rstd[m] * (acc[m][n] - mean[m] * ln_cs[n]) + bias[n]      (bias already holds beta.W + b)
+  // mean / rstd of row m come from the producer's per-row partials ln_stats[m][0..ln_slots) = (sum, sum of squares)
+  // over 64-column slots of the fp32 tensor the operand copy was made from (ln_C columns in total).
+  const float2* ln_stats; int ln_slots; int ln_C; float ln_eps;
+  const float* ln_cs;                // [N] column sums of the (operand-rounded) gamma-scaled weights
+  // per-row partial statistics of the STORED fp32 value (after bias / residual): stats[row][col/64] = (sum, sumsq)
+  float2* stats; int stats_slots;
+  // columns >= vt_col0 are stored TRANSPOSED per sample into vt[(row/vt_T)*(N-vt_col0) + col-vt_col0][ldvt] at
+  // position row%vt_T (attention V^T straight out of the fused QKV projection); vt_col0 % BN == 0 for every tile used
+  uint16_t* vt; int vt_col0; int vt_T; int ldvt;
   int store_nchw; int hw_out;        // write C as [batch][N][hw_out] instead of [rows][ldc]
   int gm;      // tile walk: each XCD's contiguous tile range runs M-fastest inside row groups of `gm` M-tiles (0 = all rows:
                // plain M-fastest; 1 = N-fastest).  Decides which operand panels an XCD's L2 can share; autotuned in situ.

@@ -158,10 +158,12 @@ __device__ __forceinline__ void epilogue_band(const GemmParams& p, int z, int ba
 template <int BM, int BN, int NT, int TM, int TN, class RowMap>
 __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int batch, float* sC,
                                                f32x16 (&acc)[TM][TN], int wrow0, int wcol0, int n0, int tid,
-                                               RowMap rowmap) {
+                                               RowMap rowmap, float2 ln_mr = make_float2(0.f, 1.f)) {
   constexpr int LDC = BN + 4;
   const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  float2* sRow = reinterpret_cast<float2*>(sC + BM * LDC);   // (mean, rstd) of tile row r (LayerNorm-folded GEMMs)
   __builtin_amdgcn_s_barrier();            // every wave is done reading the operand ring
+  if (p.ln_stats && tid < BM) sRow[tid] = ln_mr;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -194,6 +196,13 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       const int gx = min(n0 + xc, p.N - 36);
       float4 x = *reinterpret_cast<const float4*>(&sC[r * LDC + xc]);
       float4 g = *reinterpret_cast<const float4*>(&sC[r * LDC + xc + 32]);
+      if (p.ln_stats) {       // LayerNorm folded in: rstd * (acc - mean * colsum(gamma W))
+        const float2 mr = sRow[r];
+        const float4 cx = *reinterpret_cast<const float4*>(&p.ln_cs[gx]);
+        const float4 cg = *reinterpret_cast<const float4*>(&p.ln_cs[gx + 32]);
+        x.x = mr.y * (x.x - mr.x * cx.x); x.y = mr.y * (x.y - mr.x * cx.y); x.z = mr.y * (x.z - mr.x * cx.z); x.w = mr.y * (x.w - mr.x * cx.w);
+        g.x = mr.y * (g.x - mr.x * cg.x); g.y = mr.y * (g.y - mr.x * cg.y); g.z = mr.y * (g.z - mr.x * cg.z); g.w = mr.y * (g.w - mr.x * cg.w);
+      }
       if (has_bias) {
         const float4 bx = *reinterpret_cast<const float4*>(&p.bias[gx]);
         const float4 bg = *reinterpret_cast<const float4*>(&p.bias[gx + 32]);
@@ -215,14 +224,55 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
   // rows_per_sample is a power of two for every latent this model is used with: shift instead of a 25-instruction divide
   const int rps_sh = (has_rb && p.rows_per_sample > 0 && (p.rows_per_sample & (p.rows_per_sample - 1)) == 0)
                          ? (31 - __builtin_clz(p.rows_per_sample)) : -1;
-  // EXTRA = ReLU and/or the second (operand-type) output of the CAVP encoder; kept out of the UNet's loop body
-#define DF_EPI_LOOP(EXTRA)                                                                                          \
+  // ---- fused QKV projection: the V columns leave transposed, V^T[sample][col][token], 4 tokens (8 B) per store
+  if (p.vt && n0 >= p.vt_col0) {
+    constexpr int RG = BM / 4;               // groups of 4 consecutive rows (tokens)
+    const int cv = p.N - p.vt_col0;
+#pragma unroll 2
+    for (int e = tid; e < BN * RG; e += NT) {
+      const int c = e / RG, r = (e - c * RG) * 4;
+      const int row = rowmap(r), col = n0 + c;
+      const int cc = min(col, p.N - 1);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = sC[(r + j) * LDC + c] * p.alpha;
+      if (p.ln_stats) {
+        const float cs = p.ln_cs[cc];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float2 mr = sRow[r + j];
+          v[j] = mr.y * (v[j] - mr.x * cs);
+        }
+      }
+      if (has_bias) {
+        const float b = p.bias[cc];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += b;
+      }
+      if (row < p.M && col < p.N) {           // M % 4 == 0 and vt_T % 4 == 0: the 4 rows belong to one sample
+        const int smp = row / p.vt_T, t = row - smp * p.vt_T;
+        *reinterpret_cast<uint2*>(p.vt + ((long)smp * cv + (col - p.vt_col0)) * p.ldvt + t) =
+            make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      }
+    }
+    return;
+  }
+  // FL bit 0: ReLU and/or a second (operand-type) copy of the stored value; bit 1: LayerNorm folded into this GEMM;
+  // bit 2: per-row partial statistics of the stored value (16 lanes = one 64-column slot of one row).  Every variant
+  // is instantiated separately so the UNet's plain epilogues keep their lean loop body.
+#define DF_EPI_LOOP(FL)                                                                                             \
   _Pragma("unroll 4") for (int e = tid; e < BM * CPR; e += NT) {                                                    \
     const int r = e / CPR, c4 = (e - r * CPR) * 4;                                                                  \
     const int row = rowmap(r), col = n0 + c4;                                                                       \
     const int rc = min(row, p.M - 1), cc = min(col, p.N - 4);                                                       \
     float4 v = *reinterpret_cast<const float4*>(&sC[r * LDC + c4]);                                                 \
     v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;                                                 \
+    if ((FL) & 2) {                                                                                                 \
+      const float2 mr = sRow[r];                                                                                    \
+      const float4 cs = *reinterpret_cast<const float4*>(&p.ln_cs[cc]);                                            \
+      v.x = mr.y * (v.x - mr.x * cs.x); v.y = mr.y * (v.y - mr.x * cs.y);                                           \
+      v.z = mr.y * (v.z - mr.x * cs.z); v.w = mr.y * (v.w - mr.x * cs.w);                                           \
+    }                                                                                                               \
     if (has_bias) {                                                                                                 \
       const float4 b = *reinterpret_cast<const float4*>(&p.bias[cc]);                                               \
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
@@ -237,21 +287,33 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       const float4 b = *reinterpret_cast<const float4*>(&p.res[(long)batch * p.res_bs + (long)rc * p.ldr + cc]);    \
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
     }                                                                                                               \
-    if ((EXTRA) && p.relu) {                                                                                        \
+    if (((FL) & 1) && p.relu) {                                                                                     \
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);                   \
     }                                                                                                               \
-    if (row < p.M && col < p.N) {                                                                                   \
+    const bool ok = row < p.M && col < p.N;                                                                         \
+    if ((FL) & 4) {                                                                                                 \
+      float s1 = ok ? (v.x + v.y) + (v.z + v.w) : 0.f;                                                              \
+      float s2 = ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;                                      \
+      _Pragma("unroll") for (int o = 1; o < 16; o <<= 1) {                                                          \
+        s1 += __shfl_xor(s1, o);                                                                                    \
+        s2 += __shfl_xor(s2, o);                                                                                    \
+      }                                                                                                             \
+      if (ok && (tid & 15) == 0) p.stats[(long)row * p.stats_slots + (col >> 6)] = make_float2(s1, s2);             \
+    }                                                                                                               \
+    if (ok) {                                                                                                       \
       const long idx = (long)batch * p.c_bs + (long)row * p.ldc + col;                                              \
       if (p.out_bf16)                                                                                               \
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
       else                                                                                                          \
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;                                        \
-      if ((EXTRA) && p.aux)                                                                                         \
+      if (((FL) & 1) && p.aux)                                                                                      \
         *reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
     }                                                                                                               \
   }
-  if (p.relu || p.aux) DF_EPI_LOOP(true)
-  else DF_EPI_LOOP(false)
+  if (p.stats) DF_EPI_LOOP(5)
+  else if (p.ln_stats) DF_EPI_LOOP(2)
+  else if (p.relu || p.aux) DF_EPI_LOOP(1)
+  else DF_EPI_LOOP(0)
 #undef DF_EPI_LOOP
 }
 
@@ -484,6 +546,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   if (NST > 3) DF_DMA(2, 2);
   if (NST > 4) DF_DMA(3, 3);
 
+  // LayerNorm folded into this GEMM: thread r < BM reduces the producer's per-slot partials of tile row r to
+  // (mean, rstd) while the first operand tiles are in flight; the pair is parked in LDS by the epilogue.
+  float2 ln_mr = make_float2(0.f, 1.f);
+  if (MODE == 0 && p.ln_stats && p.splitk <= 1 && tid < BM) {
+    const float2* sp = p.ln_stats + (long)min(m0 + tid, p.M - 1) * p.ln_slots;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < p.ln_slots; ++i) {
+      const float2 v = sp[i];
+      s1 += v.x;
+      s2 += v.y;
+    }
+    const float inv = 1.0f / (float)p.ln_C;
+    const float mean = s1 * inv;
+    ln_mr = make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
+  }
+
   int it = 0;
   while (it < nt) {
     DF_ITER(0);
@@ -516,7 +594,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
                       (p.ld_rowbias & 3) == 0 && (p.res_bs & 3) == 0 && (p.c_bs & 3) == 0 && (p.ld_aux & 3) == 0;
   if (vec_ok) {
     epilogue_block<BM, BN, NT, TM, TN>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid,
-                                        [&](int r) { return m0 + r; });
+                                        [&](int r) { return m0 + r; }, ln_mr);
     return;
   }
 #pragma unroll
@@ -841,6 +919,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
       v.x += t[s].x; v.y += t[s].y; v.z += t[s].z; v.w += t[s].w;
     }
     v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+    if (p.ln_stats) {        // LayerNorm folded into the GEMM: row statistics from the producer's per-slot partials
+      const float2* sp = p.ln_stats + (long)row * p.ln_slots;
+      float s1 = 0.f, s2 = 0.f;
+      for (int i = 0; i < p.ln_slots; ++i) {
+        const float2 t2 = sp[i];
+        s1 += t2.x;
+        s2 += t2.y;
+      }
+      const float inv = 1.0f / (float)p.ln_C;
+      const float mean = s1 * inv, rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps);
+      const float4 cs = *reinterpret_cast<const float4*>(&p.ln_cs[col]);
+      v.x = rstd * (v.x - mean * cs.x); v.y = rstd * (v.y - mean * cs.y);
+      v.z = rstd * (v.z - mean * cs.z); v.w = rstd * (v.w - mean * cs.w);
+    }
     if (has_bias) {
       const float4 b = *reinterpret_cast<const float4*>(&p.bias[col]);
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
@@ -857,6 +949,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
     if (p.relu) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
+    if (p.stats) {           // N % 64 == 0: 16 consecutive threads hold one 64-column slot of one row
+      float s1 = (v.x + v.y) + (v.z + v.w);
+      float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+      }
+      if ((threadIdx.x & 15) == 0) p.stats[(long)row * p.stats_slots + (col >> 6)] = make_float2(s1, s2);
+    }
     const long idx = (long)row * p.ldc + col;
     if (p.out_bf16)
       *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
@@ -869,7 +971,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
 template <int BM, int BN, int WGM, int WGN, int NST, int MODE>
 hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  constexpr size_t ring = (size_t)(BM + BN) * BK * 2 * NST, stage = (size_t)BM * (BN + 4) * 4;   // operand ring | epilogue tile
+  constexpr size_t ring = (size_t)(BM + BN) * BK * 2 * NST;                    // operand ring
+  constexpr size_t stage = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8;          // epilogue tile + (mean, rstd) row table
   const size_t lds = ring > stage ? ring : stage;
   static bool attr_set = false;
   if (!attr_set) {
@@ -919,6 +1022,11 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   if (!gemm_tile_is_halo(tile)) {
     if (tile < 0 || tile >= TILE_ALL) return false;
     if (p.geglu && ((p.N & 63) != 0 || (p.ldc & 3) != 0)) return false;   // GEGLU needs the vectorised block epilogue
+    int bm_, bn_;
+    gemm_tile_dims(tile, &bm_, &bn_);
+    if (p.vt && (splitk > 1 || batch > 1 || p.vt_col0 % bn_ != 0)) return false;   // transposed-V tiles are whole tiles
+    if (p.ln_stats && (batch > 1 || (p.geglu && splitk > 1))) return false;
+    if (p.stats && batch > 1) return false;
     return splitk == 1 || (batch <= 1 && nk / splitk >= 2);
   }
   if (p.taps != 9 || p.stride != 1 || p.ups != 0 || p.geglu || batch > 1) return false;
@@ -937,6 +1045,12 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
 
 hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t stream) {
   const int zdim = (p.splitk > 1) ? p.splitk : (batch > 0 ? batch : 1);
+  if (p.ln_stats || p.stats || p.vt) {     // these epilogues exist in the vectorised paths only
+    const bool vec = !p.store_nchw && (p.N & 63) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.ld_rowbias & 3) == 0 &&
+                     (p.ld_aux & 3) == 0 && (p.M & 3) == 0;
+    if (!vec || (p.vt && ((p.vt_T & 3) != 0 || (p.ldvt & 3) != 0 || p.taps != 1))) return hipErrorInvalidValue;
+    if (p.ln_stats && p.taps != 1) return hipErrorInvalidValue;
+  }
   hipError_t e;
   // MODE 0: linear / 1x1;  1: 3x3 stride 1 (tap offsets are linear, 2 VALU per request);  2: 3x3 stride 2 / upsampled
   const int mode = (p.taps != 9) ? 0 : ((p.stride == 1 && !p.ups) ? 1 : 2);

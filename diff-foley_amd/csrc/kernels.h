@@ -29,6 +29,11 @@ hipError_t launch_softmax_rows(const float* s, uint16_t* p, int rows, int T, hip
 hipError_t launch_linear_rows(const float* a, int lda, const uint16_t* W, const float* bias, float* out, int ldo,
                               int M, int N, int K, int act_out /*0 none, 1 silu, 2 sigmoid*/, hipStream_t s);
 
+// Same, activations staged in LDS (weight stream is the only global traffic; HBM-rate).  tvals != nullptr: the
+// activations are the sinusoidal embedding (dim K) of tvals[m % t_B], generated in the kernel (`a` is ignored).
+hipError_t launch_linear_rows_lds(const float* a, int lda, const float* tvals, int t_B, const uint16_t* W,
+                                  const float* bias, float* out, int ldo, int M, int N, int K, int act_out, hipStream_t s);
+
 // Sinusoidal timestep embedding [cos | sin] (util.py:151-171), t fp32 (may be fractional) -> [N][dim] fp32
 hipError_t launch_timestep_embedding(const float* t, float* out, int N, int dim, hipStream_t s);
 
@@ -47,6 +52,11 @@ hipError_t launch_cast_bf16_2d(const float* x, int ld, uint16_t* out, long rows,
 // Weight re-pack on device: conv OIHW fp32 -> [O][kh][kw][Ipad] bf16 ; (Ipad >= I, zero filled)
 hipError_t launch_pack_conv_weight(const float* w, uint16_t* out, int O, int I, int KH, int KW, int Ipad, hipStream_t s);
 // GEGLU weight/bias interleave: rows [x(4C) ; gate(4C)] -> blocks of (32 x-rows | 32 gate-rows)
+// LayerNorm-folded Linear weight (one call per stacked matrix): operand rows gamma*W at row_off (or GEGLU-interleaved
+// when geglu_half > 0), their column sums cs and the folded bias bb = beta.W + bias
+hipError_t launch_pack_ln_linear(const float* w, const float* bias, const float* gamma, const float* beta,
+                                 uint16_t* wout, float* cs, float* bb, int rows, int K, int row_off, int geglu_half,
+                                 hipStream_t s);
 hipError_t launch_pack_geglu(const float* w, const float* b, uint16_t* wout, float* bout, int half_rows, int K,
                              hipStream_t s);
 

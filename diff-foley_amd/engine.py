@@ -76,6 +76,9 @@ _SIGS = {
     "df_profile_end": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "df_profile_dump": [C.c_void_p, C.c_char_p],
     "df_test_gemm": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "df_test_ln_chain": [C.c_void_p] * 11 + [C.c_int] * 10 + [C.c_void_p],
+    "df_test_linear_rows": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6
+                           + [C.c_void_p],
     "df_test_conv3x3": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p],
     "df_test_groupnorm": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
                           C.c_void_p, C.c_void_p],

@@ -154,6 +154,18 @@ int df_profile_dump(df_ctx* ctx, const char* path);
 /* Run ONE op family in isolation for unit tests (see tests/test_kernels_gpu.py). */
 int df_test_gemm(const uint16_t* A_dev, const uint16_t* W_dev, float* C_dev, int M, int N, int K, int tile, int splitk,
                  void* stream);
+/* SpatialTransformer GEMM pair: producer (fp32 t0 + operand copy + per-row partial statistics from the epilogue) and
+ * LayerNorm-folded consumer (attention_openai.py:211-215 pre-norms never run as kernels).  mode 0 plain fp32 out,
+ * 1 GEGLU, 2 fused QKV with the V third stored transposed per sample of T rows. */
+int df_test_ln_chain(const uint16_t* A0_dev, const uint16_t* W0_dev, const float* b0_dev, const float* res_in_dev,
+                     const float* gamma_dev, const float* beta_dev, const float* W1_dev, const float* b1_dev,
+                     float* t0_dev, void* y_dev, uint16_t* vt_dev, int M, int C, int N1, int mode, int T, int ldvt,
+                     int tile0, int sk0, int tile1, int sk1, void* stream);
+/* Small-M weight-streaming linear (time-embedding path): lds_variant 1 = activations staged in LDS (tvals != NULL:
+ * the activations are the sinusoidal embedding of tvals[m % t_B]); 0 = the register variant. */
+int df_test_linear_rows(const float* a_dev, int lda, const float* tvals_dev, int t_B, const uint16_t* W_dev,
+                        const float* bias_dev, float* out_dev, int ldo, int M, int N, int K, int act, int lds_variant,
+                        void* stream);
 int df_test_conv3x3(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, float* C_dev, int NB, int H,
                     int W, int Cin, int Cout, int stride, int ups, int tile, int splitk, void* stream);
 int df_test_groupnorm(const float* x_dev, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,
