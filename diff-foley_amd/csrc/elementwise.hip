@@ -199,11 +199,11 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
 // sinusoidal timestep embedding of tvals[m % t_B] (util.py:151-171, [cos | sin]) generated in place: the copy,
 // embedding and first MLP layer of the time-embedding path are one launch.
 template <int MR>
-__global__ __launch_bounds__(256) void linear_rows_lds_kernel(const float* __restrict__ a, int lda,
+__global__ __launch_bounds__(256, MR <= 8 ? 4 : 2) void linear_rows_lds_kernel(const float* __restrict__ a, int lda,
                                                               const float* __restrict__ tvals, int t_B,
                                                               const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, float* __restrict__ out,
-                                                              int ldo, int M, int N, int K, int act_out) {
+                                                              int ldo, int M, int N, int K, int act_out, int cpw) {
   extern __shared__ __attribute__((aligned(16))) float sA[];   // [MR][K]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (tvals) {
@@ -216,45 +216,73 @@ __global__ __launch_bounds__(256) void linear_rows_lds_kernel(const float* __res
       sA[m * K + half + k] = sinf(ang);
     }
   } else {
-    for (int i = tid * 4; i < M * K; i += 1024) {
+    // all of a thread's float4 loads are issued before the first LDS store (a load-store-load chain costs one L2 round
+    // trip per iteration: 10 of them for 8 x 1280 activations)
+    constexpr int SV = (MR * 1536 / 4 + 255) / 256;
+    float4 sv[SV];
+#pragma unroll
+    for (int j = 0; j < SV; ++j) {
+      const int i = min((tid + j * 256) * 4, M * K - 4);
       const int m = i / K, k = i - m * K;
-      *reinterpret_cast<float4*>(&sA[i]) = *reinterpret_cast<const float4*>(a + (long)m * lda + k);
+      sv[j] = *reinterpret_cast<const float4*>(a + (long)m * lda + k);
+    }
+#pragma unroll
+    for (int j = 0; j < SV; ++j) {
+      const int i = (tid + j * 256) * 4;
+      if (i < M * K) *reinterpret_cast<float4*>(&sA[i]) = sv[j];
     }
   }
   for (int i = M * K + tid; i < MR * K; i += 256) sA[i] = 0.f;
   __syncthreads();
-  const int col0 = blockIdx.x * 64 + wid * 16;
+  // Each wave owns cpw consecutive columns and walks them two at a time: 6 independent 16-B weight loads per pass
+  // (K <= 1536).  The kernel is capped at 128 VGPRs (4 blocks = 16 waves per CU, LDS 4 x 40 KB), which keeps ~96 KB of
+  // weight requests in flight per CU -- what it takes to stream at the HBM rate -- without any software pipelining.
+  constexpr int KI = 3;
+  const int col0 = (blockIdx.x * 4 + wid) * cpw;
 #pragma unroll 1
-  for (int pass = 0; pass < 8; ++pass) {
+  for (int pass = 0; pass < cpw / 2; ++pass) {
     const int n0 = col0 + pass * 2;
     if (n0 >= N) break;
-    const int n1 = min(n0 + 1, N - 1);
+    const bf16_t* w0 = W + (long)n0 * K;
+    const bf16_t* w1 = W + (long)min(n0 + 1, N - 1) * K;
+    uint4 u0[KI], u1[KI];
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int kc = min(lane * 8 + i * 512, K - 8);
+      u0[i] = *reinterpret_cast<const uint4*>(w0 + kc);
+      u1[i] = *reinterpret_cast<const uint4*>(w1 + kc);
+    }
     float acc0[MR], acc1[MR];
 #pragma unroll
     for (int m = 0; m < MR; ++m) acc0[m] = acc1[m] = 0.f;
-    const bf16_t* w0 = W + (long)n0 * K;
-    const bf16_t* w1 = W + (long)n1 * K;
-    for (int k = lane * 8; k < K; k += 64 * 8) {
-      const uint4 u0 = *reinterpret_cast<const uint4*>(w0 + k);
-      const uint4 u1 = *reinterpret_cast<const uint4*>(w1 + k);
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int k = lane * 8 + i * 512;
+      if (i * 512 >= K) break;                            // wave-uniform
+      const bool live = k < K;                            // lanes past K contribute nothing
+      const int kc = min(k, K - 8);
       float x0[8], x1[8];
-      x0[0] = bf2f(u0.x & 0xFFFF); x0[1] = bf2f(u0.x >> 16); x0[2] = bf2f(u0.y & 0xFFFF); x0[3] = bf2f(u0.y >> 16);
-      x0[4] = bf2f(u0.z & 0xFFFF); x0[5] = bf2f(u0.z >> 16); x0[6] = bf2f(u0.w & 0xFFFF); x0[7] = bf2f(u0.w >> 16);
-      x1[0] = bf2f(u1.x & 0xFFFF); x1[1] = bf2f(u1.x >> 16); x1[2] = bf2f(u1.y & 0xFFFF); x1[3] = bf2f(u1.y >> 16);
-      x1[4] = bf2f(u1.z & 0xFFFF); x1[5] = bf2f(u1.z >> 16); x1[6] = bf2f(u1.w & 0xFFFF); x1[7] = bf2f(u1.w >> 16);
+      x0[0] = bf2f(u0[i].x & 0xFFFF); x0[1] = bf2f(u0[i].x >> 16); x0[2] = bf2f(u0[i].y & 0xFFFF); x0[3] = bf2f(u0[i].y >> 16);
+      x0[4] = bf2f(u0[i].z & 0xFFFF); x0[5] = bf2f(u0[i].z >> 16); x0[6] = bf2f(u0[i].w & 0xFFFF); x0[7] = bf2f(u0[i].w >> 16);
+      x1[0] = bf2f(u1[i].x & 0xFFFF); x1[1] = bf2f(u1[i].x >> 16); x1[2] = bf2f(u1[i].y & 0xFFFF); x1[3] = bf2f(u1[i].y >> 16);
+      x1[4] = bf2f(u1[i].z & 0xFFFF); x1[5] = bf2f(u1[i].z >> 16); x1[6] = bf2f(u1[i].w & 0xFFFF); x1[7] = bf2f(u1[i].w >> 16);
+      if (!live) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x0[j] = x1[j] = 0.f;
+      }
 #pragma unroll
       for (int m = 0; m < MR; ++m) {
-        const float4 a0 = *reinterpret_cast<const float4*>(&sA[m * K + k]);
-        const float4 a1 = *reinterpret_cast<const float4*>(&sA[m * K + k + 4]);
+        const float4 a0 = *reinterpret_cast<const float4*>(&sA[m * K + kc]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&sA[m * K + kc + 4]);
         acc0[m] += a0.x * x0[0] + a0.y * x0[1] + a0.z * x0[2] + a0.w * x0[3] + a1.x * x0[4] + a1.y * x0[5] + a1.z * x0[6] + a1.w * x0[7];
         acc1[m] += a0.x * x1[0] + a0.y * x1[1] + a0.z * x1[2] + a0.w * x1[3] + a1.x * x1[4] + a1.y * x1[5] + a1.z * x1[6] + a1.w * x1[7];
       }
     }
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
-      const float v0 = wave_sum(acc0[m]), v1 = wave_sum(acc1[m]);
+      const float v0 = wave_sum_dpp(acc0[m]), v1 = wave_sum_dpp(acc1[m]);
       if (lane == 0 && m < M) {
-        float r0 = v0 + (bias ? bias[n0] : 0.f), r1 = v1 + (bias ? bias[n1] : 0.f);
+        float r0 = v0 + (bias ? bias[n0] : 0.f), r1 = v1 + (bias ? bias[min(n0 + 1, N - 1)] : 0.f);
         if (act_out == 1) { r0 = silu_f(r0); r1 = silu_f(r1); }
         else if (act_out == 2) { r0 = 1.0f / (1.0f + __expf(-r0)); r1 = 1.0f / (1.0f + __expf(-r1)); }
         out[(long)m * ldo + n0] = r0;
@@ -489,8 +517,9 @@ hipError_t launch_linear_rows(const float* a, int lda, const uint16_t* W, const 
 
 hipError_t launch_linear_rows_lds(const float* a, int lda, const float* tvals, int t_B, const uint16_t* W,
                                   const float* bias, float* out, int ldo, int M, int N, int K, int act_out, hipStream_t s) {
-  if (K % 8 != 0 || (a && lda % 4 != 0) || M < 1 || M > 16 || (size_t)16 * K * 4 > 96 * 1024) return hipErrorInvalidValue;
-  const int blocks = (N + 63) / 64;
+  if (K % 8 != 0 || K < 8 || K > 1536 || (a && lda % 4 != 0) || M < 1 || M > 16) return hipErrorInvalidValue;
+  const int cpw = N >= 16384 ? 6 : (N >= 4096 ? 4 : 2);      // columns per wave: all blocks co-resident on 256 CUs
+  const int blocks = (N + 4 * cpw - 1) / (4 * cpw);
 #define DF_LRL(MR)                                                                                                  \
   {                                                                                                                 \
     const size_t lds = (size_t)MR * K * 4;                                                                          \
@@ -502,7 +531,7 @@ hipError_t launch_linear_rows_lds(const float* a, int lda, const float* tvals, i
       attr = lds;                                                                                                   \
     }                                                                                                               \
     hipLaunchKernelGGL(linear_rows_lds_kernel<MR>, dim3(blocks), dim3(256), lds, s, a, lda, tvals, t_B, W, bias, out, ldo, \
-                       M, N, K, act_out);                                                                           \
+                       M, N, K, act_out, cpw);                                                                      \
   }
   if (M <= 4) DF_LRL(4)
   else if (M <= 8) DF_LRL(8)

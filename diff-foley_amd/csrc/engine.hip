@@ -405,6 +405,11 @@ struct Builder {
       sk = 1;
       while (blocks * sk < 160 && sk < 16 && gp.Cin / 64 / (sk * 2) >= 2) sk *= 2;
     }
+    if (!gemm_tile_valid(gp, o.tile, batch, sk)) {   // epilogue features narrow the tile set: 64x64, no split-K always runs
+      o.tile = TILE_64x64;
+      sk = 1;
+      if (!gemm_tile_valid(gp, o.tile, batch, sk)) fail("no valid tile for GEMM %s (%dx%dx%d)", tag, gp.M, gp.N, gp.K);
+    }
     gp.splitk = sk;
     if (sk > 1) {
       const size_t need = (size_t)sk * gp.M * gp.N * 4;
@@ -527,6 +532,7 @@ struct Builder {
     const float scale = 1.0f / sqrtf((float)D);
     bf16_t* a = groupnorm(x, NB, p + ".norm", 1e-6f, 0, nullptr);
     float* t0 = buf<float>((size_t)M * C);        // fp32 residual stream of the transformer block
+    F32 t0v{t0, M, C, C};
     bf16_t* xb = buf<bf16_t>((size_t)M * C);      // its operand-type copy (A operand of the LayerNorm-folded GEMMs)
     const int slots = C / 64;
     float2* st = buf<float2>((size_t)M * slots);  // per-row (sum, sumsq) partials per 64-column slot of t0
@@ -552,7 +558,25 @@ struct Builder {
     bf16_t* qk = buf<bf16_t>((size_t)M * 2 * C);
     const int ldvt = rup(T, 32);
     bf16_t* vt = buf<bf16_t>((size_t)NB * C * ldvt);
-    {
+    const bool fuse_v = (T % 4 == 0);           // the transposed store moves 4 tokens of one sample per lane
+    bf16_t* o_own = nullptr;
+    if (!fuse_v) {   // 1- or 2-token maps (8x8 / 8x16 latents at ds 8): LayerNorm kernel + separate K|Q and V^T GEMMs
+      layernorm(t0v, tb + ".norm1", a);
+      {
+        const bf16_t* w = c->w_stack(nm(tb + ".attn1.qk"), {nm(tb + ".attn1.to_q.weight"), nm(tb + ".attn1.to_k.weight")});
+        GemmParams g = gp_linear(a, M, C, w, 2 * C);
+        out_b16(g, qk, 2 * C);
+        gemm(g, 1, "st.qk");
+      }
+      {  // V^T[n] = Wv . a[n]^T  (batched: A = Wv shared, "W" operand = this sample's tokens)
+        GemmParams g = gp_linear(c->w_linear(nm(tb + ".attn1.to_v.weight")), C, C, a, T);
+        g.w_bs = (long)T * C;
+        out_b16(g, vt, ldvt);
+        g.c_bs = (long)C * ldvt;
+        gemm(g, NB, "st.vT");
+      }
+      o_own = buf<bf16_t>((size_t)M * C);
+    } else {
       const bf16_t* w;
       const float *cs, *bb;
       c->w_ln_stack(nm(tb + ".attn1.qkv"), nm(tb + ".norm1"),
@@ -564,7 +588,7 @@ struct Builder {
       g.vt = vt; g.vt_col0 = 2 * C; g.vt_T = T; g.ldvt = ldvt;
       gemm(g, 1, "st.qkv");
     }
-    bf16_t* o = a;                                 // GroupNorm output is dead after proj_in
+    bf16_t* o = o_own ? o_own : a;                 // GroupNorm output is dead after proj_in
     other("attn.self", [=](hipStream_t s, const RunArgs&) {
       return launch_attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, o, C, NB, heads, D, T, T, scale, s);
     });
@@ -631,6 +655,7 @@ struct Builder {
     pl->release(t0);
     pl->release(xb);
     pl->release(st);
+    pl->release(o_own);
   }
 
   // context -> per-ST K [NB*Tc][C] and V^T [NB][C][ldvt]
@@ -1674,6 +1699,7 @@ void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const
   for (size_t i = begin; i < end; ++i) {
     Op& o = pl->ops[i];
     hipError_t e;
+    (void)hipGetLastError();     // a stale launch-configuration error (e.g. a refused tuning candidate) is not this op's
     if (c->prof_on) {
       if (c->prof_used + 2 > c->prof_ev.size()) {
         hipEvent_t e0, e1;
@@ -1691,7 +1717,12 @@ void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const
     } else {
       e = o.fn(s, a);
     }
-    if (e != hipSuccess) fail("op %zu (%s) failed: %s", i, o.tag, hipGetErrorString(e));
+    if (e != hipSuccess) {
+      if (o.is_gemm)
+        fail("op %zu (%s: GEMM %dx%dx%d taps %d batch %d tile %d split-K %d) failed: %s", i, o.tag, o.gp.M, o.gp.N, o.gp.K,
+             o.gp.taps, o.batch, o.tile, o.gp.splitk, hipGetErrorString(e));
+      fail("op %zu (%s) failed: %s", i, o.tag, hipGetErrorString(e));
+    }
     if (c->prof_on) {
       HIPCHK(hipEventRecord(c->prof_ev[c->prof_used + 1], s));
       c->prof_fam.push_back(op_family(o));
@@ -1763,6 +1794,7 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
         o.gp.gm = ch.gm;
         o.gp.partial = pl->partial;
       }
+      tune_cache_save();     // DF_TUNE_CACHE may name a file this process has not written yet
       return;
     }
   }

@@ -10,6 +10,8 @@
 // fragment reads of a 16-lane group hit 16 distinct slots.  The DMA writes LDS linearly (wave base +
 // lane*16), so the swizzle is applied to the per-lane SOURCE chunk instead (rule: both sides or neither).
 // Out-of-range rows / conv padding use an out-of-bounds buffer offset: the hardware then writes zeros.
+#include <algorithm>
+
 #include "common.h"
 #include "gemm.h"
 
@@ -27,6 +29,16 @@ bool halo_patch(int H, int W, int BM, int* th, int* tw) {
   *th = h;
   *tw = w;
   return true;
+}
+
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: two quad butterflies and two row
+// rotations, all DPP modifiers on VALU adds -- no LDS-pipe traffic (ds_bpermute) in the epilogue.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));  // row_ror:8
+  return v;
 }
 
 __device__ __forceinline__ float epi_bias(const GemmParams& p, int row, int col, float v) {
@@ -226,33 +238,40 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
                          ? (31 - __builtin_clz(p.rows_per_sample)) : -1;
   // ---- fused QKV projection: the V columns leave transposed, V^T[sample][col][token], 4 tokens (8 B) per store
   if (p.vt && n0 >= p.vt_col0) {
-    constexpr int RG = BM / 4;               // groups of 4 consecutive rows (tokens)
+    constexpr int RG = BM / 4, CG = BN / 4;   // 4-row (token) groups x 4-column groups: a 4x4 block per thread step
     const int cv = p.N - p.vt_col0;
 #pragma unroll 2
-    for (int e = tid; e < BN * RG; e += NT) {
-      const int c = e / RG, r = (e - c * RG) * 4;
-      const int row = rowmap(r), col = n0 + c;
-      const int cc = min(col, p.N - 1);
-      float v[4];
+    for (int e = tid; e < CG * RG; e += NT) {
+      const int cg = e / RG, r = (e - cg * RG) * 4, c4 = cg * 4;   // lanes run along the tokens of one column group
+      const int row = rowmap(r), col = n0 + c4;
+      const int cc = min(col, p.N - 4);
+      float4 v[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = sC[(r + j) * LDC + c] * p.alpha;
+      for (int j = 0; j < 4; ++j) {
+        v[j] = *reinterpret_cast<const float4*>(&sC[(r + j) * LDC + c4]);
+        v[j].x *= p.alpha; v[j].y *= p.alpha; v[j].z *= p.alpha; v[j].w *= p.alpha;
+      }
       if (p.ln_stats) {
-        const float cs = p.ln_cs[cc];
+        const float4 cs = *reinterpret_cast<const float4*>(&p.ln_cs[cc]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float2 mr = sRow[r + j];
-          v[j] = mr.y * (v[j] - mr.x * cs);
+          v[j].x = mr.y * (v[j].x - mr.x * cs.x); v[j].y = mr.y * (v[j].y - mr.x * cs.y);
+          v[j].z = mr.y * (v[j].z - mr.x * cs.z); v[j].w = mr.y * (v[j].w - mr.x * cs.w);
         }
       }
       if (has_bias) {
-        const float b = p.bias[cc];
+        const float4 b = *reinterpret_cast<const float4*>(&p.bias[cc]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += b;
+        for (int j = 0; j < 4; ++j) { v[j].x += b.x; v[j].y += b.y; v[j].z += b.z; v[j].w += b.w; }
       }
       if (row < p.M && col < p.N) {           // M % 4 == 0 and vt_T % 4 == 0: the 4 rows belong to one sample
         const int smp = row / p.vt_T, t = row - smp * p.vt_T;
-        *reinterpret_cast<uint2*>(p.vt + ((long)smp * cv + (col - p.vt_col0)) * p.ldvt + t) =
-            make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        bf16_t* dst = p.vt + ((long)smp * cv + (col - p.vt_col0)) * p.ldvt + t;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf2(v[0].x, v[1].x), pack_bf2(v[2].x, v[3].x));
+        *reinterpret_cast<uint2*>(dst + p.ldvt) = make_uint2(pack_bf2(v[0].y, v[1].y), pack_bf2(v[2].y, v[3].y));
+        *reinterpret_cast<uint2*>(dst + 2 * p.ldvt) = make_uint2(pack_bf2(v[0].z, v[1].z), pack_bf2(v[2].z, v[3].z));
+        *reinterpret_cast<uint2*>(dst + 3 * p.ldvt) = make_uint2(pack_bf2(v[0].w, v[1].w), pack_bf2(v[2].w, v[3].w));
       }
     }
     return;
@@ -292,12 +311,8 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
     }                                                                                                               \
     const bool ok = row < p.M && col < p.N;                                                                         \
     if ((FL) & 4) {                                                                                                 \
-      float s1 = ok ? (v.x + v.y) + (v.z + v.w) : 0.f;                                                              \
-      float s2 = ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;                                      \
-      _Pragma("unroll") for (int o = 1; o < 16; o <<= 1) {                                                          \
-        s1 += __shfl_xor(s1, o);                                                                                    \
-        s2 += __shfl_xor(s2, o);                                                                                    \
-      }                                                                                                             \
+      const float s1 = row16_sum(ok ? (v.x + v.y) + (v.z + v.w) : 0.f);                                             \
+      const float s2 = row16_sum(ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f);                     \
       if (ok && (tid & 15) == 0) p.stats[(long)row * p.stats_slots + (col >> 6)] = make_float2(s1, s2);             \
     }                                                                                                               \
     if (ok) {                                                                                                       \
@@ -364,6 +379,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   int mt_, nt_;
   tile_of(lid, nbm, nbn, p.gm, mt_, nt_);
   const int m0 = mt_ * BM, n0 = nt_ * BN;
+
+  // LayerNorm folded into this GEMM: the producer's per-row (sum, sumsq) partials of this tile's rows are one
+  // contiguous run of BM * ln_slots float2; every thread requests its share FIRST (<= LNPT 8-byte loads, in flight
+  // under the operand prologue), parks it in LDS behind the ring, and thread r < BM folds row r's slots to
+  // (mean, rstd) after the main loop.  Nothing on the critical path waits for these loads.
+  constexpr int LNPT = 5;
+  constexpr size_t RING_B = (size_t)(BM + BN) * BK * 2 * NST, STAGE_B = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8;
+  constexpr size_t SCR_OFF = RING_B > STAGE_B ? RING_B : STAGE_B;
+  const bool ln_on = MODE == 0 && p.ln_stats != nullptr && p.splitk <= 1;
+  float2 lnv[LNPT];
+  if (ln_on) {
+    const int cnt = min(BM, p.M - m0) * p.ln_slots;
+    const float2* sp = p.ln_stats + (long)m0 * p.ln_slots;
+#pragma unroll
+    for (int i = 0; i < LNPT; ++i) lnv[i] = sp[min(tid + i * NT, cnt - 1)];
+  }
 
   int z = blockIdx.z;
   const int nk = p.K / BK;
@@ -546,20 +577,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   if (NST > 3) DF_DMA(2, 2);
   if (NST > 4) DF_DMA(3, 3);
 
-  // LayerNorm folded into this GEMM: thread r < BM reduces the producer's per-slot partials of tile row r to
-  // (mean, rstd) while the first operand tiles are in flight; the pair is parked in LDS by the epilogue.
-  float2 ln_mr = make_float2(0.f, 1.f);
-  if (MODE == 0 && p.ln_stats && p.splitk <= 1 && tid < BM) {
-    const float2* sp = p.ln_stats + (long)min(m0 + tid, p.M - 1) * p.ln_slots;
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < p.ln_slots; ++i) {
-      const float2 v = sp[i];
-      s1 += v.x;
-      s2 += v.y;
-    }
-    const float inv = 1.0f / (float)p.ln_C;
-    const float mean = s1 * inv;
-    ln_mr = make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
+  if (ln_on) {
+    float2* sLn = reinterpret_cast<float2*>(smem + SCR_OFF);
+#pragma unroll
+    for (int i = 0; i < LNPT; ++i)
+      if (tid + i * NT < BM * p.ln_slots) sLn[tid + i * NT] = lnv[i];
   }
 
   int it = 0;
@@ -581,6 +603,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     }
   }
   wait_vmcnt<0>();                     // dead-slot requests of the last iterations must land before LDS is released
+
+  float2 ln_mr = make_float2(0.f, 1.f);
+  if (ln_on && tid < BM) {             // the slots were parked before the first K-step barrier: visible to every thread
+    const float2* sLn = reinterpret_cast<const float2*>(smem + SCR_OFF) + tid * p.ln_slots;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < p.ln_slots; ++i) {
+      s1 += sLn[i].x;
+      s2 += sLn[i].y;
+    }
+    const float inv = 1.0f / (float)p.ln_C;
+    const float mean = s1 * inv;
+    ln_mr = make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
+  }
 
   // ---- epilogue
   if (p.dbg & 2) {   // tools: keep the accumulators alive, store nothing
@@ -950,13 +985,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
     if (p.stats) {           // N % 64 == 0: 16 consecutive threads hold one 64-column slot of one row
-      float s1 = (v.x + v.y) + (v.z + v.w);
-      float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        s1 += __shfl_xor(s1, o);
-        s2 += __shfl_xor(s2, o);
-      }
+      const float s1 = row16_sum((v.x + v.y) + (v.z + v.w));
+      const float s2 = row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
       if ((threadIdx.x & 15) == 0) p.stats[(long)row * p.stats_slots + (col >> 6)] = make_float2(s1, s2);
     }
     const long idx = (long)row * p.ldc + col;
@@ -973,11 +1003,15 @@ hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   constexpr size_t ring = (size_t)(BM + BN) * BK * 2 * NST;                    // operand ring
   constexpr size_t stage = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8;          // epilogue tile + (mean, rstd) row table
-  const size_t lds = ring > stage ? ring : stage;
+  const size_t base = ring > stage ? ring : stage;
+  // LayerNorm-folded GEMMs park the producer's row partials behind the ring: BM * ln_slots float2
+  const size_t lds = base + ((MODE == 0 && p.ln_stats && p.splitk <= 1) ? (size_t)BM * p.ln_slots * 8 : 0);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
+    const size_t cap = std::min<size_t>(160 * 1024, base + (size_t)5 * 64 * WGM * WGN * 8);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -1026,6 +1060,13 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
     gemm_tile_dims(tile, &bm_, &bn_);
     if (p.vt && (splitk > 1 || batch > 1 || p.vt_col0 % bn_ != 0)) return false;   // transposed-V tiles are whole tiles
     if (p.ln_stats && (batch > 1 || (p.geglu && splitk > 1))) return false;
+    if (p.ln_stats && splitk <= 1) {     // row partials: <= 5 float2 per thread, parked in LDS behind the ring
+      static const int nst[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0};
+      const int threads = (tile == TILE_128x256 || tile == TILE_256x128) ? 512 : 256;
+      const size_t ring = (size_t)(bm_ + bn_) * 128 * nst[tile], stage = (size_t)bm_ * (bn_ + 4) * 4 + (size_t)bm_ * 8;
+      if (bm_ * p.ln_slots > 5 * threads) return false;
+      if (std::max(ring, stage) + (size_t)bm_ * p.ln_slots * 8 > 160 * 1024) return false;
+    }
     if (p.stats && batch > 1) return false;
     return splitk == 1 || (batch <= 1 && nk / splitk >= 2);
   }
@@ -1047,8 +1088,8 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
   const int zdim = (p.splitk > 1) ? p.splitk : (batch > 0 ? batch : 1);
   if (p.ln_stats || p.stats || p.vt) {     // these epilogues exist in the vectorised paths only
     const bool vec = !p.store_nchw && (p.N & 63) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.ld_rowbias & 3) == 0 &&
-                     (p.ld_aux & 3) == 0 && (p.M & 3) == 0;
-    if (!vec || (p.vt && ((p.vt_T & 3) != 0 || (p.ldvt & 3) != 0 || p.taps != 1))) return hipErrorInvalidValue;
+                     (p.ld_aux & 3) == 0;
+    if (!vec || (p.vt && ((p.M & 3) != 0 || (p.vt_T & 3) != 0 || (p.ldvt & 3) != 0 || p.taps != 1))) return hipErrorInvalidValue;
     if (p.ln_stats && p.taps != 1) return hipErrorInvalidValue;
   }
   hipError_t e;
