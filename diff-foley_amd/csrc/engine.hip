@@ -522,10 +522,112 @@ struct Builder {
     pl->release(a2);
   }
 
+  // The same block as separate launches -- LayerNorm kernels, K|Q and V^T projections apart (env DF_NO_LNFOLD=1):
+  // kept as the A/B reference for the folded plan below.
+  void spatial_transformer_unfused(const F32& x, const F32& out, int NB, int T, const std::string& p, int heads,
+                           const bf16_t* ctxK, const bf16_t* ctxVt, int Tc, int ldvtc) {
+    const int C = x.C, M = x.rows, D = C / heads;
+    if (!attention_supported(D)) fail("unsupported attention head dim %d", D);
+    const std::string tb = p + ".transformer_blocks.0";
+    const float scale = 1.0f / sqrtf((float)D);
+    bf16_t* a = groupnorm(x, NB, p + ".norm", 1e-6f, 0, nullptr);
+    float* t0 = buf<float>((size_t)M * C);
+    F32 t0v{t0, M, C, C};
+    {
+      GemmParams g = gp_linear(a, M, C, c->w_linear(nm(p + ".proj_in.weight")), C);
+      out_f32(g, t0, C);
+      g.bias = c->f32(nm(p + ".proj_in.bias"));
+      gemm(g, 1, "st.proj_in");
+    }
+    // ---- self attention
+    layernorm(t0v, tb + ".norm1", a);
+    bf16_t* qk = buf<bf16_t>((size_t)M * 2 * C);
+    {
+      const bf16_t* w = c->w_stack(nm(tb + ".attn1.qk"), {nm(tb + ".attn1.to_q.weight"), nm(tb + ".attn1.to_k.weight")});
+      GemmParams g = gp_linear(a, M, C, w, 2 * C);
+      out_b16(g, qk, 2 * C);
+      gemm(g, 1, "st.qk");
+    }
+    const int ldvt = rup(T, 32);
+    bf16_t* vt = buf<bf16_t>((size_t)NB * C * ldvt);
+    {  // V^T[n] = Wv . a[n]^T  (batched: A = Wv shared, "W" operand = this sample's tokens)
+      GemmParams g = gp_linear(c->w_linear(nm(tb + ".attn1.to_v.weight")), C, C, a, T);
+      g.w_bs = (long)T * C;
+      out_b16(g, vt, ldvt);
+      g.c_bs = (long)C * ldvt;
+      gemm(g, NB, "st.vT");
+    }
+    bf16_t* o = buf<bf16_t>((size_t)M * C);
+    other("attn.self", [=](hipStream_t s, const RunArgs&) {
+      return launch_attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, o, C, NB, heads, D, T, T, scale, s);
+    });
+    {
+      GemmParams g = gp_linear(o, M, C, c->w_linear(nm(tb + ".attn1.to_out.0.weight")), C);
+      out_f32(g, t0, C);
+      g.bias = c->f32(nm(tb + ".attn1.to_out.0.bias"));
+      g.res = t0; g.ldr = C;
+      gemm(g, 1, "st.attn1.out");
+    }
+    // ---- cross attention (K / V^T of the context were computed by set_context)
+    layernorm(t0v, tb + ".norm2", a);
+    bf16_t* q2 = qk;
+    {
+      GemmParams g = gp_linear(a, M, C, c->w_linear(nm(tb + ".attn2.to_q.weight")), C);
+      out_b16(g, q2, C);
+      gemm(g, 1, "st.q2");
+    }
+    other("attn.cross", [=](hipStream_t s, const RunArgs&) {
+      return launch_attention(q2, C, ctxK, C, ctxVt, ldvtc, o, C, NB, heads, D, T, Tc, scale, s);
+    });
+    {
+      GemmParams g = gp_linear(o, M, C, c->w_linear(nm(tb + ".attn2.to_out.0.weight")), C);
+      out_f32(g, t0, C);
+      g.bias = c->f32(nm(tb + ".attn2.to_out.0.bias"));
+      g.res = t0; g.ldr = C;
+      gemm(g, 1, "st.attn2.out");
+    }
+    pl->release(qk);
+    pl->release(vt);
+    pl->release(o);
+    // ---- GEGLU feed-forward
+    layernorm(t0v, tb + ".norm3", a);
+    bf16_t* gl = buf<bf16_t>((size_t)M * 4 * C);
+    {
+      const bf16_t* w;
+      const float* b;
+      c->w_geglu(nm(tb + ".ff.net.0.proj"), &w, &b);
+      GemmParams g = gp_linear(a, M, C, w, 8 * C);
+      out_b16(g, gl, 4 * C);
+      g.bias = b;
+      g.geglu = 1;
+      gemm(g, 1, "st.ff1");
+    }
+    {
+      GemmParams g = gp_linear(gl, M, 4 * C, c->w_linear(nm(tb + ".ff.net.2.weight")), C);
+      out_b16(g, a, C);            // transformer output, consumed only by proj_out
+      g.bias = c->f32(nm(tb + ".ff.net.2.bias"));
+      g.res = t0; g.ldr = C;
+      gemm(g, 1, "st.ff2");
+    }
+    pl->release(gl);
+    {
+      GemmParams g = gp_linear(a, M, C, c->w_linear(nm(p + ".proj_out.weight")), C);
+      out_f32(g, out.p, out.ld);
+      g.bias = c->f32(nm(p + ".proj_out.bias"));
+      g.res = x.p; g.ldr = x.ld;
+      attach_aux(g, M, C);
+      gemm(g, 1, "st.proj_out");
+    }
+    pl->release(a);
+    pl->release(t0);
+  }
+
   // SpatialTransformer (attention_openai.py:250-261) with one BasicTransformerBlock (:211-215).
   // ctxK [NB*Tc][C] bf16 and ctxVt [NB][C][ldvt] bf16 are the hoisted cross-attention K / V^T.
   void spatial_transformer(const F32& x, const F32& out, int NB, int T, const std::string& p, int heads,
                            const bf16_t* ctxK, const bf16_t* ctxVt, int Tc, int ldvtc) {
+    static const bool no_fold = getenv("DF_NO_LNFOLD") && atoi(getenv("DF_NO_LNFOLD"));
+    if (no_fold) return spatial_transformer_unfused(x, out, NB, T, p, heads, ctxK, ctxVt, Tc, ldvtc);
     const int C = x.C, M = x.rows, D = C / heads;
     if (!attention_supported(D)) fail("unsupported attention head dim %d", D);
     const std::string tb = p + ".transformer_blocks.0";
@@ -838,18 +940,14 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
     const bf16_t* w = c->w_stack(pre + "#embw", wn);
     const float* bb = c->b_stack(pre + "#embb", bn);
     if (N <= 16) {
-      // three weight-streaming launches: [timestep embedding (CFG duplication folded in) -> Linear -> SiLU],
-      // [Linear -> SiLU] (emb is only ever consumed through SiLU: emb_layers = SiLU -> Linear), and the stacked
-      // emb_layers projections of all ResBlocks
+      // three weight-streaming launches: [timestep embedding (CFG duplication folded in) -> Linear -> SiLU] (LDS-staged
+      // activations), [Linear -> SiLU] (emb is only ever consumed through SiLU: emb_layers = SiLU -> Linear), and the
+      // stacked emb_layers projections of all ResBlocks (register kernel: measured faster for the 52 MB stream)
       b.other("t.mlp0", [=](hipStream_t s, const RunArgs& a) {
         return launch_linear_rows_lds(nullptr, 0, a.t, B_ext, w0, b0, e1, temb, N, temb, mc, 1, s);
       });
-      b.other("t.mlp2", [=](hipStream_t s, const RunArgs&) {
-        return launch_linear_rows_lds(e1, temb, nullptr, 0, w2, b2, semb, temb, N, temb, temb, 1, s);
-      });
-      b.other("t.embproj", [=](hipStream_t s, const RunArgs&) {
-        return launch_linear_rows_lds(semb, temb, nullptr, 0, w, bb, E, etot, N, etot, temb, 0, s);
-      });
+      b.other("t.mlp2", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(e1, temb, w2, b2, semb, temb, N, temb, temb, 1, s); });
+      b.other("t.embproj", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(semb, temb, w, bb, E, etot, N, etot, temb, 0, s); });
     } else {
       float* tbuf = b.buf<float>(N);
       b.other("t.copy", [=](hipStream_t s, const RunArgs& a) {

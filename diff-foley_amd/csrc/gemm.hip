@@ -280,7 +280,8 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
   // bit 2: per-row partial statistics of the stored value (16 lanes = one 64-column slot of one row).  Every variant
   // is instantiated separately so the UNet's plain epilogues keep their lean loop body.
 #define DF_EPI_LOOP(FL)                                                                                             \
-  _Pragma("unroll 4") for (int e = tid; e < BM * CPR; e += NT) {                                                    \
+  _Pragma("unroll 4") for (int ei = 0; ei < BM * CPR / NT; ++ei) {                                                  \
+    const int e = tid + ei * NT;                                                                                    \
     const int r = e / CPR, c4 = (e - r * CPR) * 4;                                                                  \
     const int row = rowmap(r), col = n0 + c4;                                                                       \
     const int rc = min(row, p.M - 1), cc = min(col, p.N - 4);                                                       \
@@ -547,11 +548,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
       DSTB[j] = *reinterpret_cast<const bf16x8*>(fB[j][S] + (ST) * BN * BK * 2);                \
   }
-#define DF_MMA(SRCA, SRCB)                                                                        \
+#define DF_MMA(SRCA, SRCB, ACC)                                                                   \
   {                                                                                             \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
       _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
-        acc[i][j] = DF_MFMA_32x32x16(SRCA[i], SRCB[j], acc[i][j]); \
+        ACC[i][j] = DF_MFMA_32x32x16(SRCA[i], SRCB[j], ACC[i][j]); \
   }
   // One K tile out of ring slot ST; refills the slot of the previous tile ((ST + NST - 1) % NST).
 #define DF_ITER(ST)                                                                               \
@@ -562,12 +563,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     DF_FRAG(a0, b0, 0, ST);                                                                     \
     DF_DMA(it + NST - 1, ((ST) + NST - 1) % NST);                                               \
     DF_FRAG(a1, b1, 1, ST);                                                                     \
-    DF_MMA(a0, b0);                                                                             \
+    DF_MMA(a0, b0, acc);                                                                        \
     DF_FRAG(a0, b0, 2, ST);                                                                     \
-    DF_MMA(a1, b1);                                                                             \
+    DF_MMA(a1, b1, acc);                                                                        \
     DF_FRAG(a1, b1, 3, ST);                                                                     \
-    DF_MMA(a0, b0);                                                                             \
-    DF_MMA(a1, b1);                                                                             \
+    DF_MMA(a0, b0, acc);                                                                        \
+    DF_MMA(a1, b1, acc);                                                                        \
     ++it;                                                                                       \
   }
 

@@ -102,6 +102,8 @@ def lib(precision=None):
                                "(there is no CPU/torch fallback for the sampling path)")
         L = C.CDLL(path)
         for name, args in _SIGS.items():
+            if os.environ.get("DF_LIB_OVERRIDE") and name.startswith("df_test_") and not hasattr(L, name):
+                continue                      # A/B against an older build that predates a unit-test entry point
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = C.c_int
