@@ -12,903 +12,16 @@
 // Out-of-range rows / conv padding use an out-of-bounds buffer offset: the hardware then writes zeros.
 #include <algorithm>
 
-#include "common.h"
-#include "gemm.h"
+#include "gemm_impl.h"
+
+
+hipError_t launch_gemm_m0a(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
+hipError_t launch_gemm_m0b(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
+hipError_t launch_gemm_m1(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
+hipError_t launch_gemm_m2(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
+hipError_t launch_gemm_halo(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 
 namespace {
-
-constexpr int BK = 64;
-
-// Spatial patch (th x tw output pixels) owned by one block of a halo kernel with BM rows.
-bool halo_patch(int H, int W, int BM, int* th, int* tw) {
-  const int w = (W % 16 == 0) ? 16 : W;
-  if (w <= 0 || BM % w != 0) return false;
-  int h = BM / w;
-  if (h > H) h = H;
-  if (h <= 0 || H % h != 0 || BM % (h * w) != 0) return false;
-  *th = h;
-  *tw = w;
-  return true;
-}
-
-// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: two quad butterflies and two row
-// rotations, all DPP modifiers on VALU adds -- no LDS-pipe traffic (ds_bpermute) in the epilogue.
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));  // row_ror:4
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));  // row_ror:8
-  return v;
-}
-
-__device__ __forceinline__ float epi_bias(const GemmParams& p, int row, int col, float v) {
-  v *= p.alpha;
-  if (p.bias) v += p.bias[col];
-  if (p.rowbias) {
-    const int ri = (p.rowbias_mode == 1) ? (row / p.rows_per_sample) : (row % p.rows_per_sample);
-    v += p.rowbias[(long)ri * p.ld_rowbias + col];
-  }
-  return v;
-}
-
-__device__ __forceinline__ void epi_store(const GemmParams& p, int z, int row, int col, int nout, float v) {
-  if (p.relu) v = fmaxf(v, 0.f);
-  if (p.aux) p.aux[(long)row * p.ld_aux + col] = f2bf(v);
-  long idx;
-  if (p.store_nchw) {
-    const int b = row / p.hw_out, px = row - b * p.hw_out;
-    idx = ((long)b * nout + col) * p.hw_out + px;
-  } else {
-    idx = (long)row * p.ldc + col;
-  }
-  idx += (long)z * p.c_bs;
-  if (p.out_bf16)
-    reinterpret_cast<bf16_t*>(p.C)[idx] = f2bf(v);
-  else
-    reinterpret_cast<float*>(p.C)[idx] = v;
-}
-
-__device__ __forceinline__ void epi_out(const GemmParams& p, int z, int row, int col, float v) {
-  if (p.res) v += p.res[(long)z * p.res_bs + (long)row * p.ldr + col];
-  epi_store(p, z, row, col, p.geglu ? (p.N >> 1) : p.N, v);
-}
-
-// Epilogue of one 32-row band of a wavefront's tile: TN 32x32 accumulator tiles side by side.
-// C/D layout of the 32x32 MFMA: col = lane&31, row r -> (r&3) + 8*(r>>2) + 4*(lane>>5).  rowv[r] is the OUTPUT row
-// (NHWC pixel index) of accumulator register r, or >= p.M when that row does not exist.  All loads of a tile
-// (bias, per-sample bias, residual) are issued unconditionally from clamped addresses before any use, so they
-// overlap instead of serialising behind per-element branches.
-template <int TN>
-__device__ __forceinline__ void epilogue_band(const GemmParams& p, int z, int batch, const int (&rowv)[16],
-                                              f32x16 (&acc)[TN], int col0, int l31) {
-  if (p.splitk > 1) {
-    float* part = p.partial + (long)z * p.M * p.N;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = col0 + j * 32 + l31;
-      if (col >= p.N) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (rowv[r] < p.M) part[(long)rowv[r] * p.N + col] = acc[j][r];
-    }
-    return;
-  }
-  const bool has_bias = p.bias != nullptr, has_rb = p.rowbias != nullptr, has_res = p.res != nullptr;
-  const int nout = p.geglu ? (p.N >> 1) : p.N;
-  int rowc[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) rowc[r] = min(rowv[r], p.M - 1);
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    if (p.geglu) {
-      if constexpr (TN % 2 == 0) {
-        if (j & 1) continue;
-        const int xcol = col0 + j * 32 + l31;
-        const int xc = min(xcol, p.N - 33);
-        const int ocol = (xcol >> 6) * 32 + (xcol & 63);
-        const float bx = has_bias ? p.bias[xc] : 0.f, bg = has_bias ? p.bias[xc + 32] : 0.f;
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float xv = acc[j][r] * p.alpha + bx;
-          const float gv = acc[j + 1][r] * p.alpha + bg;
-          v[r] = xv * gelu_erf(gv);
-        }
-        if (has_res) {
-          float rr[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            rr[r] = p.res[(long)batch * p.res_bs + (long)rowc[r] * p.ldr + min(ocol, nout - 1)];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += rr[r];
-        }
-        if (xcol < p.N) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (rowv[r] < p.M) epi_store(p, batch, rowv[r], ocol, nout, v[r]);
-        }
-      }
-      continue;
-    }
-    const int col = col0 + j * 32 + l31;
-    const int cc = min(col, p.N - 1);
-    const float b0 = has_bias ? p.bias[cc] : 0.f;
-    float v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc[j][r] * p.alpha + b0;
-    if (has_rb) {
-      float rb_[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ri = (p.rowbias_mode == 1) ? (rowc[r] / p.rows_per_sample) : (rowc[r] % p.rows_per_sample);
-        rb_[r] = p.rowbias[(long)ri * p.ld_rowbias + cc];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] += rb_[r];
-    }
-    if (has_res) {
-      float rr[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rr[r] = p.res[(long)batch * p.res_bs + (long)rowc[r] * p.ldr + cc];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] += rr[r];
-    }
-    if (col < p.N) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (rowv[r] < p.M) epi_store(p, batch, rowv[r], col, nout, v[r]);
-    }
-  }
-}
-
-// Block-level epilogue through LDS: the accumulators of the whole BM x BN tile are parked in LDS as fp32 (row
-// stride BN+4 floats keeps the 16-B reads conflict-free), then every thread re-reads 4 consecutive columns of one
-// row, applies alpha / bias / per-sample bias / residual / GEGLU on float4s and issues ONE 16-byte (fp32) or 8-byte
-// (bf16) store: rows leave the CU as full 128..512-B contiguous runs instead of 4-B-per-lane column slivers.
-// ROWMAP(r) gives the output row (NHWC pixel index) of tile row r, or >= p.M when the row does not exist.
-// Requires N % 4 == 0, ldc % 4 == 0 and row-major output (the caller falls back to epilogue_band otherwise).
-template <int BM, int BN, int NT, int TM, int TN, class RowMap>
-__device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int batch, float* sC,
-                                               f32x16 (&acc)[TM][TN], int wrow0, int wcol0, int n0, int tid,
-                                               RowMap rowmap, float2 ln_mr = make_float2(0.f, 1.f)) {
-  constexpr int LDC = BN + 4;
-  const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
-  float2* sRow = reinterpret_cast<float2*>(sC + BM * LDC);   // (mean, rstd) of tile row r (LayerNorm-folded GEMMs)
-  __builtin_amdgcn_s_barrier();            // every wave is done reading the operand ring
-  if (p.ln_stats && tid < BM) sRow[tid] = ln_mr;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        sC[(wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wcol0 + j * 32 + l31] = acc[i][j][r];
-  __syncthreads();
-  const bool has_bias = p.bias != nullptr, has_rb = p.rowbias != nullptr, has_res = p.res != nullptr;
-  if (p.splitk > 1) {
-    float* part = p.partial + (long)z * p.M * p.N;
-    constexpr int CPR = BN / 4;
-#pragma unroll 4
-    for (int e = tid; e < BM * CPR; e += NT) {
-      const int r = e / CPR, c4 = (e - r * CPR) * 4;
-      const int row = rowmap(r), col = n0 + c4;
-      const float4 v = *reinterpret_cast<const float4*>(&sC[r * LDC + c4]);
-      if (row < p.M && col < p.N) *reinterpret_cast<float4*>(&part[(long)row * p.N + col]) = v;
-    }
-    return;
-  }
-  if (p.geglu) {
-    constexpr int CPR = BN / 8;              // float4 chunks of OUTPUT columns per row (output width BN/2)
-    const int nout = p.N >> 1;
-#pragma unroll 2
-    for (int e = tid; e < BM * CPR; e += NT) {
-      const int r = e / CPR, oc = (e - r * CPR) * 4;           // output column within the tile
-      const int xc = (oc >> 5) * 64 + (oc & 31);               // packed x column within the tile; gate at +32
-      const int row = rowmap(r), ocol = (n0 >> 1) + oc;
-      const int gx = min(n0 + xc, p.N - 36);
-      float4 x = *reinterpret_cast<const float4*>(&sC[r * LDC + xc]);
-      float4 g = *reinterpret_cast<const float4*>(&sC[r * LDC + xc + 32]);
-      if (p.ln_stats) {       // LayerNorm folded in: rstd * (acc - mean * colsum(gamma W))
-        const float2 mr = sRow[r];
-        const float4 cx = *reinterpret_cast<const float4*>(&p.ln_cs[gx]);
-        const float4 cg = *reinterpret_cast<const float4*>(&p.ln_cs[gx + 32]);
-        x.x = mr.y * (x.x - mr.x * cx.x); x.y = mr.y * (x.y - mr.x * cx.y); x.z = mr.y * (x.z - mr.x * cx.z); x.w = mr.y * (x.w - mr.x * cx.w);
-        g.x = mr.y * (g.x - mr.x * cg.x); g.y = mr.y * (g.y - mr.x * cg.y); g.z = mr.y * (g.z - mr.x * cg.z); g.w = mr.y * (g.w - mr.x * cg.w);
-      }
-      if (has_bias) {
-        const float4 bx = *reinterpret_cast<const float4*>(&p.bias[gx]);
-        const float4 bg = *reinterpret_cast<const float4*>(&p.bias[gx + 32]);
-        x.x = x.x * p.alpha + bx.x; x.y = x.y * p.alpha + bx.y; x.z = x.z * p.alpha + bx.z; x.w = x.w * p.alpha + bx.w;
-        g.x = g.x * p.alpha + bg.x; g.y = g.y * p.alpha + bg.y; g.z = g.z * p.alpha + bg.z; g.w = g.w * p.alpha + bg.w;
-      }
-      float4 v = make_float4(x.x * gelu_erf(g.x), x.y * gelu_erf(g.y), x.z * gelu_erf(g.z), x.w * gelu_erf(g.w));
-      if (row < p.M && ocol < nout) {
-        const long idx = (long)batch * p.c_bs + (long)row * p.ldc + ocol;
-        if (p.out_bf16)
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-        else
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;
-      }
-    }
-    return;
-  }
-  constexpr int CPR = BN / 4;
-  // rows_per_sample is a power of two for every latent this model is used with: shift instead of a 25-instruction divide
-  const int rps_sh = (has_rb && p.rows_per_sample > 0 && (p.rows_per_sample & (p.rows_per_sample - 1)) == 0)
-                         ? (31 - __builtin_clz(p.rows_per_sample)) : -1;
-  // ---- fused QKV projection: the V columns leave transposed, V^T[sample][col][token], 4 tokens (8 B) per store
-  if (p.vt && n0 >= p.vt_col0) {
-    constexpr int RG = BM / 4, CG = BN / 4;   // 4-row (token) groups x 4-column groups: a 4x4 block per thread step
-    const int cv = p.N - p.vt_col0;
-#pragma unroll 2
-    for (int e = tid; e < CG * RG; e += NT) {
-      const int cg = e / RG, r = (e - cg * RG) * 4, c4 = cg * 4;   // lanes run along the tokens of one column group
-      const int row = rowmap(r), col = n0 + c4;
-      const int cc = min(col, p.N - 4);
-      float4 v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = *reinterpret_cast<const float4*>(&sC[(r + j) * LDC + c4]);
-        v[j].x *= p.alpha; v[j].y *= p.alpha; v[j].z *= p.alpha; v[j].w *= p.alpha;
-      }
-      if (p.ln_stats) {
-        const float4 cs = *reinterpret_cast<const float4*>(&p.ln_cs[cc]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float2 mr = sRow[r + j];
-          v[j].x = mr.y * (v[j].x - mr.x * cs.x); v[j].y = mr.y * (v[j].y - mr.x * cs.y);
-          v[j].z = mr.y * (v[j].z - mr.x * cs.z); v[j].w = mr.y * (v[j].w - mr.x * cs.w);
-        }
-      }
-      if (has_bias) {
-        const float4 b = *reinterpret_cast<const float4*>(&p.bias[cc]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j].x += b.x; v[j].y += b.y; v[j].z += b.z; v[j].w += b.w; }
-      }
-      if (row < p.M && col < p.N) {           // M % 4 == 0 and vt_T % 4 == 0: the 4 rows belong to one sample
-        const int smp = row / p.vt_T, t = row - smp * p.vt_T;
-        bf16_t* dst = p.vt + ((long)smp * cv + (col - p.vt_col0)) * p.ldvt + t;
-        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf2(v[0].x, v[1].x), pack_bf2(v[2].x, v[3].x));
-        *reinterpret_cast<uint2*>(dst + p.ldvt) = make_uint2(pack_bf2(v[0].y, v[1].y), pack_bf2(v[2].y, v[3].y));
-        *reinterpret_cast<uint2*>(dst + 2 * p.ldvt) = make_uint2(pack_bf2(v[0].z, v[1].z), pack_bf2(v[2].z, v[3].z));
-        *reinterpret_cast<uint2*>(dst + 3 * p.ldvt) = make_uint2(pack_bf2(v[0].w, v[1].w), pack_bf2(v[2].w, v[3].w));
-      }
-    }
-    return;
-  }
-  // FL bit 0: ReLU and/or a second (operand-type) copy of the stored value; bit 1: LayerNorm folded into this GEMM;
-  // bit 2: per-row partial statistics of the stored value (16 lanes = one 64-column slot of one row).  Every variant
-  // is instantiated separately so the UNet's plain epilogues keep their lean loop body.
-#define DF_EPI_LOOP(FL)                                                                                             \
-  _Pragma("unroll 4") for (int ei = 0; ei < BM * CPR / NT; ++ei) {                                                  \
-    const int e = tid + ei * NT;                                                                                    \
-    const int r = e / CPR, c4 = (e - r * CPR) * 4;                                                                  \
-    const int row = rowmap(r), col = n0 + c4;                                                                       \
-    const int rc = min(row, p.M - 1), cc = min(col, p.N - 4);                                                       \
-    float4 v = *reinterpret_cast<const float4*>(&sC[r * LDC + c4]);                                                 \
-    v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;                                                 \
-    if ((FL) & 2) {                                                                                                 \
-      const float2 mr = sRow[r];                                                                                    \
-      const float4 cs = *reinterpret_cast<const float4*>(&p.ln_cs[cc]);                                            \
-      v.x = mr.y * (v.x - mr.x * cs.x); v.y = mr.y * (v.y - mr.x * cs.y);                                           \
-      v.z = mr.y * (v.z - mr.x * cs.z); v.w = mr.y * (v.w - mr.x * cs.w);                                           \
-    }                                                                                                               \
-    if (has_bias) {                                                                                                 \
-      const float4 b = *reinterpret_cast<const float4*>(&p.bias[cc]);                                               \
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
-    }                                                                                                               \
-    if (has_rb) {                                                                                                   \
-      const int ri = (rps_sh >= 0) ? ((p.rowbias_mode == 1) ? (rc >> rps_sh) : (rc & (p.rows_per_sample - 1)))      \
-                                   : ((p.rowbias_mode == 1) ? (rc / p.rows_per_sample) : (rc % p.rows_per_sample)); \
-      const float4 b = *reinterpret_cast<const float4*>(&p.rowbias[(long)ri * p.ld_rowbias + cc]);                  \
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
-    }                                                                                                               \
-    if (has_res) {                                                                                                  \
-      const float4 b = *reinterpret_cast<const float4*>(&p.res[(long)batch * p.res_bs + (long)rc * p.ldr + cc]);    \
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
-    }                                                                                                               \
-    if (((FL) & 1) && p.relu) {                                                                                     \
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);                   \
-    }                                                                                                               \
-    const bool ok = row < p.M && col < p.N;                                                                         \
-    if ((FL) & 4) {                                                                                                 \
-      const float s1 = row16_sum(ok ? (v.x + v.y) + (v.z + v.w) : 0.f);                                             \
-      const float s2 = row16_sum(ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f);                     \
-      if (ok && (tid & 15) == 0) p.stats[(long)row * p.stats_slots + (col >> 6)] = make_float2(s1, s2);             \
-    }                                                                                                               \
-    if (ok) {                                                                                                       \
-      const long idx = (long)batch * p.c_bs + (long)row * p.ldc + col;                                              \
-      if (p.out_bf16)                                                                                               \
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
-      else                                                                                                          \
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;                                        \
-      if (((FL) & 1) && p.aux)                                                                                      \
-        *reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
-    }                                                                                                               \
-  }
-  if (p.stats) DF_EPI_LOOP(5)
-  else if (p.ln_stats) DF_EPI_LOOP(2)
-  else if (p.relu || p.aux) DF_EPI_LOOP(1)
-  else DF_EPI_LOOP(0)
-#undef DF_EPI_LOOP
-}
-
-template <int N_>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
-}
-
-// Logical tile id -> (M tile, N tile): M-fastest inside row groups of `gm` M-tiles (gm <= 0: one group = plain M-fastest).
-__device__ __forceinline__ void tile_of(int lid, int nbm, int nbn, int gm, int& mt, int& nt) {
-  if (gm <= 0 || gm >= nbm) {
-    mt = lid % nbm;
-    nt = lid / nbm;
-    return;
-  }
-  const int per = gm * nbn, grp = lid / per, rem = lid - grp * per;
-  const int rows = min(gm, nbm - grp * gm);
-  nt = rem / rows;
-  mt = grp * gm + (rem - nt * rows);
-}
-
-template <int BM, int BN, int WGM, int WGN, int NST, int MODE>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)   // host pass only needs the launch stub (LDS-DMA builtins do not parse there)
-  constexpr int WTM = BM / WGM, WTN = BN / WGN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int NT = 64 * WGM * WGN;          // threads (4 or 8 wavefronts)
-  constexpr int RPP = NT / 8;                 // LDS rows filled per DMA pass of the block
-  constexpr int AP = BM / RPP, BP = BN / RPP;
-  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the DMA pass");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(NST >= 2 && NST <= 5, "ring depth");
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WGN, wn = wid % WGN;
-  const int l31 = lane & 31, lh = lane >> 5;
-
-  // ---- tile id with XCD-aware remap (block b runs on XCD b%8; give each XCD a contiguous range)
-  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const int nblk = nbm * nbn;
-  int lid;
-  {
-    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  // each XCD owns a contiguous range of logical tiles, walked M-fastest inside row groups of p.gm M-tiles: the walk
-  // decides which A / W panels the XCD's 4 MB L2 gets to share (a miss is served by MALL at ~1/5 of the L2 rate)
-  int mt_, nt_;
-  tile_of(lid, nbm, nbn, p.gm, mt_, nt_);
-  const int m0 = mt_ * BM, n0 = nt_ * BN;
-
-  // LayerNorm folded into this GEMM: the producer's per-row (sum, sumsq) partials of this tile's rows are one
-  // contiguous run of BM * ln_slots float2; every thread requests its share FIRST (<= LNPT 8-byte loads, in flight
-  // under the operand prologue), parks it in LDS behind the ring, and thread r < BM folds row r's slots to
-  // (mean, rstd) after the main loop.  Nothing on the critical path waits for these loads.
-  constexpr int LNPT = 5;
-  constexpr size_t RING_B = (size_t)(BM + BN) * BK * 2 * NST, STAGE_B = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8;
-  constexpr size_t SCR_OFF = RING_B > STAGE_B ? RING_B : STAGE_B;
-  const bool ln_on = MODE == 0 && p.ln_stats != nullptr && p.splitk <= 1;
-  float2 lnv[LNPT];
-  if (ln_on) {
-    const int cnt = min(BM, p.M - m0) * p.ln_slots;
-    const float2* sp = p.ln_stats + (long)m0 * p.ln_slots;
-#pragma unroll
-    for (int i = 0; i < LNPT; ++i) lnv[i] = sp[min(tid + i * NT, cnt - 1)];
-  }
-
-  int z = blockIdx.z;
-  const int nk = p.K / BK;
-  int kt0 = 0, kt1 = nk, batch = z;
-  if (p.splitk > 1) {
-    const int per = (nk + p.splitk - 1) / p.splitk;
-    kt0 = z * per;
-    kt1 = min(nk, kt0 + per);
-    batch = 0;
-  }
-  const bf16_t* Ab = p.A + (long)batch * p.a_bs;
-  const bf16_t* Wb = p.W + (long)batch * p.w_bs;
-
-  // ---- per-thread staging coordinates: chunk c (8 bf16 = 16 B) of rows (tid>>3) + 32*i.
-  // Operands are fetched with raw buffer loads: an out-of-range byte offset (OOB) makes the hardware return
-  // zeros, so zero padding / ragged tiles need no branches.  Everything the inner loop needs is hoisted: a DMA
-  // request costs one v_add (+ one v_cndmask for conv padding), an LDS fragment read costs no VALU at all
-  // (per-k-step byte offsets are precomputed, the ring slot is a compile-time immediate).
-  constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)p.w_bytes, 0x00020000);
-  const int r0 = tid >> 3;
-  const int c8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;   // source chunk that lands in LDS slot (tid&7) of row r0+32i
-  unsigned a_off[AP];   // MODE 0: byte offset of (row, chunk); MODE 1: byte offset of the centre-tap pixel;
-                        // MODE 2: pixel index base n*H*W
-  unsigned a_msk[AP];   // MODE 1: bit t set <=> tap t of this row reads inside the image
-  int a_iy[AP], a_ix[AP];
-  const int UH = p.H << p.ups, UW = p.Wd << p.ups;
-#pragma unroll
-  for (int i = 0; i < AP; ++i) {
-    const int m = m0 + r0 + RPP * i;
-    const bool mv = m < p.M;
-    a_msk[i] = 0;
-    a_iy[i] = a_ix[i] = 0;
-    if (MODE == 0) {
-      a_off[i] = mv ? (unsigned)(((long)m * p.lda + c8) * 2) : OOB;
-    } else {
-      const int ohw = p.OH * p.OW;
-      const int nb = m / ohw, rem = m - nb * ohw;
-      const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      if (MODE == 1) {
-        a_off[i] = (unsigned)((((long)(nb * p.H + oy) * p.Wd + ox) * p.lda + c8) * 2);
-        unsigned msk = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int y = oy + t / 3 - 1, x = ox + t % 3 - 1;
-          if (mv && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd) msk |= 1u << t;
-        }
-        a_msk[i] = msk;
-      } else {
-        a_off[i] = (unsigned)(nb * p.H * p.Wd);
-        a_iy[i] = mv ? oy * p.stride - 1 : -(1 << 20);
-        a_ix[i] = ox * p.stride - 1;
-      }
-    }
-  }
-  unsigned b_off[BP];
-#pragma unroll
-  for (int i = 0; i < BP; ++i) {
-    const int n = n0 + r0 + RPP * i;
-    b_off[i] = (n < p.N) ? (unsigned)(((long)n * p.K + c8) * 2) : OOB;
-  }
-
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  constexpr int LPT = AP + BP;                  // DMA instructions per wave per K tile
-  const int nt = (p.dbg & 4) ? 0 : kt1 - kt0;
-
-  // Request tile T (relative to kt0) into ring slot ST (compile-time): every wave writes 8 rows x 128 B (1 KiB,
-  // lane-linear) per instruction.  Tiles past the end are requested out of bounds (zeros land in a dead slot), so
-  // the DMA count per iteration is constant.
-  int d_tap = 0, d_cc = 0;       // conv: (tap, channel offset) of the NEXT tile to request, advanced incrementally
-  if (MODE != 0) {
-    const int k0 = kt0 * BK;
-    d_tap = k0 / p.Cin;
-    d_cc = k0 - d_tap * p.Cin;
-  }
-  char* const dmaA = smem + wid * (8 * BK * 2);
-  char* const dmaB = smem + NST * BM * BK * 2 + wid * (8 * BK * 2);
-#define DF_DMA(T, ST)                                                                             \
-  {                                                                                             \
-    const bool live = (T) < nt;                                                                 \
-    const unsigned k0b = (p.dbg & 1) ? 0u : (unsigned)(kt0 + (T)) * (BK * 2);                         \
-    if (MODE == 0) {                                                                            \
-      const unsigned kb = live ? k0b : OOB;                                                     \
-      _Pragma("unroll") for (int i = 0; i < AP; ++i)                                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
-                                                 a_off[i] + kb, 0, 0, 0);                       \
-    } else if (MODE == 1) {                                                                     \
-      const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                    \
-      const unsigned delta = (unsigned)((((ky - 1) * p.Wd + (kx - 1)) * p.lda + d_cc) * 2);     \
-      const unsigned bit = live ? (1u << d_tap) : 0u;                                           \
-      _Pragma("unroll") for (int i = 0; i < AP; ++i)                                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
-                                                 (a_msk[i] & bit) ? a_off[i] + delta : OOB, 0, 0, 0); \
-    } else {                                                                                    \
-      const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                    \
-      _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                          \
-        const int uy = a_iy[i] + ky, ux = a_ix[i] + kx;                                         \
-        const bool v = live && ((unsigned)uy < (unsigned)UH) && ((unsigned)ux < (unsigned)UW) && \
-                       !(p.zstuff && ((uy | ux) & 1));                                          \
-        const int sy = uy >> p.ups, sx = ux >> p.ups;                                           \
-        const unsigned off = ((a_off[i] + (unsigned)(sy * p.Wd + sx)) * (unsigned)p.lda + (unsigned)(d_cc + c8)) * 2u; \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
-                                                 v ? off : OOB, 0, 0, 0);                       \
-      }                                                                                         \
-    }                                                                                           \
-    if (MODE != 0) {                                                                            \
-      d_cc += BK;                                                                               \
-      if (d_cc == p.Cin) {                                                                      \
-        d_cc = 0;                                                                               \
-        ++d_tap;                                                                                \
-      }                                                                                         \
-    }                                                                                           \
-    {                                                                                           \
-      const unsigned kb = live ? k0b : OOB;                                                     \
-      _Pragma("unroll") for (int i = 0; i < BP; ++i)                                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(dmaB + ((ST) * BN + i * RPP) * (BK * 2)), 16, \
-                                                 b_off[i] + kb, 0, 0, 0);                       \
-    }                                                                                           \
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- LDS fragment byte offsets (slot 0) for the 4 k-steps of a tile: loop invariant
-  const char* fA[TM][4];
-  const char* fB[TN][4];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int row = wm * WTM + i * 32 + l31;
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) fA[i][s2] = smem + (row * BK + (((2 * s2 + lh) ^ ((row >> 1) & 7)) << 3)) * 2;
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int row = wn * WTN + j * 32 + l31;
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
-      fB[j][s2] = smem + NST * BM * BK * 2 + (row * BK + (((2 * s2 + lh) ^ ((row >> 1) & 7)) << 3)) * 2;
-  }
-#define DF_FRAG(DSTA, DSTB, S, ST)                                                                \
-  {                                                                                             \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
-      DSTA[i] = *reinterpret_cast<const bf16x8*>(fA[i][S] + (ST) * BM * BK * 2);                \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
-      DSTB[j] = *reinterpret_cast<const bf16x8*>(fB[j][S] + (ST) * BN * BK * 2);                \
-  }
-#define DF_MMA(SRCA, SRCB, ACC)                                                                   \
-  {                                                                                             \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
-        ACC[i][j] = DF_MFMA_32x32x16(SRCA[i], SRCB[j], ACC[i][j]); \
-  }
-  // One K tile out of ring slot ST; refills the slot of the previous tile ((ST + NST - 1) % NST).
-#define DF_ITER(ST)                                                                               \
-  {                                                                                             \
-    wait_vmcnt<(NST - 2) * LPT>();   /* tile `it` landed: <= NST-2 younger tiles of this wave in flight */ \
-    __builtin_amdgcn_s_barrier();    /* all parts of tile `it` visible; everyone is done with tile it-1 */  \
-    bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];                                                      \
-    DF_FRAG(a0, b0, 0, ST);                                                                     \
-    DF_DMA(it + NST - 1, ((ST) + NST - 1) % NST);                                               \
-    DF_FRAG(a1, b1, 1, ST);                                                                     \
-    DF_MMA(a0, b0, acc);                                                                        \
-    DF_FRAG(a0, b0, 2, ST);                                                                     \
-    DF_MMA(a1, b1, acc);                                                                        \
-    DF_FRAG(a1, b1, 3, ST);                                                                     \
-    DF_MMA(a0, b0, acc);                                                                        \
-    DF_MMA(a1, b1, acc);                                                                        \
-    ++it;                                                                                       \
-  }
-
-  // ---- prologue: fill NST-1 ring slots
-  DF_DMA(0, 0);
-  if (NST > 2) DF_DMA(1, 1);
-  if (NST > 3) DF_DMA(2, 2);
-  if (NST > 4) DF_DMA(3, 3);
-
-  if (ln_on) {
-    float2* sLn = reinterpret_cast<float2*>(smem + SCR_OFF);
-#pragma unroll
-    for (int i = 0; i < LNPT; ++i)
-      if (tid + i * NT < BM * p.ln_slots) sLn[tid + i * NT] = lnv[i];
-  }
-
-  int it = 0;
-  while (it < nt) {
-    DF_ITER(0);
-    if (it >= nt) break;
-    DF_ITER(1);
-    if (NST > 2) {
-      if (it >= nt) break;
-      DF_ITER(2 % NST);
-    }
-    if (NST > 3) {
-      if (it >= nt) break;
-      DF_ITER(3 % NST);
-    }
-    if (NST > 4) {
-      if (it >= nt) break;
-      DF_ITER(4 % NST);
-    }
-  }
-  wait_vmcnt<0>();                     // dead-slot requests of the last iterations must land before LDS is released
-
-  float2 ln_mr = make_float2(0.f, 1.f);
-  if (ln_on && tid < BM) {             // the slots were parked before the first K-step barrier: visible to every thread
-    const float2* sLn = reinterpret_cast<const float2*>(smem + SCR_OFF) + tid * p.ln_slots;
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < p.ln_slots; ++i) {
-      s1 += sLn[i].x;
-      s2 += sLn[i].y;
-    }
-    const float inv = 1.0f / (float)p.ln_C;
-    const float mean = s1 * inv;
-    ln_mr = make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
-  }
-
-  // ---- epilogue
-  if (p.dbg & 2) {   // tools: keep the accumulators alive, store nothing
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
-  }
-  const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
-                      (p.ld_rowbias & 3) == 0 && (p.res_bs & 3) == 0 && (p.c_bs & 3) == 0 && (p.ld_aux & 3) == 0;
-  if (vec_ok) {
-    epilogue_block<BM, BN, NT, TM, TN>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid,
-                                        [&](int r) { return m0 + r; }, ln_mr);
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    int rowv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rowv[r] = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    epilogue_band<TN>(p, z, batch, rowv, acc[i], n0 + wn * WTN, l31);
-  }
-#endif
-}
-
-
-// Runtime-valued vmcnt wait (the immediate must be a literal): small switch over the values that occur.
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-  switch (n) {
-    case 1: wait_vmcnt<1>(); break;
-    case 2: wait_vmcnt<2>(); break;
-    case 3: wait_vmcnt<3>(); break;
-    case 4: wait_vmcnt<4>(); break;
-    case 5: wait_vmcnt<5>(); break;
-    case 6: wait_vmcnt<6>(); break;
-    case 7: wait_vmcnt<7>(); break;
-    case 8: wait_vmcnt<8>(); break;
-    case 9: wait_vmcnt<9>(); break;
-    case 10: wait_vmcnt<10>(); break;
-    case 11: wait_vmcnt<11>(); break;
-    case 12: wait_vmcnt<12>(); break;
-    case 13: wait_vmcnt<13>(); break;
-    case 14: wait_vmcnt<14>(); break;
-    case 15: wait_vmcnt<15>(); break;
-    case 16: wait_vmcnt<16>(); break;
-    case 17: wait_vmcnt<17>(); break;
-    case 18: wait_vmcnt<18>(); break;
-    case 19: wait_vmcnt<19>(); break;
-    case 20: wait_vmcnt<20>(); break;
-    case 21: wait_vmcnt<21>(); break;
-    case 22: wait_vmcnt<22>(); break;
-    case 23: wait_vmcnt<23>(); break;
-    case 24: wait_vmcnt<24>(); break;
-    case 25: wait_vmcnt<25>(); break;
-    case 26: wait_vmcnt<26>(); break;
-    case 27: wait_vmcnt<27>(); break;
-    case 28: wait_vmcnt<28>(); break;
-    case 29: wait_vmcnt<29>(); break;
-    case 30: wait_vmcnt<30>(); break;
-    case 31: wait_vmcnt<31>(); break;
-    case 32: wait_vmcnt<32>(); break;
-    case 33: wait_vmcnt<33>(); break;
-    case 34: wait_vmcnt<34>(); break;
-    case 35: wait_vmcnt<35>(); break;
-    case 36: wait_vmcnt<36>(); break;
-    case 37: wait_vmcnt<37>(); break;
-    case 38: wait_vmcnt<38>(); break;
-    case 39: wait_vmcnt<39>(); break;
-    case 40: wait_vmcnt<40>(); break;
-    default: wait_vmcnt<0>(); break;   // conservative: full drain
-  }
-}
-
-// ===============================================================================================================
-// conv3x3 (stride 1, pad 1) with an LDS-staged HALO tile.
-//
-// The implicit-GEMM kernel above re-fetches the A operand once per tap (9x).  On this chip the L2->LDS fill rate of
-// a CU (~20 B/clk measured) is what bounds these GEMMs, so here a block owns PB spatial patches of TH x TW output
-// pixels (BM = PB*TH*TW), stages their (TH+2) x (TW+2) input halo for a 64-channel slice ONCE, and runs all 9 taps
-// out of it: per slice the block fetches HR*128 B of activations + 9 * BN*128 B of weights for 9*2*BM*BN*64 FLOP.
-// Pipeline: A halo double-buffered (slice c+1 requested during slice c), weights in a 4-deep ring requested 3 taps
-// ahead; the 9 taps are unrolled so every wait is a compile-time `vmcnt` (loads retire in issue order):
-//   wait for W(c,t):  younger = W(+1) .. W(+NSTW-2) and, for t in 1..NSTW-1, the A(c+1) request issued at tap 0.
-// Zero padding and ragged edges come from out-of-bounds buffer offsets (hardware writes zeros to LDS).
-template <int BM, int BN, int WGM, int WGN, int NSTW>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NT = 64 * WGM * WGN;          // threads
-  constexpr int RPP = NT / 8;                 // LDS rows written per DMA pass of the whole block
-  constexpr int WTM = BM / WGM, WTN = BN / WGN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int WPASS = (BN + RPP - 1) / RPP; // weight passes per tap
-  static_assert(NSTW >= 3 && NSTW <= 8, "weight ring depth");
-  constexpr unsigned OOB = 0x80000000u;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WGN, wn = wid % WGN;
-  const int l31 = lane & 31, lh = lane >> 5;
-
-  const int TH = p.th, TW = p.tw, HWp = (TH + 2) * (TW + 2), PPX = TH * TW;
-  const int PB = BM / PPX;                      // patches per block
-  const int HR = PB * HWp;                      // halo rows
-  const int APASS = (HR + RPP - 1) / RPP;       // halo passes (block-uniform)
-  const int HRP = APASS * RPP;
-  bf16_t* sA = reinterpret_cast<bf16_t*>(smem);                 // [2][HRP][64]
-  bf16_t* sW = sA + 2 * HRP * BK;                               // [NSTW][max(BN,RPP)][64]
-  constexpr int WROWS = WPASS * RPP;
-
-  const int npx = p.Wd / TW, npy = p.H / TH;    // patches per image
-  const int npatch = (p.M / PPX);               // total patches (M = NB*H*W)
-  const int nbm = (npatch + PB - 1) / PB, nbn = (p.N + BN - 1) / BN;
-  const int nblk = nbm * nbn;
-  int lid;
-  {
-    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int mt, nt_;
-  tile_of(lid, nbm, nbn, p.gm, mt, nt_);
-  const int n0 = nt_ * BN;
-
-  const int z = blockIdx.z;
-  const int nchunk = p.Cin / BK;
-  int c0 = 0, c1 = nchunk;
-  if (p.splitk > 1) {
-    const int per = (nchunk + p.splitk - 1) / p.splitk;
-    c0 = z * per;
-    c1 = min(nchunk, c0 + per);
-  }
-  const int nc = max(c1 - c0, 0);
-
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
-
-  // ---- staging coordinates.  Thread (r0 = tid>>3, slot = tid&7) fills LDS slot `slot` of rows r0 + RPP*i with the
-  // source chunk slot ^ ((row>>1)&7)   (RPP is a multiple of 16, so the swizzle term is the same for every pass).
-  const int r0 = tid >> 3;
-  const int c8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;
-  constexpr int MAXAP = 12;
-  unsigned a_off[MAXAP];
-#pragma unroll
-  for (int i = 0; i < MAXAP; ++i) {
-    const int hr = r0 + RPP * i;                 // halo row
-    unsigned off = OOB;
-    if (i < APASS && hr < HR) {
-      const int pi = hr / HWp, rem = hr - pi * HWp;
-      const int hy = rem / (TW + 2), hx = rem - hy * (TW + 2);
-      const int g = mt * PB + pi;                // global patch id
-      if (g < npatch) {
-        const int n = g / (npy * npx), gr = g - n * (npy * npx);
-        const int y = (gr / npx) * TH + hy - 1, x = (gr % npx) * TW + hx - 1;
-        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd)
-          off = (unsigned)((((long)(n * p.H + y) * p.Wd + x) * p.lda + c8) * 2);
-      }
-    }
-    a_off[i] = off;
-  }
-  unsigned w_off[WPASS];
-#pragma unroll
-  for (int i = 0; i < WPASS; ++i) {
-    const int n = n0 + r0 + RPP * i;
-    w_off[i] = (n < p.N && r0 + RPP * i < BN) ? (unsigned)(((long)n * p.K + c8) * 2) : OOB;
-  }
-
-  // ---- MFMA row -> halo row of tap (0,0) and output pixel index
-  int hb[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int r = wm * WTM + i * 32 + l31;
-    const int pi = r / PPX, rem = r - pi * PPX;
-    const int y = rem / TW, x = rem - y * TW;
-    hb[i] = pi * HWp + y * (TW + 2) + x;
-  }
-  int fb[TN], sb[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int row = wn * WTN + j * 32 + l31;
-    fb[j] = row * BK;
-    sb[j] = (row >> 1) & 7;
-  }
-
-  // DMA helpers -------------------------------------------------------------------------------------------------
-  // A halo of channel slice C (absolute slice index) into buffer BUF
-#define DF_HALO_A(C, BUF)                                                                         \
-  {                                                                                             \
-    bf16_t* a_ = sA + (BUF) * HRP * BK + wid * (8 * BK);                                        \
-    const bool live = (C) < c1;                                                                 \
-    const unsigned cb = (unsigned)(C) * (BK * 2);                                               \
-    _Pragma("unroll") for (int i = 0; i < MAXAP; ++i)                                           \
-      if (i < APASS)                                                                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a_ + i * RPP * BK), 16,         \
-                                                 (live && a_off[i] != OOB) ? a_off[i] + cb : OOB, 0, 0, 0); \
-  }
-  // weights of iteration IT (= slice*9 + tap, relative to c0) into ring slot ST
-#define DF_HALO_W(IT, ST)                                                                         \
-  {                                                                                             \
-    bf16_t* w_ = sW + (ST) * WROWS * BK + wid * (8 * BK);                                       \
-    const int cs_ = (IT) / 9, tp_ = (IT) - cs_ * 9;                                             \
-    const bool live = cs_ < nc;                                                                 \
-    const unsigned kb = (unsigned)(tp_ * p.Cin + (c0 + cs_) * BK) * 2u;                         \
-    _Pragma("unroll") for (int i = 0; i < WPASS; ++i)                                           \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(w_ + i * RPP * BK), 16,           \
-                                               (live && w_off[i] != OOB) ? w_off[i] + kb : OOB, 0, 0, 0); \
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- prologue: A(0), W(0 .. NSTW-2)
-  DF_HALO_A(c0, 0);
-#pragma unroll
-  for (int t = 0; t < NSTW - 1; ++t) DF_HALO_W(t, t);
-
-  // One tap.  VM = loads of this wave allowed to be still in flight when W(c,t) must have landed.
-#define DF_TAP(T)                                                                        \
-  {                                                                                             \
-    if ((T) >= 1 && (T) <= NSTW - 1) wait_vmcnt_dyn((NSTW - 2) * WPASS + APASS);               \
-    else wait_vmcnt<(NSTW - 2) * WPASS>();                                                      \
-    __builtin_amdgcn_s_barrier();                                                               \
-    const int it_ = cs * 9 + (T);                                                               \
-    const bf16_t* a = sA + (cs & 1) * HRP * BK;                                                 \
-    const bf16_t* b = sW + (it_ % NSTW) * WROWS * BK;                                           \
-    DF_HALO_W(it_ + NSTW - 1, (it_ + NSTW - 1) % NSTW);                                         \
-    if ((T) == 0) DF_HALO_A(c0 + cs + 1, (cs + 1) & 1);                                         \
-    constexpr int dy_ = (T) / 3, dx_ = (T) - dy_ * 3;                                           \
-    int ha_[TM], sa_[TM];                                                                       \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                            \
-      const int hr = hb[i] + dy_ * (TW + 2) + dx_;                                              \
-      ha_[i] = hr * BK;                                                                         \
-      sa_[i] = (hr >> 1) & 7;                                                                   \
-    }                                                                                           \
-    _Pragma("unroll") for (int s = 0; s < BK / 16; ++s) {                                       \
-      bf16x8 af[TM], bfr[TN];                                                                   \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
-        af[i] = *reinterpret_cast<const bf16x8*>(a + ha_[i] + (((2 * s + lh) ^ sa_[i]) << 3));  \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
-        bfr[j] = *reinterpret_cast<const bf16x8*>(b + fb[j] + (((2 * s + lh) ^ sb[j]) << 3));   \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
-          acc[i][j] = DF_MFMA_32x32x16(af[i], bfr[j], acc[i][j]); \
-    }                                                                                           \
-  }
-
-  for (int cs = 0; cs < nc; ++cs) {
-    DF_TAP(0)
-    DF_TAP(1)
-    DF_TAP(2)
-    DF_TAP(3)
-    DF_TAP(4)
-    DF_TAP(5)
-    DF_TAP(6)
-    DF_TAP(7)
-    DF_TAP(8)
-  }
-  wait_vmcnt<0>();
-
-  // ---- epilogue: tile row -> NHWC pixel index of its output pixel.  Five integer divisions per row: computed once per
-  // row into a BM-entry LDS table behind the operand ring instead of once per 4-column chunk of the epilogue loop.
-  auto rowmap_calc = [&](int rr) {
-    const int pi = rr / PPX, rem = rr - pi * PPX;
-    const int y = rem / TW, x = rem - y * TW;
-    const int g = mt * PB + pi;
-    const int n = g / (npy * npx), gr = g - n * (npy * npx);
-    return (g < npatch) ? (n * p.H + (gr / npx) * TH + y) * p.Wd + (gr % npx) * TW + x : p.M;
-  };
-  int* srow = reinterpret_cast<int*>(smem + p.halo_ring_bytes);
-  for (int rr = tid; rr < BM; rr += NT) srow[rr] = rowmap_calc(rr);
-  __syncthreads();
-  auto rowmap = [&](int rr) { return srow[rr]; };
-  const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
-                      (p.ld_rowbias & 3) == 0 && (p.ld_aux & 3) == 0;
-  if (vec_ok) {
-    epilogue_block<BM, BN, NT, TM, TN>(p, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap);
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    int rowv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rowv[r] = rowmap(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
-    epilogue_band<TN>(p, z, 0, rowv, acc[i], n0 + wn * WTN, l31);
-  }
-#endif
-}
 
 // Sums the split-K partial slabs and applies the same epilogue.  One thread per output element (scalar fallback:
 // GEGLU, NCHW stores, unaligned leading dimensions).
@@ -999,57 +112,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, int MODE>
-hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
-  const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  constexpr size_t ring = (size_t)(BM + BN) * BK * 2 * NST;                    // operand ring
-  constexpr size_t stage = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8;          // epilogue tile + (mean, rstd) row table
-  const size_t base = ring > stage ? ring : stage;
-  // LayerNorm-folded GEMMs park the producer's row partials behind the ring: BM * ln_slots float2
-  const size_t lds = base + ((MODE == 0 && p.ln_stats && p.splitk <= 1) ? (size_t)BM * p.ln_slots * 8 : 0);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const size_t cap = std::min<size_t>(160 * 1024, base + (size_t)5 * 64 * WGM * WGN * 8);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE>), dim3(nbm * nbn, 1, zdim), dim3(64 * WGM * WGN), lds, stream, p);
-  return hipGetLastError();
-}
-
-
-template <int BM, int BN, int WGM, int WGN, int NSTW>
-hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
-  constexpr int NT = 64 * WGM * WGN, RPP = NT / 8;
-  GemmParams p = pin;
-  if (!halo_patch(p.H, p.Wd, BM, &p.th, &p.tw)) return hipErrorInvalidValue;
-  const int ppx = p.th * p.tw;
-  if (ppx <= 0 || BM % ppx != 0 || p.H % p.th != 0 || p.Wd % p.tw != 0 || p.stride != 1 || p.ups != 0 || p.taps != 9)
-    return hipErrorInvalidValue;
-  const int PB = BM / ppx, HR = PB * (p.th + 2) * (p.tw + 2);
-  const int APASS = (HR + RPP - 1) / RPP;
-  if (APASS > 12) return hipErrorInvalidValue;
-  constexpr int WPASS = (BN + RPP - 1) / RPP;
-  const size_t ring = ((size_t)2 * APASS * RPP + (size_t)NSTW * WPASS * RPP) * BK * 2;
-  const size_t lds = ring + (size_t)BM * 4;          // + the epilogue's row table
-  p.halo_ring_bytes = (int)ring;
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static size_t attr = 0;
-  if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WGM, WGN, NSTW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr = lds;
-  }
-  const int npatch = p.M / ppx;
-  const int nbm = (npatch + PB - 1) / PB, nbn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WGM, WGN, NSTW>), dim3(nbm * nbn, 1, zdim), dim3(NT), lds, stream, p);
-  return hipGetLastError();
-}
-
 }  // namespace
 
 bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
@@ -1069,8 +131,10 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
       if (std::max(ring, stage) + (size_t)bm_ * p.ln_slots * 8 > 160 * 1024) return false;
     }
     if (p.stats && batch > 1) return false;
+    if (splitk > 1 && (p.N & 3) != 0) return false;          // partial slabs are written and reduced as float4
     return splitk == 1 || (batch <= 1 && nk / splitk >= 2);
   }
+  if (splitk > 1 && (p.N & 3) != 0) return false;
   if (p.taps != 9 || p.stride != 1 || p.ups != 0 || p.geglu || batch > 1) return false;
   int bm, bn, th, tw;
   gemm_tile_dims(tile, &bm, &bn);
@@ -1093,36 +157,26 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
     if (!vec || (p.vt && ((p.M & 3) != 0 || (p.vt_T & 3) != 0 || (p.ldvt & 3) != 0 || p.taps != 1))) return hipErrorInvalidValue;
     if (p.ln_stats && p.taps != 1) return hipErrorInvalidValue;
   }
+  // epilogue specialisation (gemm_impl.h): the kernel carries only the code it runs
+  const bool vec = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.ld_rowbias & 3) == 0 &&
+                   (p.res_bs & 3) == 0 && (p.c_bs & 3) == 0 && (p.ld_aux & 3) == 0;
+  int epi;
+  if (p.splitk > 1) epi = EPI_SPLITK;
+  else if (p.geglu) epi = EPI_GEGLU;
+  else if (p.ln_stats || p.vt) epi = EPI_LNC;
+  else if (p.stats) epi = EPI_PROD;
+  else if (!vec || p.relu || p.aux || p.alpha != 1.f) epi = EPI_ANY;
+  else epi = EPI_LEAN;
+  if ((epi == EPI_GEGLU || epi == EPI_LNC || epi == EPI_PROD) && (p.taps != 1 || p.alpha != 1.f || p.relu || !vec))
+    return hipErrorInvalidValue;
+  if (epi == EPI_LNC && (!p.ln_stats || p.aux)) return hipErrorInvalidValue;
   hipError_t e;
   // MODE 0: linear / 1x1;  1: 3x3 stride 1 (tap offsets are linear, 2 VALU per request);  2: 3x3 stride 2 / upsampled
   const int mode = (p.taps != 9) ? 0 : ((p.stride == 1 && !p.ups) ? 1 : 2);
-#define DF_CASE(T, BM, BN, WGM, WGN, NST)                                                              \
-  case T:                                                                                             \
-    e = mode == 0 ? launch_cfg<BM, BN, WGM, WGN, NST, 0>(p, zdim, stream)                             \
-                  : (mode == 1 ? launch_cfg<BM, BN, WGM, WGN, NST, 1>(p, zdim, stream)                \
-                               : launch_cfg<BM, BN, WGM, WGN, NST, 2>(p, zdim, stream));              \
-    break;
-  switch (tile_cfg) {
-    DF_CASE(TILE_128x128, 128, 128, 2, 2, 4)
-    DF_CASE(TILE_128x64, 128, 64, 2, 2, 5)
-    DF_CASE(TILE_64x128, 64, 128, 2, 2, 5)
-    DF_CASE(TILE_64x64, 64, 64, 2, 2, 4)
-    DF_CASE(TILE_32x128, 32, 128, 1, 4, 4)
-    DF_CASE(TILE_128x256, 128, 256, 2, 4, 3)
-    DF_CASE(TILE_256x128, 256, 128, 4, 2, 3)
-    // double-buffered variants: 2-5 blocks per CU instead of 1-2, for short-K layers (K = 320 is only 5 tiles)
-    DF_CASE(TILE_128x128_S, 128, 128, 2, 2, 2)
-    DF_CASE(TILE_128x64_S, 128, 64, 2, 2, 2)
-    DF_CASE(TILE_64x128_S, 64, 128, 2, 2, 2)
-    DF_CASE(TILE_64x64_S, 64, 64, 2, 2, 2)
-    DF_CASE(TILE_32x128_S, 32, 128, 1, 4, 2)
-    case TILE_HALO_128x64: e = launch_halo<128, 64, 2, 2, 4>(p, zdim, stream); break;
-    case TILE_HALO_256x64: e = launch_halo<256, 64, 4, 2, 4>(p, zdim, stream); break;
-    case TILE_HALO_128x128: e = launch_halo<128, 128, 2, 2, 4>(p, zdim, stream); break;
-    case TILE_HALO_128x64_D: e = launch_halo<128, 64, 2, 2, 8>(p, zdim, stream); break;
-    case TILE_HALO_256x64_D: e = launch_halo<256, 64, 4, 2, 8>(p, zdim, stream); break;
-    default: return hipErrorInvalidValue;
-  }
+  if (gemm_tile_is_halo(tile_cfg)) e = launch_gemm_halo(tile_cfg, epi, p, zdim, stream);
+  else if (mode == 0) e = (tile_cfg <= TILE_256x128) ? launch_gemm_m0a(tile_cfg, epi, p, zdim, stream) : launch_gemm_m0b(tile_cfg, epi, p, zdim, stream);
+  else if (mode == 1) e = launch_gemm_m1(tile_cfg, epi, p, zdim, stream);
+  else e = launch_gemm_m2(tile_cfg, epi, p, zdim, stream);
   if (e != hipSuccess) return e;
   if (p.splitk > 1) {
     const bool vec = !p.geglu && !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
