@@ -142,6 +142,12 @@ def _dev_f32(t, device):
     return t
 
 
+def _want_dim(what, got, want):
+    """The C ABI takes raw pointers: a tensor with the wrong feature width would be read out of bounds, not rejected."""
+    if want is not None and int(got) != int(want):
+        raise RuntimeError(f"{what}: last dimension is {got}, the loaded model expects {want}")
+
+
 def _ilist(cls, n, vals):
     a = (C.c_int * n)()
     for i, v in enumerate(vals):
@@ -240,14 +246,16 @@ class Engine:
     # ---- network calls (all asynchronous on the current torch stream)
     def cond_encode(self, feats):
         feats = _dev_f32(feats, self.device)
-        B, T, _ = feats.shape
+        B, T, D = feats.shape
+        _want_dim("get_learned_conditioning: video features", D, getattr(self, "cond_origin_dim", None))
         out = torch.empty(B, T, self.cond_embed_dim, device=self.device, dtype=torch.float32)
         _chk(self.L.df_cond_encode(self._h, _ptr(feats), _ptr(out), B, T, _stream()), self.L)
         return out
 
     def set_context(self, ctx):
         ctx = _dev_f32(ctx, self.device)
-        N, T, _ = ctx.shape
+        N, T, D = ctx.shape
+        _want_dim("cross-attention context", D, getattr(self, "unet_context_dim", None))
         _chk(self.L.df_unet_set_context(self._h, _ptr(ctx), N, T, _stream()), self.L)
 
     def unet_forward(self, x, t, out=None):
@@ -281,6 +289,7 @@ class Engine:
         t = _dev_f32(t, self.device)
         feat = _dev_f32(feat, self.device)
         B, Cc, H, W = x.shape
+        _want_dim("classifier video_feat", feat.shape[2], getattr(self, "cls_context_dim", None))
         out = torch.empty(B, self.cls_out_channels, device=self.device, dtype=torch.float32)
         _chk(self.L.df_classifier_forward(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(out), B, H, W, feat.shape[1],
                                          _stream()), self.L)
@@ -291,6 +300,7 @@ class Engine:
         t = _dev_f32(t, self.device)
         feat = _dev_f32(feat, self.device)
         B, Cc, H, W = x.shape
+        _want_dim("classifier video_feat", feat.shape[2], getattr(self, "cls_context_dim", None))
         grad = torch.empty_like(x)
         prob = torch.empty(B, 1, device=self.device, dtype=torch.float32) if want_prob else None
         _chk(self.L.df_classifier_grad(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(prob) if want_prob else None,

@@ -24,6 +24,22 @@ from .schedule import BUFFER_NAMES, register_schedule
 
 _UNET_KEYS = ("in_channels", "out_channels", "model_channels", "attention_resolutions", "num_res_blocks",
               "channel_mult", "num_heads", "context_dim")
+# UNetModel constructor arguments (openai_unetmodel.py:451-468) whose non-default values select code that is not built
+# here; the value the engine implements is listed, anything else raises instead of producing a different network.
+_UNET_FIXED = dict(dims=2, dropout=0, conv_resample=True, num_classes=None, num_head_channels=-1, num_heads_upsample=-1,
+                   use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False,
+                   use_spatial_transformer=True, transformer_depth=1, n_embed=None, legacy=False)
+
+
+def _unet_params(cfg, what):
+    p = _params(cfg)
+    for k, v in _UNET_FIXED.items():
+        if k in p and p[k] != v and not (k == "dropout" and float(p[k]) == 0.0):
+            raise NotImplementedError(f"{what}: {k}={p[k]!r} is not supported by libdfengine (built for {k}={v!r})")
+    out = {k: p[k] for k in _UNET_KEYS}
+    for k in ("attention_resolutions", "channel_mult"):
+        out[k] = [int(v) for v in out[k]]
+    return out
 
 
 def _params(cfg):
@@ -69,9 +85,7 @@ class LatentDiffusion:
             raise NotImplementedError("only eps-parameterisation is on the path")
         if conditioning_key not in (None, "crossattn"):
             raise NotImplementedError("only conditioning_key='crossattn' is on the path (Stage2_LDM.yaml:15)")
-        self.unet_cfg = {k: _params(unet_config)[k] for k in _UNET_KEYS}
-        for k in ("attention_resolutions", "channel_mult"):
-            self.unet_cfg[k] = [int(v) for v in self.unet_cfg[k]]
+        self.unet_cfg = _unet_params(unet_config, "unet_config")
         fs = _params(first_stage_config)
         dd = dict(fs["ddconfig"])
         self.vae_cfg = dict(z_channels=dd["z_channels"], embed_dim=fs["embed_dim"], ch=dd["ch"],
@@ -120,6 +134,8 @@ class LatentDiffusion:
         eng.config_vae(self.vae_cfg, self.scale_factor)
         eng.config_cond(self.cond_cfg)
         eng.cond_embed_dim = self.cond_cfg["embed_dim"]
+        eng.cond_origin_dim = self.cond_cfg["origin_dim"]
+        eng.unet_context_dim = self.unet_cfg["context_dim"]
         eng.unet_out_channels = self.unet_cfg["out_channels"]
         eng.vae_out_ch = self.vae_cfg["out_ch"]
         eng.vae_n_mult = len(self.vae_cfg["ch_mult"])
@@ -173,9 +189,12 @@ class LatentDiffusion:
     def apply_model(self, x_noisy, t, cond, return_ids=False):
         eng = self._require()
         c = self._cond_tensor(cond)
-        if self._ctx_owner is not c:
+        # the hoisted K/V projections are reused only for the very same bytes: storage, shape AND torch's version
+        # counter (an in-place c.copy_() / c.zero_() bumps it), otherwise they are recomputed like the reference does
+        key = (c.data_ptr(), tuple(c.shape), c._version, c.device)
+        if self._ctx_owner != key:
             eng.set_context(c)
-            self._ctx_owner = c
+            self._ctx_owner = key
         return eng.unet_forward(x_noisy, t)
 
     @torch.no_grad()
@@ -193,12 +212,17 @@ class LatentDiffusion:
     def sample(self, cond, batch_size=16, return_intermediates=False, x_T=None, verbose=True, timesteps=None,
                quantize_denoised=False, mask=None, x0=None, shape=None, **kwargs):
         self._require()
+        S.reject_unsupported("LatentDiffusion.sample", dict(mask=mask, x0=x0, quantize_denoised=quantize_denoised,
+                                                              start_T=kwargs.get("start_T")),
+                             dict(quantize_denoised=False, start_T=None))
         if shape is None:
             shape = (batch_size, self.channels, self.image_size, self.image_size)
         if cond is not None:
             cond = self._cond_tensor(cond)[:batch_size]
         return S.ancestral_sample(self, cond, tuple(shape), x_T=x_T, timesteps=timesteps,
-                                  return_intermediates=return_intermediates, noise_fn=kwargs.get("noise_fn"))
+                                  log_every_t=kwargs.get("log_every_t"), return_intermediates=return_intermediates,
+                                  noise_fn=kwargs.get("noise_fn"), callback=kwargs.get("callback"),
+                                  img_callback=kwargs.get("img_callback"))
 
     def _sampler(self, name):
         return {"DDIM": S.DDIMSampler, "DPM_Solver": S.DPMSolverSampler, "PLMS": S.PLMSSampler}[name](self)
@@ -235,6 +259,8 @@ class LatentDiffusion:
                                                 unconditional_conditioning=None, classifier=None,
                                                 classifier_guide_scale=0.0, **kwargs):
         self._require()
+        if classifier is not None and getattr(classifier, "engine", 1) is None:
+            classifier.attach(self)      # the notebook hands over a freshly loaded classifier (ipynb:288-311)
         if sampler_name in ("DDIM", "DPM_Solver"):
             shape = (self.channels, 16, size_len)
             return self._sampler(sampler_name).sample_with_classifier(
@@ -252,10 +278,7 @@ class AlignmentClassifier:
     double guidance needs (ddim.py:333-341): forward + hand-written backward-data pass in libdfengine.so."""
 
     def __init__(self, classifier_config=None, **ignored):
-        cfg = _params(classifier_config)
-        self.cfg = {k: cfg[k] for k in _UNET_KEYS}
-        for k in ("attention_resolutions", "channel_mult"):
-            self.cfg[k] = [int(v) for v in self.cfg[k]]
+        self.cfg = _unet_params(classifier_config, "classifier_config")
         self._state = None
         self.engine = None
 
@@ -267,6 +290,7 @@ class AlignmentClassifier:
         self.engine = ldm._require()
         self.engine.config_classifier(self.cfg)
         self.engine.cls_out_channels = self.cfg["out_channels"]
+        self.engine.cls_context_dim = self.cfg["context_dim"]
         for k, v in self._state.items():
             self.engine.load_tensor("classifier." + k, v)
         self.engine.finalize()
@@ -279,12 +303,17 @@ class AlignmentClassifier:
         return self
 
     @torch.no_grad()
-    def __call__(self, x, t, video_feat):
+    def forward(self, spec_noisy, video_feat=None, t=None):
+        """Same argument order as the reference forward(spec_noisy, video_feat, t) (alignment_classifier.py:269); the
+        reference's own callers use keywords (ddim.py:338, dpm_solver.py:1345)."""
         if self.engine is None:
-            raise RuntimeError("AlignmentClassifier.attach(ldm) first")
-        return self.engine.classifier_forward(x, t, video_feat)
+            raise RuntimeError("AlignmentClassifier: not attached to an engine yet -- pass it to "
+                               "sample_log_with_classifier_diff_sampler (attaches itself) or call .attach(ldm)")
+        if video_feat is None or t is None:
+            raise TypeError("AlignmentClassifier.forward needs spec_noisy, video_feat and t")
+        return self.engine.classifier_forward(spec_noisy, t, video_feat)
 
-    forward = __call__
+    __call__ = forward
 
     @torch.no_grad()
     def log_prob_grad(self, x, t, video_feat):

@@ -64,10 +64,18 @@ def broadcast_state_dict(state_dict, spec, device, src=0):
 
 
 def gather_to_rank0(t, dst=0):
-    """Concatenate per-rank result tensors (equal shapes) on rank dst; returns None elsewhere."""
+    """Concatenate per-rank result tensors along dim 0 on rank dst; returns None elsewhere.  Shards may differ in
+    their leading dimension (``shard_range`` gives the first G % world ranks one extra sample): the sizes are exchanged
+    first and the payload travels padded to the largest shard."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return t
-    world = dist.get_world_size()
-    bufs = [torch.empty_like(t) for _ in range(world)] if dist.get_rank() == dst else None
-    dist.gather(t, bufs, dst=dst)
-    return torch.cat(bufs) if bufs is not None else None
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    nmax = max(sizes)
+    pad = t if t.shape[0] == nmax else torch.cat([t, t.new_zeros((nmax - t.shape[0],) + tuple(t.shape[1:]))])
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad.contiguous(), bufs, dst=dst)
+    return torch.cat([b[:k] for b, k in zip(bufs, sizes)]) if bufs is not None else None

@@ -26,6 +26,22 @@ def _warn_batch(conditioning, batch_size):
             print(f"Warning: Got {c.shape[0]} conditionings but batch-size is {batch_size}")
 
 
+# Reference sampler features that are NOT on this path.  The reference classes accept them (ddim.py:58-113, 179-273;
+# plms.py:60-110; dpm_solver/sampler.py:24-56); silently dropping one would return a plausible but wrong sample, so a
+# non-default value raises.  Anything not listed is ignored exactly like the reference's own **kwargs.
+_UNSUPPORTED_DEFAULTS = dict(mask=None, x0=None, quantize_x0=False, score_corrector=None, corrector_kwargs=None,
+                             noise_dropout=0.0, normals_sequence=None)
+
+
+def reject_unsupported(sampler, kwargs, extra=None):
+    checks = dict(_UNSUPPORTED_DEFAULTS)
+    checks.update(extra or {})
+    for k, default in checks.items():
+        if k in kwargs and kwargs[k] is not None and kwargs[k] != default:
+            raise NotImplementedError(f"{sampler}: {k}={kwargs[k]!r} is not supported by the MI355X sampling path "
+                                      f"(only the default {default!r}); see DESIGN.md section 1")
+
+
 class _Guided:
     """eps(x, t) with classifier-free guidance; owns the engine context for the duration of a sample()."""
 
@@ -50,6 +66,8 @@ class _Guided:
 def _classifier_grad(model, classifier, x, t, origin_cond):
     if not hasattr(classifier, "log_prob_grad"):
         raise RuntimeError("classifier guidance needs a diff_foley_amd AlignmentClassifier (log_prob_grad)")
+    if classifier.engine is None:        # the notebook passes a freshly loaded classifier (ipynb:288-311)
+        classifier.attach(model)
     return classifier.log_prob_grad(x, t, origin_cond)
 
 
@@ -74,6 +92,7 @@ class DDIMSampler(object):
                unconditional_guidance_scale=1.0, unconditional_conditioning=None, temperature=1.0,
                verbose=True, callback=None, img_callback=None, classifier=None, origin_cond=None,
                classifier_guide_scale=0.0, **kwargs):
+        reject_unsupported("DDIMSampler", kwargs)
         _warn_batch(conditioning, batch_size)
         self.make_schedule(S, ddim_eta=eta, verbose=verbose)
         dev = self.model.device
@@ -124,6 +143,7 @@ class PLMSSampler(object):
                img_callback=None, **kwargs):
         if eta != 0:
             raise ValueError("ddim_eta must be 0 for PLMS")
+        reject_unsupported("PLMSSampler", kwargs, dict(temperature=1.0))
         _warn_batch(conditioning, batch_size)
         tb = DDIMTables(self.model.alphas_cumprod, S, 0.0)
         dev = self.model.device
@@ -175,6 +195,10 @@ class DPMSolverSampler(object):
     def sample(self, S, batch_size, shape, conditioning=None, x_T=None, unconditional_guidance_scale=1.0,
                unconditional_conditioning=None, classifier=None, origin_cond=None, classifier_guide_scale=0.0,
                **kwargs):
+        # the reference ignores eta / temperature here (sampler.py:24-56 passes neither to DPM_Solver): same
+        reject_unsupported("DPMSolverSampler", kwargs)
+        if S < 2:
+            raise AssertionError("DPM-Solver++(2M) needs steps >= order = 2 (dpm_solver.py:1083 asserts steps >= order)")
         _warn_batch(conditioning, batch_size)
         dev = self.model.device
         C, H, W = shape

@@ -1,0 +1,61 @@
+"""CPU: the drop-in boundary's host-side contract (no GPU): reference kwargs that the path does not implement raise
+instead of being swallowed, the classifier mirrors the reference argument order, unsupported UNet variants are refused
+at construction, and the samplers' guards fire before any device work."""
+import inspect
+
+import pytest
+import torch
+
+import diff_foley_amd as P
+from diff_foley_amd import samplers as S, synth
+
+
+@pytest.mark.parametrize("kw", [dict(mask=torch.ones(1)), dict(x0=torch.zeros(1)), dict(quantize_x0=True),
+                                dict(score_corrector=object()), dict(noise_dropout=0.1), dict(corrector_kwargs={"a": 1})])
+def test_unsupported_sampler_kwargs_raise(kw):
+    """ddim.py:58-113 accepts these; they select inpainting / VQ / score-correction code that is not built here."""
+    with pytest.raises(NotImplementedError):
+        S.reject_unsupported("DDIMSampler", kw)
+
+
+def test_default_and_unknown_kwargs_pass():
+    S.reject_unsupported("DDIMSampler", dict(mask=None, x0=None, quantize_x0=False, noise_dropout=0.0, score_corrector=None,
+                                             some_future_flag=3, verbose=False))
+
+
+def test_classifier_mirrors_reference_argument_order():
+    """alignment_classifier.py:269  forward(self, spec_noisy, video_feat, t)."""
+    sig = list(inspect.signature(P.AlignmentClassifier.forward).parameters)
+    assert sig == ["self", "spec_noisy", "video_feat", "t"]
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_TINY)))
+    with pytest.raises(RuntimeError, match="not attached"):
+        cls(torch.zeros(1, 4, 16, 64), video_feat=torch.zeros(1, 33, 64), t=torch.zeros(1))
+
+
+@pytest.mark.parametrize("bad", [dict(transformer_depth=2), dict(num_head_channels=64), dict(legacy=True),
+                                 dict(use_scale_shift_norm=True), dict(resblock_updown=True), dict(dims=3),
+                                 dict(use_spatial_transformer=False), dict(num_classes=10)])
+def test_unsupported_unet_variants_are_refused(bad):
+    cfg = P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
+    cfg["unet_config"]["params"].update(bad)
+    with pytest.raises(NotImplementedError):
+        P.LatentDiffusion(**cfg)
+    cc = dict(params=dict(synth.CLS_TINY, **bad))
+    with pytest.raises(NotImplementedError):
+        P.AlignmentClassifier(classifier_config=cc)
+
+
+def test_reference_yaml_defaults_are_accepted():
+    cfg = P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
+    cfg["unet_config"]["params"].update(dict(transformer_depth=1, legacy=False, use_checkpoint=True, image_size=32,
+                                             dropout=0.0, use_spatial_transformer=True))
+    m = P.LatentDiffusion(**cfg)
+    assert m.num_timesteps == 1000 and m.channels == 4
+
+
+def test_engine_rejects_wrong_feature_width_before_touching_the_device():
+    from diff_foley_amd import engine as E
+    with pytest.raises(RuntimeError, match="expects 768"):
+        E._want_dim("cross-attention context", 512, 768)
+    E._want_dim("x", 768, 768)
+    E._want_dim("x", 5, None)

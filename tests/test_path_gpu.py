@@ -398,3 +398,98 @@ def test_tiny_decode_large_batch_is_chunked(tiny):
     assert rel_l2(full[16:], part) < 2e-2          # different batch -> different plan/tiles: operand-rounding noise only
     one = tiny.decode_first_stage(z[:16].cuda()).cpu()
     assert torch.equal(full[:16], one)
+
+
+# ------------------------------------------------------------------------------------------- notebook drop-in
+def test_notebook_cells_replayed_verbatim(P):
+    """inference/diff_foley_inference.ipynb cells 5-13 with only the import line changed:
+    ``load_model_from_config`` = instantiate_from_config(config.model) -> load_state_dict(strict=False) -> .cuda() ->
+    .eval() for the LDM *and* the double-guidance classifier, which is then handed STRAIGHT to
+    sample_log_with_classifier_diff_sampler (no attach call exists in the notebook), the 32-frame window loop,
+    decode_first_stage and the channel-0 slice.  Reference targets are used as written in the YAML files
+    (Stage2_LDM.yaml:2, Double_Guidance_Classifier.yaml:3); sizes are the tiny configuration (numerics of this very
+    sampler are pinned against the reference in test_tiny_classifier_grad_and_double_guidance_vs_golden)."""
+    from diff_foley_amd import synth
+    from diff_foley_amd.ldm import instantiate_from_config
+
+    class Cfg(dict):                       # stands in for OmegaConf: attribute access on the loaded YAML
+        __getattr__ = dict.__getitem__
+
+    def load_model_from_config(config, sd, verbose=False):          # cell 5, torch.load replaced by the dict itself
+        model = instantiate_from_config(config.model)
+        m, u = model.load_state_dict(sd, strict=False)
+        model.cuda()
+        model.eval()
+        return model
+
+    ldm_config = Cfg(model=dict(target="diff_foley.models.diffusion.ddpm.LatentDiffusion",
+                                params=P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)))
+    latent_diffusion_model = load_model_from_config(ldm_config, tiny_state_dict())                      # cell 6
+    classifier_config = Cfg(model=dict(
+        target="diff_foley.modules.double_guidance.alignment_classifier.Alignment_Classifier_Double_Guidance",
+        params=dict(linear_start=0.00085, linear_end=0.0120, timesteps=1000, scale_factor=0.18215, first_stage_key="spec",
+                    classifier_config=dict(target="diff_foley.modules.double_guidance.alignment_backbone.Classifier_Backbone",
+                                           params=dict(image_size=32, use_spatial_transformer=True, transformer_depth=1,
+                                                       use_checkpoint=True, legacy=False, **synth.CLS_TINY)))))
+    classifier = load_model_from_config(classifier_config, tiny_classifier_sd())                        # cell 12
+    device = torch.device("cuda")
+    sample_num, cfg_scale, cg_scale, steps, sampler = 2, 4.5, 50, 10, "DPM_Solver"                        # cell 13
+    cavp_feats = synth.synthetic_cavp(1, 33, 64, seed=4321)[0].numpy()         # (33, 64): what extract_cavp returns
+    video_feat = torch.from_numpy(cavp_feats).unsqueeze(0).repeat(sample_num, 1, 1).to(device)
+    feat_len = video_feat.shape[1]
+    truncate_len = 32
+    window_num = feat_len // truncate_len
+    mels = []
+    for i in range(window_num):
+        start, end = i * truncate_len, (i + 1) * truncate_len
+        embed_cond_feat = latent_diffusion_model.get_learned_conditioning(video_feat[:, start:end])
+        uncond_cond = torch.zeros(embed_cond_feat.shape).to(device)
+        audio_samples, _ = latent_diffusion_model.sample_log_with_classifier_diff_sampler(
+            embed_cond_feat, origin_cond=video_feat, batch_size=video_feat.shape[0], sampler_name=sampler, ddim_steps=steps,
+            unconditional_guidance_scale=cfg_scale, unconditional_conditioning=uncond_cond, classifier=classifier,
+            classifier_guide_scale=cg_scale, x_T=synth.synthetic_xT(sample_num, seed=21).to(device))
+        assert audio_samples.shape == (sample_num, 4, 16, 64)
+        audio_samples = latent_diffusion_model.decode_first_stage(audio_samples)
+        audio_samples = audio_samples[:, 0, :, :].detach().cpu().numpy()
+        mels.append(audio_samples)
+    assert window_num == 1 and mels[0].shape[0] == sample_num and np.isfinite(mels[0]).all()
+    # second, keyword-free call: the classifier protocol of the reference (x_in, t=t, video_feat=c) also works directly
+    p = classifier(torch.zeros(sample_num, 4, 16, 64, device=device), t=torch.full((sample_num,), 500.0, device=device),
+                   video_feat=video_feat)
+    assert p.shape == (sample_num, 1) and bool(((p > 0) & (p < 1)).all())
+    # unsupported reference kwargs raise instead of being dropped
+    with pytest.raises(NotImplementedError):
+        latent_diffusion_model.sample_log_diff_sampler(embed_cond_feat, batch_size=sample_num, sampler_name="DDIM",
+                                                       ddim_steps=5, mask=torch.ones(1), x0=torch.zeros(1))
+    with pytest.raises(AssertionError):
+        latent_diffusion_model.sample_log_diff_sampler(embed_cond_feat, batch_size=sample_num, sampler_name="DPM_Solver",
+                                                       ddim_steps=1)
+    with pytest.raises(RuntimeError, match="expects"):
+        latent_diffusion_model.get_learned_conditioning(torch.zeros(1, 32, 512, device=device))     # raw dim of the FULL model
+
+
+def test_reloading_weights_invalidates_packed_copies(P):
+    """a second load_state_dict on a used model must not keep running on the old packed operands."""
+    from diff_foley_amd import synth
+    x, c = rnd((2, 4, 16, 64), 102), rnd((2, 32, 128), 101)
+    t = torch.tensor([500, 37])
+    spec = synth.state_dict_spec(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
+    sd0, sd1 = tiny_state_dict(0), synth.make_state_dict(spec, 1)
+    m = P.LatentDiffusion(**P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
+    m.load_state_dict(sd0)
+    m.cuda()
+    y0 = m.apply_model(x.cuda(), t.cuda(), c.cuda()).cpu()
+    m.load_state_dict(sd1)
+    y1 = m.apply_model(x.cuda(), t.cuda(), c.cuda()).cpu()
+    fresh = P.LatentDiffusion(**P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
+    fresh.load_state_dict(sd1)
+    fresh.cuda()
+    y1_ref = fresh.apply_model(x.cuda(), t.cuda(), c.cuda()).cpu()
+    assert rel_l2(y0, y1_ref) > 0.1                     # the two checkpoints really differ
+    assert torch.equal(y1, y1_ref)
+    # in-place mutation of the conditioning tensor is seen (apply_model keys its K/V cache on the tensor version)
+    cc = c.cuda().clone()
+    ya = m.apply_model(x.cuda(), t.cuda(), cc).cpu()
+    cc.zero_()
+    yb = m.apply_model(x.cuda(), t.cuda(), cc).cpu()
+    assert rel_l2(ya, yb) > 1e-3
