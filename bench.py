@@ -33,13 +33,12 @@ PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16 (MI355X_MICROARCH.md)
 
 def cpu_baseline(sd, nsteps):
     """The oracle (CPU restatement of the reference sampler, fp32) timed on this box's host cores:
-    BASELINE.json configs[0]: B=1, CFG 4.5 (UNet batch 2), DDIM.  Bounded sample: `nsteps` steps.
-    32 threads: measured fastest on the 128-core GPU box (8: 0.5, 16: 0.78, 32: 0.80, 64: 0.46, 128: 0.20 steps/s)."""
+    BASELINE.json configs[0]: B=1, CFG 4.5 (UNet batch 2), DDIM.  Bounded sample: `nsteps` steps at the fastest thread
+    count (32: measured on the 128-core GPU box -- 8: 0.5, 16: 0.78, 32: 0.80, 64: 0.46, 128: 0.20 steps/s) and, side by
+    side, nsteps/2 steps on 8 threads, the thread count of the build container's reference probe."""
     from oracle import unet as ou, vae as ov, schedule as osch
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
     usd = ou.sub_state_dict(sd, "model.diffusion_model.")
     csd = ou.sub_state_dict(sd, "cond_stage_model.")
-    x = synth.synthetic_xT(1)
     c = ov.cond_stage(csd, synth.synthetic_cavp(1))
     uc = torch.zeros_like(c)
     sch = osch.ddim_schedule(osch.ddpm_schedule()["alphas_cumprod"], 25)
@@ -53,14 +52,20 @@ def cpu_baseline(sd, nsteps):
         a_t, a_p = float(sch["alphas"][idx]), float(sch["alphas_prev"][idx])
         p0 = (x - float(sch["sqrt_one_minus_alphas"][idx]) * e) / a_t ** 0.5
         return a_p ** 0.5 * p0 + (1 - a_p) ** 0.5 * e
-    x = one(0, x)                      # warm-up (thread pools, allocator)
-    t0 = time.perf_counter()
-    for i in range(1, 1 + nsteps):
-        x = one(i, x)
-    dt = time.perf_counter() - t0
-    return dict(value=nsteps / dt, unit="denoise_steps/s at B=1 (UNet batch 2)", cores=torch.get_num_threads(),
-                kind="port", sample=f"{nsteps} DDIM steps of BASELINE config[0] (B=1, CFG 4.5, fp32, oracle/unet.py), "
-                                    f"{dt:.1f} s of CPU work")
+
+    def timed(threads, n):
+        torch.set_num_threads(min(threads, os.cpu_count() or 1))
+        x = one(0, synth.synthetic_xT(1))          # warm-up (thread pools, allocator)
+        t0 = time.perf_counter()
+        for i in range(1, 1 + n):
+            x = one(i, x)
+        return n / (time.perf_counter() - t0), time.perf_counter() - t0, torch.get_num_threads()
+    v32, dt32, th32 = timed(32, nsteps)
+    v8, dt8, th8 = timed(8, max(2, nsteps // 2))
+    return dict(value=v32, unit="denoise_steps/s at B=1 (UNet batch 2)", cores=th32, kind="port",
+                sample=f"{nsteps} DDIM steps of BASELINE config[0] (B=1, CFG 4.5, fp32, oracle/unet.py), {dt32:.1f} s of CPU "
+                       f"work on {th32} threads; side by side: {max(2, nsteps // 2)} steps on {th8} threads, {dt8:.1f} s",
+                threads_8={"value": v8, "cores": th8}, host_cores=os.cpu_count())
 
 
 def pmc_traffic():
@@ -84,46 +89,42 @@ def measured_peak():
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=25)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="samples per GPU (UNet batch is 2x this)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=10)
-    ap.add_argument("--no-autotune", action="store_true")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
-                    help="MFMA operand type (bf16 = BASELINE config 2, the default; fp16 = libdfengine_f16.so)")
-    ap.add_argument("--dump-ops", default="", help="write a per-op CSV of the instrumented pass")
-    a = ap.parse_args()
+GOLD = os.path.join(ROOT, "tests", "golden", "g5_full_samplers.npz")
 
-    rank, world, local = parallel.init_process_group()
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local)
+
+def golden_mel_mae(model, dev):
+    """North-star parity metric, measured inside the bench: 25-step DDIM (CFG 4.5, B=1, seed 21) + decode_first_stage
+    against the REFERENCE's own output for the same inputs (tests/golden/g5_full_samplers.npz, made by
+    tests/golden/make_golden.py from /root/reference; a fixture, not the oracle).  Mean absolute error of the mel."""
+    if not os.path.exists(GOLD):
+        return None
+    g = np.load(GOLD)
+    xT = synth.synthetic_xT(1, seed=21).to(dev)
+    c = model.get_learned_conditioning(synth.synthetic_cavp(1, 32, 512, seed=1234).to(dev))
+    z, _ = model.sample_log_diff_sampler(c, 1, "DDIM", 25, unconditional_guidance_scale=4.5,
+                                         unconditional_conditioning=torch.zeros_like(c), x_T=xT)
+    mel = model.decode_first_stage(z)[:, 0].cpu().numpy()
+    ref = g["ddim25_mel_21"]
+    return dict(mel_mae=float(np.abs(mel - ref).mean()), mel_range=float(ref.max() - ref.min()), mel_std=float(ref.std()),
+                z_rel_l2=float(np.linalg.norm(z.cpu().numpy() - g["ddim25_z_21"]) / np.linalg.norm(g["ddim25_z_21"])))
+
+
+def run_mode(precision, sd_dev, a, dev, rank, world, lo, hi, barrier, dump_ops=""):
+    """Builds the engine for one MFMA operand type and times K denoise steps of this rank's shard."""
     B = a.batch
-    G = B * world                                           # weak scaling: fixed per-GPU batch
-
-    # ---- weights: generated on rank 0, ONE flat RCCL broadcast over xGMI, re-packed to bf16 on every rank
-    spec = synth.state_dict_spec()
-    sd = synth.make_state_dict(spec, 0) if rank == 0 else None
     t0 = time.perf_counter()
-    if world > 1:
-        sd_dev = parallel.broadcast_state_dict(sd, spec, dev, src=0)
-        torch.cuda.synchronize()
-    else:
-        sd_dev = sd
-    t_bcast = time.perf_counter() - t0
-    model = P.LatentDiffusion(precision=a.precision, **P.stage2_config())
-    model.load_state_dict(sd_dev)
+    model = P.LatentDiffusion(precision=precision, **P.stage2_config())
+    if rank == 0:
+        model.load_state_dict(sd_dev)
     model.cuda(dev)
-    if not a.no_autotune:
+    if rank == 0 and not a.no_autotune:
         model.autotune(True)
-    del sd_dev
-
-    # ---- this rank's shard of the global batch (seeded by GLOBAL sample index)
-    lo, hi = parallel.shard_range(G, rank, world)
-    feats = synth.synthetic_cavp(G)[lo:hi].to(dev)
+    dist_info = None
+    if world > 1:      # rank 0 packs ONCE, one broadcast of the packed operand blob (RCCL over xGMI), the others import
+        dist_info = parallel.broadcast_packed_model(model, B, src=0)
+        if rank != 0 and not a.no_autotune:
+            model.autotune(True)
+    feats = synth.synthetic_cavp(B * world)[lo:hi].to(dev)
     x = synth.synthetic_xT(hi - lo, first_index=lo).to(dev)
     c = model.get_learned_conditioning(feats)
     uc = torch.zeros_like(c)
@@ -140,13 +141,10 @@ def main():
         xn, _ = E.ddim_update(x, e, tb.alphas[idx], tb.alphas_prev[idx], 0.0, tb.sqrt_one_minus_alphas[idx])
         return xn
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
     for i in range(a.warmup):
         x = step(i, x)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -159,7 +157,9 @@ def main():
         dt = float(t.item())
     assert torch.isfinite(x).all() or os.environ.get("DF_GEMM_DBG")
 
-    # ---- per-kernel-family time, HIP events on the launch stream, same K steps (instrumented pass)
+    # ---- per-kernel-family time: HIP events on the launch stream around every op of the same K steps (second,
+    # instrumented pass; the events themselves cost ~2 us per op, so the family times are NORMALISED to the
+    # un-instrumented step time before any rate is derived from them)
     eng.profile_begin()
     for i in range(a.steps):
         x = step(a.warmup + i, x)
@@ -168,67 +168,152 @@ def main():
     if rank == 0:
         import csv
         import tempfile
-        dump = a.dump_ops or os.path.join(tempfile.gettempdir(), f"df_ops_{os.getpid()}.csv")
+        dump = dump_ops or os.path.join(tempfile.gettempdir(), f"df_ops_{os.getpid()}.csv")
         eng.profile_dump(dump)
-        # the dump holds every launch of the K instrumented steps; fold it to ONE step (mean ms per op position)
         rows = list(csv.DictReader(open(dump)))
         if rows and len(rows) % a.steps == 0:
             n = len(rows) // a.steps
             for i in range(n):
                 rows[i]["ms"] = "%.5f" % (sum(float(rows[i + k * n]["ms"]) for k in range(a.steps)) / a.steps)
             rows = rows[:n]
-            if a.dump_ops:
+            if dump_ops:
                 with open(dump, "w", newline="") as f:
                     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
                     w.writeheader()
                     w.writerows(rows)
-            # the two family metrics the north star names: SpatialTransformer MFMA rate over every op of
-            # the 16 transformers (GEMMs, attention, LayerNorm) and ResBlock-conv HBM rate over the 44 conv3x3 launches
             st_ms = sum(float(r["ms"]) for r in rows if r["tag"].startswith(("st.", "attn.")) or r["tag"] == "layernorm")
             rc_ms = sum(float(r["ms"]) for r in rows if r["tag"] in ("res.conv1", "res.conv2"))
-            sub = {"st_ms": st_ms, "rc_ms": rc_ms}
-        if not a.dump_ops:
+            sub = {"st_ms": st_ms, "rc_ms": rc_ms, "st_launches": sum(1 for r in rows if r["tag"].startswith(("st.", "attn.")) or r["tag"] == "layernorm")}
+        if not dump_ops:
             os.remove(dump)
-    stats = eng.plan_stats()
+    return dict(model=model, dt=dt, prof=prof, sub=sub, stats=eng.plan_stats(), t_setup=t_setup, dist=dist_info)
+
+
+def vae_roofline(model, dev, B):
+    """decode_first_stage at batch B (622.2 GFLOP and 0.0989 + 0.6096 B GB of algorithmic traffic)."""
+    z = synth.synthetic_xT(B).to(dev)
+    for _ in range(2):
+        model.decode_first_stage(z)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 5
+    for _ in range(n):
+        model.decode_first_stage(z)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    gflop, gb = 622.2 * B, 0.0989 + 0.6096 * B
+    return {"batch": B, "ms": round(ms, 3), "algorithmic_gflop": gflop, "algorithmic_gb": round(gb, 4),
+            "tflops": round(gflop / ms, 1), "frac_of_mfma_peak": round(gflop / ms / PEAK_BF16_TFLOPS, 4),
+            "gb_per_s": round(gb / ms * 1e3, 1), "frac_of_hbm_peak": round(gb / ms * 1e3 / 8000.0, 4),
+            "bound": "mfma (1005 FLOP/B algorithmic) -- measured far below both ceilings: see profiles/"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=25)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="samples per GPU (UNet batch is 2x this)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="skip the second operand type and the in-bench golden check")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
+                    help="MFMA operand type of the headline value (bf16 = BASELINE configs[1]; fp16 = libdfengine_f16.so)")
+    ap.add_argument("--dump-ops", default="", help="write a per-op CSV of the instrumented pass")
+    a = ap.parse_args()
+
+    rank, world, local = parallel.init_process_group()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    B = a.batch
+    G = B * world                                           # weak scaling: fixed per-GPU batch
+
+    # ---- weights: generated on rank 0 only; for N > 1 rank 0 packs them once into the MFMA operand layouts and ONE
+    # broadcast of that blob (RCCL over xGMI) feeds every other rank (parallel.broadcast_packed_model)
+    spec = synth.state_dict_spec()
+    sd = synth.make_state_dict(spec, 0) if rank == 0 else None
+    sd_dev = sd
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    lo, hi = parallel.shard_range(G, rank, world)
+    main_run = run_mode(a.precision, sd_dev, a, dev, rank, world, lo, hi, barrier, a.dump_ops)
+    dt, prof, sub, stats = main_run["dt"], main_run["prof"], main_run["sub"], main_run["stats"]
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         per_gpu = a.steps / dt
         N = 2 * B
-        gemm_ms = prof["gemm"]["ms"] / a.steps
+        inst_total = sum(v["ms"] for v in prof.values()) / a.steps            # instrumented: includes event overhead
+        norm = ms_step / inst_total                                          # -> family times that sum to ms_per_step
+        fam_ms = {k: v["ms"] / a.steps * norm for k, v in prof.items()}
+        gemm_ms = fam_ms["gemm"]
         gemm_launches = prof["gemm"]["launches"] // a.steps
         gemm_tflops = GEMM_GFLOP_PER_SAMPLE * N / gemm_ms            # GFLOP / ms = TFLOP/s
+        name = {"bf16": "bf16", "fp16": "f16"}
         out = {
             "metric": "UNet denoise steps/sec (8s audio latent, 25-step DDIM, CFG 4.5), aggregate over GPUs",
             "value": round(per_gpu * world, 3),
             "unit": "denoise_steps/s",
             "per_gpu": round(per_gpu, 3),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": name[a.precision],
             "data": "synthetic (procedural weights of the full 859.5M-param UNet, unit-norm CAVP-like features, seeded x_T)",
             "config": {"workload": "BASELINE.json configs[1]: single MI355X, batch=4 (UNet batch 8), 25-step DDIM, "
                                    + ("bf16" if a.precision == "bf16" else "fp16") + " UNet, 32 CAVP context frames, latent 4x16x64, guidance 4.5",
                        "batch_per_gpu": B, "global_batch": G, "parallelism": f"batch-shard x{world}, no step-loop collectives",
-                       "weight_bcast_s": round(t_bcast, 3) if world > 1 else None},
+                       "weight_distribution": main_run["dist"],
+                       "engine_setup_s": round(main_run["t_setup"], 3)},
             "step_tflops_algorithmic": round(GFLOP_PER_SAMPLE * N / ms_step, 2),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (implicit-GEMM conv3x3/1x1/linear, all tile shapes)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel / conv3x3_halo_kernel (implicit-GEMM conv3x3/1x1/linear, all tile shapes, incl. split-K reduce)",
                          "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
-                         "peak_measured": measured_peak(),
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
                          "launches_per_step": int(gemm_launches), "avg_launch_us": round(gemm_ms * 1e3 / max(1, gemm_launches), 2),
-                         "algorithmic_gflop_per_step": round(GEMM_GFLOP_PER_SAMPLE * N, 1)},
+                         "algorithmic_gflop_per_step": round(GEMM_GFLOP_PER_SAMPLE * N, 1),
+                         "family_ms_per_step": round(gemm_ms, 4),
+                         "time_source": "HIP events around every op of the K steps on the launch stream, normalised so that the "
+                                        "families sum to the un-instrumented ms_per_step (events add ~2 us per op)",
+                         "traffic": pmc_traffic(), "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command; not measured in this run)",
+                         "peak_measured": measured_peak(), "peak_measured_source": "profiles/peaks.json (tools/peaks.py on an MI355X; not measured in this run)"},
             "north_star_families": None if not sub else {
-                "spatial_transformer": {"algorithmic_gflop_per_step": round(73.22 * N, 1), "ms_per_step": round(sub["st_ms"], 4),
-                                        "tflops": round(73.22 * N / sub["st_ms"], 1),
-                                        "frac_of_mfma_peak": round(73.22 * N / sub["st_ms"] / PEAK_BF16_TFLOPS, 4)},
-                "resblock_conv3x3": {"algorithmic_gb_per_step": round(1.0235 + 0.0403 * N, 4), "ms_per_step": round(sub["rc_ms"], 4),
-                                     "gb_per_s": round((1.0235 + 0.0403 * N) / sub["rc_ms"] * 1e3, 1),
-                                     "frac_of_hbm_peak": round((1.0235 + 0.0403 * N) / sub["rc_ms"] * 1e3 / 8000.0, 4),
-                                     "tflops": round(81.62 * N / sub["rc_ms"], 1)}},
-            "kernel_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in prof.items()},
+                "spatial_transformer": {"algorithmic_gflop_per_step": round(73.22 * N, 1), "ms_per_step": round(sub["st_ms"] * norm, 4),
+                                        "launches_per_step": sub["st_launches"],
+                                        "tflops": round(73.22 * N / (sub["st_ms"] * norm), 1),
+                                        "frac_of_mfma_peak": round(73.22 * N / (sub["st_ms"] * norm) / PEAK_BF16_TFLOPS, 4)},
+                "resblock_conv3x3": {"algorithmic_gb_per_step": round(1.0235 + 0.0403 * N, 4), "ms_per_step": round(sub["rc_ms"] * norm, 4),
+                                     "gb_per_s": round((1.0235 + 0.0403 * N) / (sub["rc_ms"] * norm) * 1e3, 1),
+                                     "frac_of_hbm_peak": round((1.0235 + 0.0403 * N) / (sub["rc_ms"] * norm) * 1e3 / 8000.0, 4),
+                                     "tflops": round(81.62 * N / (sub["rc_ms"] * norm), 1)}},
+            "kernel_ms_per_step": {k: round(v, 4) for k, v in fam_ms.items()},
+            "kernel_ms_per_step_instrumented": {k: round(v["ms"] / a.steps, 4) for k, v in prof.items()},
             "kernel_launches_per_step": {k: int(v["launches"] // a.steps) for k, v in prof.items()},
             "plan": stats,
         }
+        if world == 1:
+            out["vae_decode_roofline"] = vae_roofline(main_run["model"], dev, B)
+        if world == 1 and not a.no_modes:
+            # both MFMA operand types in ONE driver-run line: steps/s of the same workload + the north-star parity metric
+            # (mel MAE of a 25-step DDIM sample against the reference's golden output) measured in this very process
+            modes = {}
+            par = golden_mel_mae(main_run["model"], dev)
+            modes[name[a.precision]] = {"steps_per_s": round(per_gpu, 3), "ms_per_step": round(ms_step, 4), "parity_vs_reference": par}
+            other = "fp16" if a.precision == "bf16" else "bf16"
+            try:
+                o = run_mode(other, sd_dev, a, dev, rank, world, lo, hi, barrier)
+                modes[name[other]] = {"steps_per_s": round(a.steps / o["dt"], 3), "ms_per_step": round(o["dt"] / a.steps * 1e3, 4),
+                                      "parity_vs_reference": golden_mel_mae(o["model"], dev)}
+                del o
+            except Exception as ex:      # a missing second build must not hide the headline number
+                modes[name[other]] = {"error": str(ex)[:200]}
+            out["modes"] = modes
+            out["parity_target"] = "north_star: mel-spec MAE < 1e-3 vs the CPU reference (absolute, mel units); " \
+                                   "golden = tests/golden/g5_full_samplers.npz (reference output, B=1, seed 21)"
+        del main_run
         if not a.no_cpu_baseline and world == 1:       # reported at N=1 only (rank 0's host cores)
             out["cpu_baseline"] = cpu_baseline(sd, a.cpu_steps)
         print(json.dumps(out))

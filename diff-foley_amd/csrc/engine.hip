@@ -164,12 +164,18 @@ struct df_ctx {
     return it->second;
   }
   bool has(const std::string& name) const { return raw.count(name) != 0; }
-  const float* f32(const std::string& name) const { return rt(name).d; }
+  const float* f32(const std::string& name) const {
+    const RawT& t = rt(name);
+    if (!t.d) fail("tensor '%s' was imported shape-only (df_import_packed): its fp32 data is not on this rank", name.c_str());
+    return t.d;
+  }
 
+  std::map<const void*, size_t> block_bytes;     // size of every packed block (export of the packed blob)
   void* pmalloc(size_t bytes) {
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, (bytes + 255) & ~(size_t)255));
     packed_blocks.push_back(p);
+    block_bytes[p] = bytes;
     return p;
   }
   // Linear / 1x1-conv weight [O][I] -> bf16
@@ -177,6 +183,7 @@ struct df_ctx {
     auto it = packed.find(name);
     if (it != packed.end()) return (const bf16_t*)it->second;
     const RawT& t = rt(name);
+    (void)f32(name);
     bf16_t* o = (bf16_t*)pmalloc(t.n * 2);
     HIPCHK(launch_cast_bf16(t.d, o, (long)t.n, pack_stream));
     packed[name] = o;
@@ -2105,6 +2112,55 @@ int guard(F&& f) {
 
 }  // namespace
 
+// ---- packed-operand blob: ONE packing on the root rank, one broadcast, no fp32 masters and no re-pack elsewhere ------
+namespace {
+struct BlobW {
+  std::vector<char> m;
+  template <class T> void put(T v) { const char* p = (const char*)&v; m.insert(m.end(), p, p + sizeof(T)); }
+  void str(const std::string& s) { put<uint16_t>((uint16_t)s.size()); m.insert(m.end(), s.begin(), s.end()); }
+};
+struct BlobR {
+  const char* p; const char* e;
+  template <class T> T get() { if (p + sizeof(T) > e) fail("packed manifest truncated"); T v; memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
+  std::string str() { const uint16_t n = get<uint16_t>(); if (p + n > e) fail("packed manifest truncated"); std::string s(p, p + n); p += n; return s; }
+};
+constexpr uint32_t kBlobMagic = 0x44464250u;   // "DFBP"
+constexpr size_t kRawDataMax = 65536;          // fp32 tensors up to this many elements travel as data (biases, norm
+                                               // parameters, pos_emb, post_quant_conv); larger ones as shape only
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// Layout shared by size / export: raw entries (sorted by name) first, then packed entries (sorted by key).
+size_t blob_layout(df_ctx* c, BlobW* w) {
+  size_t off = 0;
+  if (w) {
+    w->put<uint32_t>(kBlobMagic); w->put<uint32_t>(1);
+#if defined(DF_OPERAND_F16)
+    w->put<uint32_t>(1);
+#else
+    w->put<uint32_t>(0);
+#endif
+    w->put<uint32_t>((uint32_t)c->raw.size()); w->put<uint32_t>((uint32_t)c->packed.size());
+  }
+  for (auto& kv : c->raw) {
+    const RawT& t = kv.second;
+    const bool data = t.d != nullptr && t.n <= kRawDataMax;
+    if (w) {
+      w->str(kv.first); w->put<uint8_t>((uint8_t)t.shape.size());
+      for (int64_t d : t.shape) w->put<int64_t>(d);
+      w->put<uint8_t>(data ? 1 : 0); w->put<uint64_t>((uint64_t)off);
+    }
+    if (data) off += al256(t.n * 4);
+  }
+  for (auto& kv : c->packed) {
+    auto it = c->block_bytes.find(kv.second);
+    if (it == c->block_bytes.end()) fail("packed entry '%s' has no recorded size", kv.first.c_str());
+    if (w) { w->str(kv.first); w->put<uint64_t>((uint64_t)it->second); w->put<uint64_t>((uint64_t)off); }
+    off += al256(it->second);
+  }
+  return off;
+}
+}  // namespace
+
 // ================================================================================================== C ABI
 extern "C" {
 
@@ -2179,6 +2235,7 @@ int df_finalize(df_ctx* c) {
     if (c->reloaded) {     // every packed operand copy (casts, GEGLU / LN-folded / BN-folded / stacked packings) is rebuilt
       for (void* p : c->packed_blocks) (void)hipFree(p);
       c->packed_blocks.clear();
+      c->block_bytes.clear();
       c->packed.clear();
       c->ctx_copy = nullptr;
       c->ctx_copy_bytes = 0;
@@ -2324,6 +2381,92 @@ int df_classifier_grad(df_ctx* c, const float* x, const float* t, const float* f
     a.out = grad;
     a.out2 = prob;
     run_ops(c, p, 0, p->ops.size(), (hipStream_t)stream, a);
+  });
+}
+
+// ---- packed-operand blob (helpers above the C ABI block)
+
+int df_prepack(df_ctx* c, int B, int H, int W, int T) {
+  return guard([&] {
+    HIPCHK(hipSetDevice(c->device));
+    if (c->has_unet) (void)unet_plan(c, 2 * B, H, W, T, true);
+    if (c->has_vae) (void)get_plan(c, keyf("vae_%d_%d_%d", B, H, W), [&](Plan* pl) { build_vae(c, pl, B, H, W); });
+    if (c->has_cond) (void)get_plan(c, keyf("cond_%d_%d", B, T), [&](Plan* pl) { build_cond(c, pl, B, T); });
+    HIPCHK(hipStreamSynchronize(c->pack_stream));
+  });
+}
+
+int df_packed_size(df_ctx* c, size_t* manifest_bytes, size_t* blob_bytes) {
+  return guard([&] {
+    BlobW w;
+    *blob_bytes = blob_layout(c, &w);
+    *manifest_bytes = w.m.size();
+  });
+}
+
+int df_export_packed(df_ctx* c, void* manifest_host, void* blob_dev, void* stream) {
+  return guard([&] {
+    HIPCHK(hipSetDevice(c->device));
+    BlobW w;
+    (void)blob_layout(c, &w);
+    memcpy(manifest_host, w.m.data(), w.m.size());
+    hipStream_t s = (hipStream_t)stream;
+    size_t off = 0;
+    for (auto& kv : c->raw) {
+      const RawT& t = kv.second;
+      if (t.d == nullptr || t.n > kRawDataMax) continue;
+      HIPCHK(hipMemcpyAsync((char*)blob_dev + off, t.d, t.n * 4, hipMemcpyDeviceToDevice, s));
+      off += al256(t.n * 4);
+    }
+    for (auto& kv : c->packed) {
+      const size_t b = c->block_bytes.at(kv.second);
+      HIPCHK(hipMemcpyAsync((char*)blob_dev + off, kv.second, b, hipMemcpyDeviceToDevice, s));
+      off += al256(b);
+    }
+  });
+}
+
+int df_import_packed(df_ctx* c, const void* manifest_host, size_t manifest_bytes, const void* blob_dev, size_t blob_bytes,
+                     void* stream) {
+  return guard([&] {
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    BlobR r{(const char*)manifest_host, (const char*)manifest_host + manifest_bytes};
+    if (r.get<uint32_t>() != kBlobMagic || r.get<uint32_t>() != 1) fail("not a libdfengine packed manifest");
+    const uint32_t op = r.get<uint32_t>();
+#if defined(DF_OPERAND_F16)
+    if (op != 1) fail("packed blob holds bf16 operands, this library is the fp16 build");
+#else
+    if (op != 0) fail("packed blob holds fp16 operands, this library is the bf16 build");
+#endif
+    const uint32_t nraw = r.get<uint32_t>(), npk = r.get<uint32_t>();
+    for (uint32_t i = 0; i < nraw; ++i) {
+      const std::string name = r.str();
+      RawT t;
+      t.n = 1;
+      const int nd = r.get<uint8_t>();
+      for (int k = 0; k < nd; ++k) { t.shape.push_back(r.get<int64_t>()); t.n *= (size_t)t.shape.back(); }
+      const bool data = r.get<uint8_t>() != 0;
+      const uint64_t off = r.get<uint64_t>();
+      auto it = c->raw.find(name);
+      if (it != c->raw.end()) { (void)hipFree(it->second.d); c->raw.erase(it); c->reloaded = true; }
+      if (data) {
+        if (off + t.n * 4 > blob_bytes) fail("packed blob too small for '%s'", name.c_str());
+        HIPCHK(hipMalloc((void**)&t.d, al256(t.n * 4)));
+        HIPCHK(hipMemcpyAsync(t.d, (const char*)blob_dev + off, t.n * 4, hipMemcpyDeviceToDevice, s));
+      }
+      c->raw[name] = t;
+    }
+    if (c->reloaded) fail("df_import_packed into a context that already holds these tensors (create a fresh context)");
+    for (uint32_t i = 0; i < npk; ++i) {
+      const std::string key = r.str();
+      const uint64_t b = r.get<uint64_t>(), off = r.get<uint64_t>();
+      if (off + b > blob_bytes) fail("packed blob too small for '%s'", key.c_str());
+      void* p = c->pmalloc((size_t)b);
+      HIPCHK(hipMemcpyAsync(p, (const char*)blob_dev + off, (size_t)b, hipMemcpyDeviceToDevice, s));
+      c->packed[key] = p;
+    }
+    HIPCHK(hipStreamSynchronize(s));
   });
 }
 

@@ -67,6 +67,10 @@ _SIGS = {
                               C.c_int, C.c_void_p],
     "df_classifier_grad": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                            C.c_int, C.c_int, C.c_void_p],
+    "df_prepack": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],
+    "df_packed_size": [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
+    "df_export_packed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "df_import_packed": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p],
     "df_cfg_combine": [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p],
     "df_lincomb": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_void_p],
     "df_ddim_update": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
@@ -242,6 +246,26 @@ class Engine:
 
     def autotune(self, enable=True):
         _chk(self.L.df_autotune(self._h, int(enable)), self.L)
+
+    # ---- packed-operand blob (multi-GPU weight distribution: pack once on the root rank, broadcast, import elsewhere)
+    def export_packed(self, B, H, W, T):
+        """Builds every operand packing the UNet (CFG batch 2B) / VAE / cond-stage plans of this shape need and returns
+        (manifest: uint8 CPU tensor, blob: uint8 tensor on the engine's device)."""
+        _chk(self.L.df_prepack(self._h, B, H, W, T), self.L)
+        mb, bb = C.c_size_t(), C.c_size_t()
+        _chk(self.L.df_packed_size(self._h, C.byref(mb), C.byref(bb)), self.L)
+        manifest = torch.empty(mb.value, dtype=torch.uint8)
+        blob = torch.empty(bb.value, dtype=torch.uint8, device=self.device)
+        _chk(self.L.df_export_packed(self._h, C.c_void_p(manifest.data_ptr()), _ptr(blob), _stream()), self.L)
+        torch.cuda.current_stream().synchronize()
+        return manifest, blob
+
+    def import_packed(self, manifest, blob):
+        manifest = manifest.cpu().contiguous()
+        if blob.device != self.device:
+            blob = blob.to(self.device)
+        _chk(self.L.df_import_packed(self._h, C.c_void_p(manifest.data_ptr()), manifest.numel(), _ptr(blob), blob.numel(),
+                                     _stream()), self.L)
 
     # ---- network calls (all asynchronous on the current torch stream)
     def cond_encode(self, feats):

@@ -129,6 +129,12 @@ class LatentDiffusion:
         return [], unexpected
 
     def _upload(self):
+        eng = self._configure()
+        for k, v in self._state.items():
+            eng.load_tensor(k, v)
+        eng.finalize()
+
+    def _configure(self):
         eng = self.engine
         eng.config_unet(self.unet_cfg)
         eng.config_vae(self.vae_cfg, self.scale_factor)
@@ -139,9 +145,23 @@ class LatentDiffusion:
         eng.unet_out_channels = self.unet_cfg["out_channels"]
         eng.vae_out_ch = self.vae_cfg["out_ch"]
         eng.vae_n_mult = len(self.vae_cfg["ch_mult"])
-        for k, v in self._state.items():
-            eng.load_tensor(k, v)
-        eng.finalize()
+        return eng
+
+    # ---- multi-GPU weight distribution: the root rank packs once, the others import the packed operands ----------
+    def export_packed(self, batch_size, size_len=64, context_frames=32):
+        """(manifest, blob) of this model's packed operands for sampling ``batch_size`` clips (latent 16 x size_len,
+        ``context_frames`` CAVP frames): see include/df_engine.h, df_export_packed."""
+        return self._require().export_packed(batch_size, 16, size_len, context_frames)
+
+    def load_packed(self, manifest, blob):
+        """Counterpart of load_state_dict for non-root ranks: call after .cuda(); no fp32 checkpoint is needed."""
+        if self.engine is None:
+            raise RuntimeError("load_packed: call .cuda(device) first")
+        self._configure()
+        self.engine.import_packed(manifest, blob)
+        self.engine.finalize()
+        self._state = {}
+        return self
 
     def to(self, device):
         device = torch.device(device)

@@ -1,9 +1,11 @@
 """Multi-GPU plumbing: one process per GPU, batch-of-videos sharding, ONE weight broadcast at init.
 
 Every latent sample is independent for its whole trajectory, so the global batch is split
-contiguously over ranks and the step loop contains no collective.  The only exchange is the initial broadcast
-of the fp32 checkpoint from rank 0 as a single flat buffer (RCCL over xGMI when the backend is "nccl";
-"gloo" on CPU for the tests), after which each rank re-packs its own bf16 copy.
+contiguously over ranks and the step loop contains no collective.  The only exchange is at init: rank 0 packs the
+checkpoint ONCE into the engine's MFMA operand layouts and broadcasts that blob (``broadcast_packed_model``: 1.8 GB of
+operand-type weights + the small fp32 tensors, RCCL over xGMI when the backend is "nccl"); the other ranks import it --
+no fp32 master copies and no re-packing there.  ``broadcast_state_dict`` (the flat fp32 checkpoint, 3.8 GB) remains for
+tensors that are not part of a LatentDiffusion (e.g. the classifier) and for the gloo CPU tests.
 """
 import os
 from collections import OrderedDict
@@ -79,3 +81,39 @@ def gather_to_rank0(t, dst=0):
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     dist.gather(pad.contiguous(), bufs, dst=dst)
     return torch.cat([b[:k] for b, k in zip(bufs, sizes)]) if bufs is not None else None
+
+
+def broadcast_bytes(buf, src, device):
+    """Broadcast a uint8 tensor whose length only ``src`` knows (two collectives: size, payload)."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return buf
+    n = torch.tensor([buf.numel() if rank == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=src)
+    out = buf.to(device) if rank == src else torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(out, src=src)
+    return out
+
+
+def broadcast_packed_model(model, batch_size, src=0, size_len=64, context_frames=32):
+    """``model``: a LatentDiffusion that is on its device on every rank and holds the checkpoint on ``src`` only.
+    ``src`` packs for (batch_size, 16 x size_len latent, context_frames) and exports; everyone else imports.
+    Returns seconds spent in (pack + export, broadcast, import) on this rank."""
+    import time
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    dev = model.device
+    t0 = time.perf_counter()
+    manifest = blob = None
+    if rank == src:
+        manifest, blob = model.export_packed(batch_size, size_len, context_frames)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    manifest = broadcast_bytes(manifest, src, dev)
+    blob = broadcast_bytes(blob, src, dev)
+    torch.cuda.synchronize(dev)
+    t2 = time.perf_counter()
+    if rank != src:
+        model.load_packed(manifest, blob)
+    torch.cuda.synchronize(dev)
+    return dict(pack_export_s=t1 - t0, bcast_s=t2 - t1, import_s=time.perf_counter() - t2,
+                blob_bytes=int(blob.numel()), manifest_bytes=int(manifest.numel()))

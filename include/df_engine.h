@@ -129,6 +129,19 @@ int df_classifier_forward(df_ctx* ctx, const float* x_dev, const float* t_dev, c
 int df_classifier_grad(df_ctx* ctx, const float* x_dev, const float* t_dev, const float* feat_dev, float* prob_dev,
                        float* grad_dev, int B, int H, int W, int T, void* stream);
 
+/* ---- packed-operand blob (multi-GPU weight distribution; replaces SURVEY's df_bcast_weights: the RCCL
+ * communicator belongs to torch.distributed, so the library exports / imports and the host side broadcasts).
+ * Root rank: load tensors, df_finalize, df_prepack (builds every operand packing the UNet CFG-batch 2B / VAE / cond plans
+ * of this shape use), df_packed_size, df_export_packed.  Other ranks: df_create, df_config_*, df_import_packed(manifest,
+ * blob), df_finalize -- no fp32 master copies, no re-packing.  The manifest (host bytes) lists every tensor's shape, the
+ * small fp32 tensors that plans read directly (biases, norm parameters, pos_emb) and every packed operand with its
+ * offset into the blob (device bytes, 256-B aligned segments).  Operand type (bf16 / fp16 build) is checked on import. */
+int df_prepack(df_ctx* ctx, int B, int H, int W, int T);
+int df_packed_size(df_ctx* ctx, size_t* manifest_bytes, size_t* blob_bytes);
+int df_export_packed(df_ctx* ctx, void* manifest_host, void* blob_dev, void* stream);
+int df_import_packed(df_ctx* ctx, const void* manifest_host, size_t manifest_bytes, const void* blob_dev,
+                     size_t blob_bytes, void* stream);
+
 /* ---- sampler arithmetic on fp32 latents (n = number of elements) -------------------------------
  * e = e_u + scale*(e_c - e_u), e2 = [e_u ; e_c]                     (ddim.py:245, dpm_solver.py:1386) */
 int df_cfg_combine(const float* e2_dev, float* e_dev, int64_t n, float scale, void* stream);

@@ -280,11 +280,63 @@ def cavp():
         save(f"g7_cavp_{tag}.npz", feats=f, feats_raw=f_raw)
 
 
+def configs():
+    """G8: the single-GPU BASELINE configurations that no other fixture exercises at full size.
+    configs[2]: 50-step DPM-Solver++(2M) with the double-guidance classifier in the loop (CFG 4.5, classifier scale 50),
+                reference run at B=1 (sample 0 of the B=8 test batch: samples are independent).
+    configs[4] on one GPU: full SlowOnly-R50 on 32 frames of 224x224 -> get_learned_conditioning -> 25-step DDIM ->
+                decode_first_stage, for candidates 0 and 7 of the 8 candidates per video (x_T seeded by candidate index).
+    ~8 min on 8 CPU threads."""
+    t0 = time.time()
+    spec = synth.state_dict_spec()
+    sd = synth.make_state_dict(spec, 0)
+    model, ns = ref_import.build_reference_ldm(ref_import.load_ldm_config(), sd)
+    cspec = synth.classifier_spec(synth.CLS_FULL)
+    cls = ref_import.build_reference_classifier(dict(synth.CLS_FULL), synth.make_state_dict(cspec, 0))
+
+    class Wrap:
+        def __call__(self, x, t, video_feat):
+            return cls(x, context=video_feat, timesteps=t)
+    out = {}
+    with torch.no_grad():
+        # ---- configs[2], sample 0 of 8
+        feats33 = synth.synthetic_cavp(8, 33, 512, seed=4321)[:1]
+        c = model.get_learned_conditioning(feats33[:, :32])
+        uc = torch.zeros_like(c)
+        xT = synth.synthetic_xT(8, seed=21)[:1]
+        z, _ = model.sample_log_with_classifier_diff_sampler(
+            c, origin_cond=feats33, batch_size=1, sampler_name="DPM_Solver", ddim_steps=50, unconditional_guidance_scale=4.5,
+            unconditional_conditioning=uc, classifier=Wrap(), classifier_guide_scale=50.0, x_T=xT.clone())
+        out["c2_dpm50_cg_z0"] = z
+        out["c2_dpm50_cg_mel0"] = model.decode_first_stage(z)[:, 0]
+        print("configs[2]", time.time() - t0)
+        # ---- configs[4] chain on one GPU
+        CAVP_Inference = ref_import.import_reference_cavp()
+        m = CAVP_Inference("Slowonly_pool", "cnn14_pool", synth.CAVP_FULL["embed_dim"])
+        m.eval()
+        missing, unexpected = m.load_state_dict(synth.make_state_dict(synth.cavp_spec(synth.CAVP_FULL)), strict=False)
+        assert not unexpected
+        video = synth.synthetic_video(1, 32, 224, seed=78)
+        f = m.encode_video(video, normalize=True, pool=False)          # (1, 32, 512)
+        out["c4_cavp_feats"] = f
+        c = model.get_learned_conditioning(f)
+        uc = torch.zeros_like(c)
+        xT8 = synth.synthetic_xT(8, seed=21)
+        for k in (0, 7):
+            z, _ = model.sample_log_diff_sampler(c, 1, "DDIM", 25, unconditional_guidance_scale=4.5,
+                                                 unconditional_conditioning=uc, x_T=xT8[k:k + 1].clone())
+            out[f"c4_ddim25_z{k}"] = z
+            out[f"c4_ddim25_mel{k}"] = model.decode_first_stage(z)[:, 0]
+            print("configs[4] candidate", k, time.time() - t0)
+    save("g8_full_configs.npz", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiny", action="store_true")
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--cavp", action="store_true", help="CAVP video encoder vectors (reference topology, mmcv stand-in)")
+    ap.add_argument("--configs", action="store_true", help="G8: BASELINE configs[2] / configs[4] at full size (~8 min)")
     a = ap.parse_args()
     torch.set_num_threads(8)
     if a.tiny:
@@ -293,3 +345,5 @@ if __name__ == "__main__":
         full()
     if a.cavp:
         cavp()
+    if a.configs:
+        configs()

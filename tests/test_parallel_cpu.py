@@ -56,6 +56,13 @@ def _worker(rank, world, port, q):
     allv = parallel.gather_to_rank0(mine)
     if r == 0:
         ok = ok and torch.equal(allv.flatten(), torch.arange(6, dtype=torch.float32))
+    lo, hi = parallel.shard_range(5, r, w)                    # ragged: 3 + 2 samples
+    allv = parallel.gather_to_rank0(torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1, 1).repeat(1, 2, 3))
+    if r == 0:
+        ok = ok and allv.shape == (5, 2, 3) and torch.equal(allv[:, 0, 0], torch.arange(5, dtype=torch.float32))
+    payload = torch.arange(1000, dtype=torch.int64).to(torch.uint8) if r == 0 else None   # only src knows the length
+    got_b = parallel.broadcast_bytes(payload, 0, torch.device("cpu"))
+    ok = ok and got_b.numel() == 1000 and int(got_b[999]) == 999 % 256
     q.put((r, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
