@@ -129,6 +129,7 @@ class LatentDiffusion:
         return [], unexpected
 
     def _upload(self):
+        self._ctx_owner = None            # the engine forgets its cross-attention K/V when weights are (re)loaded
         eng = self._configure()
         for k, v in self._state.items():
             eng.load_tensor(k, v)

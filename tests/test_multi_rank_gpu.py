@@ -52,12 +52,18 @@ def _worker(rank, world, port, q):
         allm = parallel.gather_to_rank0(mel.cpu())
         ok, msg = True, ""
         if r == 0:
-            ref = _sample(m, 0, G, synth).cpu()                 # the same global batch on one rank
+            # (a) the same shards computed one after the other on ONE rank (same plan shape): bit-identical -- the result
+            #     of global sample i does not depend on which rank ran it, nor on the imported-vs-packed-locally weights
+            seq = torch.cat([_sample(m, *parallel.shard_range(G, k, w), synth).cpu() for k in range(w)])
+            same = torch.equal(allm, seq)
+            # (b) the whole global batch in one plan (other tiles -> other fp32 summation order, amplified by 6 CFG
+            #     steps of a random-weight net): sampler-trajectory tolerance of test_path_gpu.py
+            ref = _sample(m, 0, G, synth).cpu()
             err = float((allm - ref).norm() / ref.norm())
-            ok = allm.shape == ref.shape and err < 2e-3         # different batch -> different tiles -> fp32 summation order
+            ok = allm.shape == ref.shape and same and err < 5e-2
             msg = (f"2 ranks on one GPU: packed blob {info['blob_bytes'] / 1e6:.1f} MB + manifest {info['manifest_bytes'] / 1e3:.1f} KB, "
-                   f"pack+export {info['pack_export_s'] * 1e3:.0f} ms, bcast {info['bcast_s'] * 1e3:.0f} ms; "
-                   f"gathered mels vs 1-rank run rel-L2 {err:.2e}")
+                   f"pack+export {info['pack_export_s'] * 1e3:.0f} ms, bcast {info['bcast_s'] * 1e3:.0f} ms; gathered mels == "
+                   f"sequential shards on one rank: {same}; vs the global batch in one plan rel-L2 {err:.2e}")
         else:
             # the importing rank never saw an fp32 checkpoint: building a NEW packing there must fail loudly
             try:
