@@ -2631,6 +2631,58 @@ int df_test_linear_rows(const float* a, int lda, const float* tvals, int t_B, co
   });
 }
 
+// ONE block of the loaded UNet in isolation, against the reference's per-block tensors (golden G3): the plan builder's
+// own resblock / spatial_transformer / Downsample / Upsample code paths on caller-supplied NHWC fp32 activations.
+//   kind 0 ResBlock (semb = SiLU(time_embed(t)) [N][4*model_channels]), 1 SpatialTransformer (context [N][T][context_dim]),
+//   2 Downsample, 3 Upsample.  x [N*H*W][Cin] -> out [N*OH*OW][Cout], both NHWC fp32.
+int df_test_unet_block(df_ctx* c, const char* prefix, int kind, const float* x, const float* semb, const float* context,
+                       float* out, int N, int H, int W, int Cin, int Cout, int T, void* stream) {
+  return guard([&] {
+    if (!c->has_unet || !c->finalized) fail("df_test_unet_block: load and finalize a UNet first");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const df_unet_config& u = c->ucfg;
+    const std::string pre = "model.diffusion_model.", p = prefix;
+    Plan plan;
+    Builder b{c, &plan, pre, 0};
+    const int rows = N * H * W, temb = 4 * u.model_channels;
+    F32 xin{b.buf<float>((size_t)rows * Cin), rows, Cin, Cin};
+    HIPCHK(hipMemcpyAsync(xin.p, x, (size_t)rows * Cin * 4, hipMemcpyDeviceToDevice, s));
+    int orow = rows;
+    if (kind == 2) orow = rows / 4;
+    if (kind == 3) orow = rows * 4;
+    F32 dst{b.buf<float>((size_t)orow * Cout), orow, Cout, Cout};
+    if (kind == 0) {
+      float* E = b.buf<float>((size_t)N * Cout);
+      const bf16_t* w = c->w_linear(pre + p + ".emb_layers.1.weight");
+      const float* bb = c->f32(pre + p + ".emb_layers.1.bias");
+      b.other("t.embproj", [=](hipStream_t st, const RunArgs&) { return launch_linear_rows(semb, temb, w, bb, E, Cout, N, Cout, temb, 0, st); });
+      b.resblock(xin, dst, N, H, W, p + ".in_layers.0", p + ".in_layers.2", p + ".out_layers.0", p + ".out_layers.3",
+                 p + ".skip_connection", 1e-5f, E, Cout, 0);
+    } else if (kind == 1) {
+      const int Dc = u.context_dim, ldvtc = rup(T, 32);
+      bf16_t* ctxb = b.buf<bf16_t>((size_t)N * T * Dc);
+      const long n = (long)N * T * Dc;
+      b.other("ctx.cast", [=](hipStream_t st, const RunArgs&) { return launch_cast_bf16(context, ctxb, n, st); });
+      bf16_t *K, *Vt;
+      b.context_kv(ctxb, N, T, Dc, p, Cin, &K, &Vt, ldvtc);
+      b.spatial_transformer(xin, dst, N, H * W, p, u.num_heads, K, Vt, T, ldvtc);
+    } else {
+      bf16_t* hb = b.cast2d(xin);
+      const std::string wn = pre + p + (kind == 2 ? ".op" : ".conv");
+      GemmParams g = Builder::gp_conv3(hb, N, H, W, Cin, c->w_conv3(wn + ".weight", Cin), Cout, kind == 2 ? 2 : 1, kind == 3 ? 1 : 0);
+      Builder::out_f32(g, dst.p, Cout);
+      g.bias = c->f32(wn + ".bias");
+      b.gemm(g, 1, kind == 2 ? "down" : "up");
+    }
+    finish_plan(c, &plan);
+    RunArgs a;
+    run_ops(c, &plan, 0, plan.ops.size(), s, a);
+    HIPCHK(hipMemcpyAsync(out, dst.p, (size_t)orow * Cout * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  });
+}
+
 int df_test_conv3x3(const uint16_t* A, const uint16_t* W, const float* bias, float* C, int NB, int H, int Wd, int Cin,
                     int Cout, int stride, int ups, int tile, int splitk, void* stream) {
   return guard([&] {

@@ -83,6 +83,8 @@ _SIGS = {
     "df_test_ln_chain": [C.c_void_p] * 11 + [C.c_int] * 10 + [C.c_void_p],
     "df_test_linear_rows": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6
                            + [C.c_void_p],
+    "df_test_unet_block": [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6
+                          + [C.c_void_p],
     "df_test_conv3x3": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p],
     "df_test_groupnorm": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
                           C.c_void_p, C.c_void_p],
@@ -330,6 +332,22 @@ class Engine:
         _chk(self.L.df_classifier_grad(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(prob) if want_prob else None,
                                       _ptr(grad), B, H, W, feat.shape[1], _stream()), self.L)
         return (grad, prob) if want_prob else grad
+
+    def test_block(self, prefix, kind, x, semb=None, context=None, cout=None):
+        """One UNet block in isolation (df_test_unet_block): x NCHW fp32 -> NCHW fp32."""
+        x = _dev_f32(x, self.device)
+        N, Cin, H, W = x.shape
+        cout = Cin if cout is None else cout
+        OH, OW = (H // 2, W // 2) if kind == 2 else ((H * 2, W * 2) if kind == 3 else (H, W))
+        xin = x.permute(0, 2, 3, 1).contiguous()
+        out = torch.empty(N, OH, OW, cout, device=self.device, dtype=torch.float32)
+        semb = None if semb is None else _dev_f32(semb, self.device)
+        context = None if context is None else _dev_f32(context, self.device)
+        T = 0 if context is None else context.shape[1]
+        _chk(self.L.df_test_unet_block(self._h, prefix.encode(), kind, _ptr(xin), _ptr(semb) if semb is not None else None,
+                                       _ptr(context) if context is not None else None, _ptr(out), N, H, W, Cin, cout, T,
+                                       _stream()), self.L)
+        return out.permute(0, 3, 1, 2).contiguous()
 
     def profile_begin(self):
         _chk(self.L.df_profile_begin(self._h), self.L)

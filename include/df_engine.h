@@ -179,6 +179,11 @@ int df_test_ln_chain(const uint16_t* A0_dev, const uint16_t* W0_dev, const float
 int df_test_linear_rows(const float* a_dev, int lda, const float* tvals_dev, int t_B, const uint16_t* W_dev,
                         const float* bias_dev, float* out_dev, int ldo, int M, int N, int K, int act, int lds_variant,
                         void* stream);
+/* ONE block of the loaded UNet in isolation (checked against the reference's per-block tensors, golden G3): kind 0
+ * ResBlock (openai_unetmodel.py:255-275; semb = SiLU(time_embed(t))), 1 SpatialTransformer (attention_openai.py:250-261),
+ * 2 Downsample, 3 Upsample.  x [N*H*W][Cin] -> out [N*OH*OW][Cout], NHWC fp32; prefix e.g. "input_blocks.1.0". */
+int df_test_unet_block(df_ctx* ctx, const char* prefix, int kind, const float* x_dev, const float* semb_dev,
+                       const float* context_dev, float* out_dev, int N, int H, int W, int Cin, int Cout, int T, void* stream);
 int df_test_conv3x3(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, float* C_dev, int NB, int H,
                     int W, int Cin, int Cout, int stride, int ups, int tile, int splitk, void* stream);
 int df_test_groupnorm(const float* x_dev, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,

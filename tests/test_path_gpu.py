@@ -70,6 +70,30 @@ def test_tiny_small_latent_ops_golden(tiny):
     assert rel_l2(y, g["y"]) < FWD_TOL
 
 
+def test_tiny_per_block_vs_reference_tensors(tiny):
+    """G3 per block: the tensors the reference's forward hooks captured at the input and output of individual ResBlocks
+    (with / without skip conv, three resolutions), SpatialTransformers (64-, 8- and 2-token maps), a Downsample and an
+    Upsample, fed through the plan builder's code path for exactly that block (df_test_unet_block).  A regression in
+    one block shows up here under its own name instead of only in the end-to-end rel-L2."""
+    import torch.nn.functional as F
+    g = gold("g3_tiny_ops.npz")
+    eng = tiny.engine
+    worst = {}
+    for p in ("input_blocks.1.0", "input_blocks.4.0", "output_blocks.5.0"):
+        y = eng.test_block(p, 0, g[p + "__in"], semb=F.silu(g[p + "__in1"]), cout=g[p + "__out"].shape[1]).cpu()
+        worst[p] = rel_l2(y, g[p + "__out"])
+    for p in ("input_blocks.1.1", "middle_block.1", "output_blocks.5.1"):
+        y = eng.test_block(p, 1, g[p + "__in"], context=g[p + "__in1"]).cpu()
+        worst[p] = rel_l2(y, g[p + "__out"])
+    y = eng.test_block("input_blocks.3.0", 2, g["input_blocks.3.0__in"]).cpu()
+    worst["input_blocks.3.0 (down)"] = rel_l2(y, g["input_blocks.3.0__out"])
+    y = eng.test_block("output_blocks.2.1", 3, g["output_blocks.2.1__in"]).cpu()
+    worst["output_blocks.2.1 (up)"] = rel_l2(y, g["output_blocks.2.1__out"])
+    print("per-block rel-L2:", {k: f"{v:.2e}" for k, v in worst.items()})
+    for k, v in worst.items():
+        assert v < 1e-2, (k, v)          # one block, bf16 operands: well inside the whole-UNet tolerance of 2e-2
+
+
 def test_tiny_vae_and_cond_vs_golden(tiny):
     g = gold("g3_tiny_unet.npz")
     d = tiny.decode_first_stage(rnd((2, 4, 16, 64), 103).cuda()).cpu()
