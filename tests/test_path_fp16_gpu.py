@@ -123,7 +123,7 @@ def test_fp16_full_dpm50_and_classifier(P, full):
     cls.attach(full)
     x = rnd((2, 4, 16, 64), 205)
     vf = synth.synthetic_cavp(2, 33, 512, seed=4321)
-    p = cls(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda()).cpu()
+    p = cls(x.cuda(), t=torch.tensor([500.0, 37.0]).cuda(), video_feat=vf.cuda()).cpu()      # keywords, as ddim.py:338 calls it
     assert torch.allclose(p, g6["cls_p"], atol=3e-3), (p, g6["cls_p"])
     grad = cls.log_prob_grad(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda()).cpu()
     err = rel_l2(grad, g6["cls_grad"])

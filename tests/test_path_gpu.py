@@ -180,7 +180,7 @@ def test_tiny_classifier_forward_vs_golden(P, tiny):
     cls.attach(tiny)
     x = rnd((2, 4, 16, 64), 105)
     vf = synth.synthetic_cavp(2, 33, 64, seed=4321)
-    p = cls(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda()).cpu()
+    p = cls(x.cuda(), t=torch.tensor([500.0, 37.0]).cuda(), video_feat=vf.cuda()).cpu()      # keywords, as ddim.py:338 calls it
     assert p.shape == (2, 1)
     assert torch.allclose(p, g["cls_p"], atol=2e-2)
 
@@ -324,7 +324,7 @@ def test_full_classifier_forward_vs_golden(P, full):
     cls.attach(full)
     x = rnd((2, 4, 16, 64), 205)
     vf = synth.synthetic_cavp(2, 33, 512, seed=4321)
-    p = cls(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda()).cpu()
+    p = cls(x.cuda(), t=torch.tensor([500.0, 37.0]).cuda(), video_feat=vf.cuda()).cpu()      # keywords, as ddim.py:338 calls it
     assert torch.allclose(p, g["cls_p"], atol=2e-2), (p, g["cls_p"])
     grad = cls.log_prob_grad(x.cuda(), torch.tensor([500.0, 37.0]).cuda(), vf.cuda()).cpu()
     err = rel_l2(grad, g["cls_grad"])
