@@ -357,6 +357,24 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, bf16_t* __r
   }
 }
 
+// conv2 of a ResBlock with its 1x1 skip connection folded in: out[o] = [ conv taps (ky,kx,ci) : 9*I | skip weights : I2 ]
+__global__ void pack_conv_skip_kernel(const float* __restrict__ w, const float* __restrict__ ws, bf16_t* __restrict__ out,
+                                      int O, int I, int I2) {
+  const int KT = 9 * I + I2;
+  const long total = (long)O * KT;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % KT), o = (int)(e / KT);
+    float v;
+    if (k < 9 * I) {
+      const int tap = k / I, ci = k - tap * I;
+      v = w[((long)o * I + ci) * 9 + tap];
+    } else {
+      v = ws[(long)o * I2 + (k - 9 * I)];
+    }
+    out[e] = f2bf(v);
+  }
+}
+
 __global__ void pack_geglu_kernel(const float* __restrict__ w, const float* __restrict__ b,
                                   bf16_t* __restrict__ wout, float* __restrict__ bout, int half_rows, int K) {
   const long total = (long)2 * half_rows * K;
@@ -570,6 +588,12 @@ hipError_t launch_pack_conv_weight(const float* w, uint16_t* out, int O, int I, 
                                    hipStream_t s) {
   const long n = (long)O * KH * KW * Ipad;
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for(n)), dim3(256), 0, s, w, out, O, I, KH, KW, Ipad);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_conv_skip(const float* w, const float* ws, uint16_t* out, int O, int I, int I2, hipStream_t s) {
+  const long n = (long)O * (9 * I + I2);
+  hipLaunchKernelGGL(pack_conv_skip_kernel, dim3(grid_for(n)), dim3(256), 0, s, w, ws, out, O, I, I2);
   return hipGetLastError();
 }
 

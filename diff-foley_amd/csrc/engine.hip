@@ -233,6 +233,25 @@ struct df_ctx {
     packed[key] = o;
     return o;
   }
+  // conv2 + folded 1x1 skip connection: operand [O][9*I + I2] and the summed bias
+  void w_conv3_skip(const std::string& conv, const std::string& skip, const bf16_t** w, const float** b) {
+    const std::string kw = conv + ".weight#c3skip", kb = conv + ".bias#c3skip";
+    if (!packed.count(kw)) {
+      const RawT& t = rt(conv + ".weight");
+      const RawT& ts = rt(skip + ".weight");
+      const int O = (int)t.shape[0], I = (int)t.shape[1], I2 = (int)ts.shape[1];
+      bf16_t* wo = (bf16_t*)pmalloc((size_t)O * (9 * I + I2) * 2);
+      float* bo = (float*)pmalloc((size_t)O * 4);
+      HIPCHK(launch_pack_conv_skip(f32(conv + ".weight"), f32(skip + ".weight"), wo, O, I, I2, pack_stream));
+      const float* ins[2] = {f32(conv + ".bias"), f32(skip + ".bias")};
+      const float co[2] = {1.f, 1.f};
+      HIPCHK(launch_lincomb(bo, ins, co, 2, O, pack_stream));
+      packed[kw] = wo;
+      packed[kb] = bo;
+    }
+    *w = (const bf16_t*)packed[kw];
+    *b = (const float*)packed[kb];
+  }
   // Linear weights [O_j][I] stacked along O and transposed -> bf16 [I][sum O_j]  (backward-data operand)
   const bf16_t* w_stack_t(const std::string& key, const std::vector<std::string>& names) {
     auto it = packed.find(key);
@@ -511,7 +530,9 @@ struct Builder {
     F32 h1v{h1, M, cout, cout};
     bf16_t* a2 = groupnorm(h1v, NB, n2, eps, 1, nullptr);
     pl->release(h1);
-    if (has_skip) {
+    static const bool no_skipfold = getenv("DF_NO_SKIPFOLD") && atoi(getenv("DF_NO_SKIPFOLD"));
+    const bool fold_skip = has_skip && !no_skipfold && cin % 64 == 0;
+    if (has_skip && !fold_skip) {
       GemmParams g = gp_linear(xraw, M, cin, c->w_linear(nm(skip + ".weight")), cout);
       out_f32(g, out.p, out.ld);
       g.bias = c->f32(nm(skip + ".bias"));
@@ -522,10 +543,21 @@ struct Builder {
       GemmParams g = gp_conv3(a2, NB, H, Wd, cout, c->w_conv3(nm(c2 + ".weight"), cout), cout, 1, 0);
       out_f32(g, out.p, out.ld);
       g.bias = c->f32(nm(c2 + ".bias"));
-      if (has_skip) { g.res = out.p; g.ldr = out.ld; } else { g.res = x.p; g.ldr = x.ld; }
+      if (fold_skip) {
+        // skip(x) + conv2(h) as ONE implicit GEMM: the 1x1 skip conv is a tenth K range over the raw operand copy of x
+        const bf16_t* w;
+        const float* bsum;
+        c->w_conv3_skip(nm(c2), nm(skip), &w, &bsum);
+        g.W = w;
+        g.bias = bsum;
+        g.A2 = xraw; g.lda2 = cin; g.Cin2 = cin; g.a2_bytes = op_bytes((size_t)M * cin * 2);
+        g.K = 9 * cout + cin;
+        g.w_bytes = op_bytes((size_t)cout * g.K * 2);
+      } else if (has_skip) { g.res = out.p; g.ldr = out.ld; } else { g.res = x.p; g.ldr = x.ld; }
       attach_aux(g, M, cout);
       gemm(g, 1, "res.conv2");
     }
+    if (fold_skip) pl->release(xraw);
     pl->release(a2);
   }
 
@@ -1848,7 +1880,7 @@ struct TuneCand { int tile, sk; float iso_ms; double situ_ms; };
 static std::string tune_key(const Op& o) {
   const GemmParams& g = o.gp;
   char key[160];
-  const int epi = (g.ln_stats ? 1 : 0) | (g.stats ? 2 : 0) | (g.vt ? 4 : 0) | (g.aux ? 8 : 0) | (g.res ? 16 : 0);
+  const int epi = (g.ln_stats ? 1 : 0) | (g.stats ? 2 : 0) | (g.vt ? 4 : 0) | (g.aux ? 8 : 0) | (g.res ? 16 : 0) | (g.Cin2 ? 32 : 0);
   snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d_%d_e%d", g.M, g.N, g.K, g.taps, g.stride, g.ups, o.batch, g.geglu, epi);
   return key;
 }

@@ -18,6 +18,9 @@ struct GemmParams {
   unsigned a_bytes, w_bytes;   // bytes addressable from A / W of ONE batch slice (buffer-load bounds, < 2 GiB)
   int M, N, K;
   // implicit-conv geometry
+  // ResBlock skip connection folded into conv2 (openai_unetmodel.py:234-241, 275: skip(x) + h): a TENTH K range of
+  // Cin2 channels read from a second operand tensor at the centre pixel, K = 9*Cin + Cin2, W rows = [conv taps | skip]
+  const uint16_t* A2; int lda2; unsigned a2_bytes; int Cin2;
   int taps;    // 1 (linear / 1x1) or 9 (3x3, pad 1)
   int Cin;     // channels per tap, K = taps * Cin, Cin % 64 == 0
   int H, Wd;   // stored input spatial size

@@ -131,10 +131,12 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
       if (std::max(ring, stage) + (size_t)bm_ * p.ln_slots * 8 > 160 * 1024) return false;
     }
     if (p.stats && batch > 1) return false;
+    if (p.Cin2 > 0 && (p.taps != 9 || p.stride != 1 || p.ups || batch > 1 || (p.Cin2 & 63) != 0)) return false;
     if (splitk > 1 && (p.N & 3) != 0) return false;          // partial slabs are written and reduced as float4
     return splitk == 1 || (batch <= 1 && nk / splitk >= 2);
   }
   if (splitk > 1 && (p.N & 3) != 0) return false;
+  if (p.Cin2 > 0) return false;                 // the folded skip connection exists in the generic stride-1 kernel only
   if (p.taps != 9 || p.stride != 1 || p.ups != 0 || p.geglu || batch > 1) return false;
   int bm, bn, th, tw;
   gemm_tile_dims(tile, &bm, &bn);

@@ -431,11 +431,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   constexpr unsigned OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == 1 && p.A2 ? p.A2 : Ab), 0,
+                                                                          (int)(MODE == 1 && p.A2 ? p.a2_bytes : 0u), 0x00020000);
   const int r0 = tid >> 3;
   const int c8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;   // source chunk that lands in LDS slot (tid&7) of row r0+32i
   unsigned a_off[AP];   // MODE 0: byte offset of (row, chunk); MODE 1: byte offset of the centre-tap pixel;
                         // MODE 2: pixel index base n*H*W
   unsigned a_msk[AP];   // MODE 1: bit t set <=> tap t of this row reads inside the image
+  unsigned a_off2[AP];  // MODE 1 with a folded skip connection: byte offset of the centre pixel in the second tensor
   int a_iy[AP], a_ix[AP];
   const int UH = p.H << p.ups, UW = p.Wd << p.ups;
 #pragma unroll
@@ -443,6 +446,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     const int m = m0 + r0 + RPP * i;
     const bool mv = m < p.M;
     a_msk[i] = 0;
+    a_off2[i] = OOB;
     a_iy[i] = a_ix[i] = 0;
     if (MODE == 0) {
       a_off[i] = mv ? (unsigned)(((long)m * p.lda + c8) * 2) : OOB;
@@ -451,6 +455,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
       const int nb = m / ohw, rem = m - nb * ohw;
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
       if (MODE == 1) {
+        a_off2[i] = mv ? (unsigned)((((long)(nb * p.H + oy) * p.Wd + ox) * p.lda2 + c8) * 2) : OOB;
         a_off[i] = (unsigned)((((long)(nb * p.H + oy) * p.Wd + ox) * p.lda + c8) * 2);
         unsigned msk = 0;
 #pragma unroll
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   int d_tap = 0, d_cc = 0;       // conv: (tap, channel offset) of the NEXT tile to request, advanced incrementally
   if (MODE != 0) {
     const int k0 = kt0 * BK;
-    d_tap = k0 / p.Cin;
+    d_tap = min(k0 / p.Cin, 9);             // tap 9 = the folded skip connection's channel range
     d_cc = k0 - d_tap * p.Cin;
   }
   char* const dmaA = smem + wid * (8 * BK * 2);
@@ -498,12 +503,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
                                                  a_off[i] + kb, 0, 0, 0);                       \
     } else if (MODE == 1) {                                                                     \
-      const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                    \
-      const unsigned delta = (unsigned)((((ky - 1) * p.Wd + (kx - 1)) * p.lda + d_cc) * 2);     \
-      const unsigned bit = live ? (1u << d_tap) : 0u;                                           \
-      _Pragma("unroll") for (int i = 0; i < AP; ++i)                                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
-                                                 (a_msk[i] & bit) ? a_off[i] + delta : OOB, 0, 0, 0); \
+      if (d_tap < 9) {                                                                          \
+        const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                  \
+        const unsigned delta = (unsigned)((((ky - 1) * p.Wd + (kx - 1)) * p.lda + d_cc) * 2);   \
+        const unsigned bit = live ? (1u << d_tap) : 0u;                                         \
+        _Pragma("unroll") for (int i = 0; i < AP; ++i)                                          \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
+                                                   (a_msk[i] & bit) ? a_off[i] + delta : OOB, 0, 0, 0); \
+      } else {   /* folded skip: centre pixel of the second tensor (wave-uniform branch) */      \
+        const unsigned delta = (unsigned)(d_cc * 2);                                            \
+        _Pragma("unroll") for (int i = 0; i < AP; ++i)                                          \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
+                                                   (live && a_off2[i] != OOB) ? a_off2[i] + delta : OOB, 0, 0, 0); \
+      }                                                                                         \
     } else {                                                                                    \
       const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                    \
       _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                          \
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     }                                                                                           \
     if (MODE != 0) {                                                                            \
       d_cc += BK;                                                                               \
-      if (d_cc == p.Cin) {                                                                      \
+      if (d_cc == p.Cin && d_tap < 9) {                                                         \
         d_cc = 0;                                                                               \
         ++d_tap;                                                                                \
       }                                                                                         \

@@ -57,6 +57,8 @@ hipError_t launch_pack_conv_weight(const float* w, uint16_t* out, int O, int I, 
 hipError_t launch_pack_ln_linear(const float* w, const float* bias, const float* gamma, const float* beta,
                                  uint16_t* wout, float* cs, float* bb, int rows, int K, int row_off, int geglu_half,
                                  hipStream_t s);
+// conv3x3 OIHW + 1x1 skip weight [O][I2] -> operand rows [O][9*I + I2] (taps (ky,kx,ci), then the skip channels)
+hipError_t launch_pack_conv_skip(const float* w, const float* ws, uint16_t* out, int O, int I, int I2, hipStream_t s);
 hipError_t launch_pack_geglu(const float* w, const float* b, uint16_t* wout, float* bout, int half_rows, int K,
                              hipStream_t s);
 
