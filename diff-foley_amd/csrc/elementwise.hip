@@ -9,10 +9,20 @@ namespace {
 // registers -- PER float2 items per thread, loaded unconditionally from clamped addresses so all loads are in
 // flight together -- and read from memory exactly once; mean and the centred variance (two-pass, fp32) are
 // block reductions.  Large slabs (VAE, up to 1 MB) take the streaming 3-pass path.
+// Split-K input (GnSlabs::n > 0): x is the FIRST fp32 partial slab of the producing conv; the kernel sums the n slabs
+// (fixed order: deterministic) and adds the conv's bias and per-sample FiLM bias while loading -- the conv's reduce
+// launch and the fp32 round trip of its output disappear (the normalised operand is the only consumer of that tensor).
+struct GnSlabs {
+  int n;
+  long stride;                 // floats between consecutive slabs
+  const float* bias;           // [C] or null
+  const float* rowbias;        // [samples][ld_rowbias] or null
+  int ld_rowbias;
+};
 template <int PER>
 __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                     int silu, bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw) {
+                                     int silu, bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw, GnSlabs sl) {
   __shared__ float red[16];
   // block b runs on XCD b%8: put the 4 neighbouring groups that share 128-B lines of every pixel row on one XCD
   const int g = (blockIdx.x & 7) * 4 + (blockIdx.x >> 3), n = blockIdx.y;
@@ -29,6 +39,25 @@ __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW
     px[k] = ic / half;
     jj[k] = ic - px[k] * half;
     v[k] = *reinterpret_cast<const float2*>(xb + (long)px[k] * ld + 2 * jj[k]);
+  }
+  if (sl.n > 0) {
+    for (int sidx = 1; sidx < sl.n; ++sidx) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const float2 t = *reinterpret_cast<const float2*>(xb + sidx * sl.stride + (long)px[k] * ld + 2 * jj[k]);
+        v[k].x += t.x;
+        v[k].y += t.y;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int c = g * cpg + 2 * jj[k];
+      float bx = 0.f, by = 0.f;
+      if (sl.bias) { bx = sl.bias[c]; by = sl.bias[c + 1]; }
+      if (sl.rowbias) { bx += sl.rowbias[(long)n * sl.ld_rowbias + c]; by += sl.rowbias[(long)n * sl.ld_rowbias + c + 1]; }
+      v[k].x += bx;
+      v[k].y += by;
+    }
   }
 #pragma unroll
   for (int k = 0; k < PER; ++k)
@@ -469,14 +498,19 @@ inline int grid_for(long n, int block = 256, int cap = 4096) {
 
 }  // namespace
 
-hipError_t launch_groupnorm(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
-                            float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, hipStream_t s) {
+bool groupnorm_accepts_slabs(int HW, int C) { return C % 64 == 0 && (long)HW * (C / 64) <= 16384; }
+
+hipError_t launch_groupnorm_slabs(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
+                                  float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, int nslab,
+                                  long slab_stride, const float* bias, const float* rowbias, int ld_rowbias, hipStream_t s) {
   if (C % 64 != 0) return hipErrorInvalidValue;
   const int cpg = C / 32;
   const long items = (long)HW * (cpg / 2);
+  GnSlabs sl{nslab, slab_stride, bias, rowbias, ld_rowbias};
+  if (nslab > 0 && items > 16384) return hipErrorInvalidValue;     // the streaming kernel has no slab path
 #define DF_GN_REG(PER, THREADS)                                                                                     \
   hipLaunchKernelGGL(groupnorm_reg_kernel<PER>, dim3(32, N), dim3(THREADS), 0, s, x, ld, HW, C, cpg, gamma, beta, eps, \
-                     silu, out, ldo, raw_out)
+                     silu, out, ldo, raw_out, sl)
   if (items <= 256) DF_GN_REG(1, 256);
   else if (items <= 512) DF_GN_REG(2, 256);
   else if (items <= 1024) DF_GN_REG(2, 512);
@@ -489,6 +523,11 @@ hipError_t launch_groupnorm(const float* x, int ld, int N, int HW, int C, const 
                        ldo, raw_out);
 #undef DF_GN_REG
   return hipGetLastError();
+}
+
+hipError_t launch_groupnorm(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
+                            float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, hipStream_t s) {
+  return launch_groupnorm_slabs(x, ld, N, HW, C, gamma, beta, eps, silu, out, ldo, raw_out, 0, 0, nullptr, nullptr, 0, s);
 }
 
 hipError_t launch_layernorm(const float* x, int ld, int rows, int C, const float* gamma, const float* beta,

@@ -69,6 +69,7 @@ struct Op {
   GemmParams gp{};
   int tile = 0, batch = 1;
   bool c_ext = false;            // gp.C <- RunArgs.out at run time
+  bool defer = false;            // when tuned to split-K: leave the partial slabs to the next op (a GroupNorm that sums them)
   std::function<hipError_t(hipStream_t, const RunArgs&)> fn;
   const char* tag = "";
 };
@@ -527,8 +528,28 @@ struct Builder {
       gemm(g, 1, "res.conv1");
     }
     pl->release(a1);
-    F32 h1v{h1, M, cout, cout};
-    bf16_t* a2 = groupnorm(h1v, NB, n2, eps, 1, nullptr);
+    // h1 has ONE consumer, the second GroupNorm.  When conv1 runs split-K, its reduce launch is dropped: the norm sums
+    // the partial slabs while loading and adds the bias / FiLM bias itself (no reduce kernel, no fp32 round trip of h1).
+    static const bool no_defer = getenv("DF_NO_GNSLABS") && atoi(getenv("DF_NO_GNSLABS"));
+    const size_t ci = pl->ops.size() - 1;
+    const bool can_defer = !no_defer && groupnorm_accepts_slabs(H * Wd, cout);
+    pl->ops[ci].defer = can_defer;
+    bf16_t* a2 = buf<bf16_t>((size_t)M * cout);
+    {
+      Plan* plp = pl;
+      const float* gm = c->f32(nm(n2 + ".weight"));
+      const float* bt = c->f32(nm(n2 + ".bias"));
+      const float* cb = c->f32(nm(c1 + ".bias"));
+      const float* rb = emb ? emb + emb_col : nullptr;
+      const int HW = H * Wd;
+      other("groupnorm", [=](hipStream_t s, const RunArgs&) {
+        const Op& co = plp->ops[ci];
+        if (co.defer && co.gp.splitk > 1)
+          return launch_groupnorm_slabs(co.gp.partial, cout, NB, HW, cout, gm, bt, eps, 1, a2, cout, nullptr, co.gp.splitk,
+                                        (long)M * cout, cb, rb, emb_ld, s);
+        return launch_groupnorm(h1, cout, NB, HW, cout, gm, bt, eps, 1, a2, cout, nullptr, s);
+      });
+    }
     pl->release(h1);
     static const bool no_skipfold = getenv("DF_NO_SKIPFOLD") && atoi(getenv("DF_NO_SKIPFOLD"));
     const bool fold_skip = has_skip && !no_skipfold && cin % 64 == 0;
@@ -1850,6 +1871,7 @@ void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const
     if (o.is_gemm) {
       GemmParams g = o.gp;
       if (o.c_ext) g.C = a.out;
+      if (o.defer && g.splitk > 1) g.defer_reduce = 1;
       e = launch_gemm(g, o.tile, o.batch, s);
     } else {
       e = o.fn(s, a);
@@ -1880,7 +1902,8 @@ struct TuneCand { int tile, sk; float iso_ms; double situ_ms; };
 static std::string tune_key(const Op& o) {
   const GemmParams& g = o.gp;
   char key[160];
-  const int epi = (g.ln_stats ? 1 : 0) | (g.stats ? 2 : 0) | (g.vt ? 4 : 0) | (g.aux ? 8 : 0) | (g.res ? 16 : 0) | (g.Cin2 ? 32 : 0);
+  const int epi = (g.ln_stats ? 1 : 0) | (g.stats ? 2 : 0) | (g.vt ? 4 : 0) | (g.aux ? 8 : 0) | (g.res ? 16 : 0) | (g.Cin2 ? 32 : 0) |
+                  (o.defer ? 64 : 0);
   snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d_%d_e%d", g.M, g.N, g.K, g.taps, g.stride, g.ups, o.batch, g.geglu, epi);
   return key;
 }
@@ -2032,7 +2055,8 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
       const Op& o = pl->ops[i];
       if (!o.is_gemm || o.c_ext) continue;
       std::vector<TuneCand>& v = cands[tune_key(o)];
-      if (r < v.size()) v[r].situ_ms += best[i];
+      // a deferred split-K reduce is paid by the next op (the GroupNorm sums the slabs): judge the pair
+      if (r < v.size()) v[r].situ_ms += best[i] + ((o.defer && i + 1 < pl->ops.size()) ? best[i + 1] : 0.f);
     }
   }
   apply(-1);

@@ -56,6 +56,7 @@ struct GemmParams {
   int dbg;     // tools only: 1 = every K tile re-reads tile 0 (cache-resident operands; isolates memory latency)
   // split-K
   int splitk; float* partial;
+  int defer_reduce;   // split-K only: write the partial slabs and do NOT launch the reduce -- the consumer (GroupNorm) sums them
 };
 
 enum GemmTile {

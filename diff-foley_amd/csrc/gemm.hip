@@ -180,7 +180,7 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
   else if (mode == 1) e = launch_gemm_m1(tile_cfg, epi, p, zdim, stream);
   else e = launch_gemm_m2(tile_cfg, epi, p, zdim, stream);
   if (e != hipSuccess) return e;
-  if (p.splitk > 1) {
+  if (p.splitk > 1 && !p.defer_reduce) {
     const bool vec = !p.geglu && !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
                      (p.ld_rowbias & 3) == 0 && (p.ld_aux & 3) == 0;
     if (vec) {

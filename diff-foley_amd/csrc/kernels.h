@@ -8,6 +8,13 @@
 hipError_t launch_groupnorm(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
                             float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, hipStream_t s);
 
+// Same with a split-K producer: x = first fp32 partial slab [rows][ld] of the conv that feeds this norm; the kernel sums
+// nslab slabs (slab_stride floats apart) and adds the conv's bias / per-sample bias on the fly (nslab = 0: plain input).
+hipError_t launch_groupnorm_slabs(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
+                                  float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, int nslab,
+                                  long slab_stride, const float* bias, const float* rowbias, int ld_rowbias, hipStream_t s);
+bool groupnorm_accepts_slabs(int HW, int C);
+
 // LayerNorm over the last dim of fp32 [rows][ld] -> bf16 [rows][C]   (eps 1e-5, affine)
 hipError_t launch_layernorm(const float* x, int ld, int rows, int C, const float* gamma, const float* beta,
                             float eps, uint16_t* out, hipStream_t s);
