@@ -131,6 +131,115 @@ __global__ void groupnorm_kernel(const float* __restrict__ x, int ld, int HW, in
   }
 }
 
+// ------------------------------------------------------------------ GroupNorm for LARGE slabs (VAE decoder: up to
+// 128x512 px x 512 ch per sample).  The one-block-per-(group, sample) kernels above touch 40..64-B slivers of every
+// pixel row and occupy 32*N blocks; here the tensor is walked in pixel chunks with ALL channels (full 512..2048-B
+// rows, one float4 per thread), three launches:
+//   gn_chunk_stats:  per (chunk, sample): per-group (mean, M2) of the chunk, two passes over the chunk (the second
+//                    comes out of L2), written as partials -- numerically a chunked Welford, deterministic;
+//   gn_merge_stats:  per (sample, group): Chan merge of the chunk partials -> (mean, rstd);
+//   gn_chunk_apply:  normalise + affine [+ SiLU] -> operand type, same chunking.
+// HBM traffic: 2 reads + 1 operand-type write of the tensor instead of 3 strided reads.
+constexpr int GN_CHUNK_PX = 256;
+
+__global__ __launch_bounds__(256) void gn_chunk_stats_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
+                                                             float* __restrict__ part /*[N][chunks][32][2]*/) {
+  __shared__ float red[256 * 2];
+  const int n = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int q = C >> 2;                       // float4 lanes per pixel (32 | 64 | 128)
+  const int lane_c = threadIdx.x % q, lane_p = threadIdx.x / q, ppi = 256 / q;   // pixels per iteration
+  const int p0 = chunk * GN_CHUNK_PX, p1 = min(HW, p0 + GN_CHUNK_PX);
+  const float* xb = x + (long)n * HW * ld + lane_c * 4;
+  const int qpg = max(cpg >> 2, 1);           // float4 lanes per group (cpg = 4 | 8 | 16)
+  const int grp = lane_c / qpg;
+  float s = 0.f;
+  for (int p = p0 + lane_p; p < p1; p += ppi) {
+    const float4 v = *reinterpret_cast<const float4*>(xb + (long)p * ld);
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  // group sum of the chunk: every thread adds the q/… lanes of its group over all pixel lanes (<= 64 LDS reads)
+  float gs = 0.f;
+  for (int lp = 0; lp < ppi; ++lp)
+    for (int k = 0; k < qpg; ++k) gs += red[lp * q + grp * qpg + k];
+  const float cnt = (float)(p1 - p0) * (float)cpg;
+  const float mean = gs / cnt;
+  float m2 = 0.f;
+  for (int p = p0 + lane_p; p < p1; p += ppi) {
+    const float4 v = *reinterpret_cast<const float4*>(xb + (long)p * ld);
+    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+    m2 += (a * a + b * b) + (c * c + d * d);
+  }
+  __syncthreads();
+  red[threadIdx.x] = m2;
+  __syncthreads();
+  if (lane_p == 0 && (lane_c % qpg) == 0) {
+    float g2 = 0.f;
+    for (int lp = 0; lp < ppi; ++lp)
+      for (int k = 0; k < qpg; ++k) g2 += red[lp * q + grp * qpg + k];
+    float* o = part + (((long)n * nchunk + chunk) * 32 + grp) * 2;
+    o[0] = mean;
+    o[1] = g2;
+  }
+}
+
+__global__ __launch_bounds__(64) void gn_merge_stats_kernel(const float* __restrict__ part, int nchunk, int HW, int cpg,
+                                                            float eps, float* __restrict__ stat /*[N][32][2]*/) {
+  const int n = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+  // Chan merge of the chunk partials: lane l folds chunks l, l+64, ... (independent loads), then a fixed shuffle tree
+  // joins the 64 lanes -- the association order depends on nothing but nchunk, so the result is deterministic
+  float cnt = 0.f, mean = 0.f, m2 = 0.f;
+  for (int c = lane; c < nchunk; c += 64) {
+    const float* p = part + (((long)n * nchunk + c) * 32 + g) * 2;
+    const float nb = (float)(min(HW, (c + 1) * GN_CHUNK_PX) - c * GN_CHUNK_PX) * (float)cpg;
+    const float d = p[0] - mean, tot = cnt + nb;
+    mean += d * nb / tot;
+    m2 += p[1] + d * d * cnt * nb / tot;
+    cnt = tot;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float c2 = __shfl_down(cnt, o), mu2 = __shfl_down(mean, o), q2 = __shfl_down(m2, o);
+    const float tot = cnt + c2;
+    if (tot > 0.f) {
+      const float d = mu2 - mean;
+      mean += d * c2 / tot;
+      m2 += q2 + d * d * cnt * c2 / tot;
+    }
+    cnt = tot;
+  }
+  if (lane == 0) {
+    stat[((long)n * 32 + g) * 2] = mean;
+    stat[((long)n * 32 + g) * 2 + 1] = rsqrtf(m2 / cnt + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_chunk_apply_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ stat, int silu,
+                                                             bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw) {
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int q = C >> 2;
+  const int lane_c = threadIdx.x % q, lane_p = threadIdx.x / q, ppi = 256 / q;
+  const int p0 = chunk * GN_CHUNK_PX, p1 = min(HW, p0 + GN_CHUNK_PX);
+  const int c0 = lane_c * 4, grp = c0 / cpg;
+  const float mean = stat[((long)n * 32 + grp) * 2], rstd = stat[((long)n * 32 + grp) * 2 + 1];
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + c0), bt = *reinterpret_cast<const float4*>(beta + c0);
+  const float4 sc = make_float4(rstd * gm.x, rstd * gm.y, rstd * gm.z, rstd * gm.w);
+  const float4 sh = make_float4(bt.x - mean * sc.x, bt.y - mean * sc.y, bt.z - mean * sc.z, bt.w - mean * sc.w);
+  const float* xb = x + (long)n * HW * ld + c0;
+  bf16_t* ob = out + (long)n * HW * ldo + c0;
+  bf16_t* rb = raw ? raw + (long)n * HW * ldo + c0 : nullptr;
+  for (int p = p0 + lane_p; p < p1; p += ppi) {
+    const float4 v = *reinterpret_cast<const float4*>(xb + (long)p * ld);
+    float a = v.x * sc.x + sh.x, b = v.y * sc.y + sh.y, c = v.z * sc.z + sh.z, d = v.w * sc.w + sh.w;
+    if (silu) { a = silu_f(a); b = silu_f(b); c = silu_f(c); d = silu_f(d); }
+    *reinterpret_cast<uint2*>(ob + (long)p * ldo) = make_uint2(pack_bf2(a, b), pack_bf2(c, d));
+    if (rb) *reinterpret_cast<uint2*>(rb + (long)p * ldo) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+  }
+}
+
 // ------------------------------------------------------------------ LayerNorm -> bf16, one wave per row
 // C == 64 * NV exactly, so every lane issues its NV loads unconditionally (all in flight at once).
 template <int NV>
@@ -499,6 +608,27 @@ inline int grid_for(long n, int block = 256, int cap = 4096) {
 }  // namespace
 
 bool groupnorm_accepts_slabs(int HW, int C) { return C % 64 == 0 && (long)HW * (C / 64) <= 16384; }
+
+size_t groupnorm_scratch_bytes(int N, int HW, int C) {
+  const long items = (long)HW * (C / 64);
+  if (items <= 16384 || (C != 128 && C != 256 && C != 512)) return 0;      // register kernels / generic streaming kernel
+  const int nchunk = (HW + GN_CHUNK_PX - 1) / GN_CHUNK_PX;
+  return ((size_t)N * nchunk * 32 * 2 + (size_t)N * 32 * 2) * sizeof(float);
+}
+
+hipError_t launch_groupnorm_chunked(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
+                                    float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, float* scratch,
+                                    hipStream_t s) {
+  if ((C != 128 && C != 256 && C != 512) || (ld & 3) || (ldo & 3) || !scratch) return hipErrorInvalidValue;
+  const int cpg = C / 32, nchunk = (HW + GN_CHUNK_PX - 1) / GN_CHUNK_PX;
+  float* part = scratch;
+  float* stat = scratch + (size_t)N * nchunk * 32 * 2;
+  hipLaunchKernelGGL(gn_chunk_stats_kernel, dim3(nchunk, N), dim3(256), 0, s, x, ld, HW, C, cpg, part);
+  hipLaunchKernelGGL(gn_merge_stats_kernel, dim3(32, N), dim3(64), 0, s, part, nchunk, HW, cpg, eps, stat);
+  hipLaunchKernelGGL(gn_chunk_apply_kernel, dim3(nchunk, N), dim3(256), 0, s, x, ld, HW, C, cpg, gamma, beta, stat, silu, out,
+                     ldo, raw_out);
+  return hipGetLastError();
+}
 
 hipError_t launch_groupnorm_slabs(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
                                   float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, int nslab,

@@ -486,6 +486,15 @@ struct Builder {
     const float* b = c->f32(nm(p + ".bias"));
     const float* xp = x.p;
     const int ld = x.ld, HW = x.rows / NB, C = x.C;
+    const size_t sb = groupnorm_scratch_bytes(NB, HW, C);
+    if (sb) {          // large slabs (VAE decoder): pixel-chunked, fully coalesced three-launch form
+      float* scr = (float*)pl->alloc(sb);
+      other("groupnorm", [=](hipStream_t s, const RunArgs&) {
+        return launch_groupnorm_chunked(xp, ld, NB, HW, C, g, b, eps, silu, o, C, r, scr, s);
+      });
+      pl->release(scr);
+      return o;
+    }
     other("groupnorm", [=](hipStream_t s, const RunArgs&) {
       return launch_groupnorm(xp, ld, NB, HW, C, g, b, eps, silu, o, C, r, s);
     });
@@ -542,13 +551,17 @@ struct Builder {
       const float* cb = c->f32(nm(c1 + ".bias"));
       const float* rb = emb ? emb + emb_col : nullptr;
       const int HW = H * Wd;
+      const size_t sb = groupnorm_scratch_bytes(NB, HW, cout);
+      float* scr = sb ? (float*)pl->alloc(sb) : nullptr;
       other("groupnorm", [=](hipStream_t s, const RunArgs&) {
         const Op& co = plp->ops[ci];
         if (co.defer && co.gp.splitk > 1)
           return launch_groupnorm_slabs(co.gp.partial, cout, NB, HW, cout, gm, bt, eps, 1, a2, cout, nullptr, co.gp.splitk,
                                         (long)M * cout, cb, rb, emb_ld, s);
+        if (scr) return launch_groupnorm_chunked(h1, cout, NB, HW, cout, gm, bt, eps, 1, a2, cout, nullptr, scr, s);
         return launch_groupnorm(h1, cout, NB, HW, cout, gm, bt, eps, 1, a2, cout, nullptr, s);
       });
+      pl->release(scr);
     }
     pl->release(h1);
     static const bool no_skipfold = getenv("DF_NO_SKIPFOLD") && atoi(getenv("DF_NO_SKIPFOLD"));
@@ -2754,7 +2767,15 @@ int df_test_conv3x3(const uint16_t* A, const uint16_t* W, const float* bias, flo
 
 int df_test_groupnorm(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,
                       int silu, uint16_t* out, void* stream) {
-  return guard([&] { HIPCHK(launch_groupnorm(x, ld, N, HW, C, gamma, beta, eps, silu, out, C, nullptr, (hipStream_t)stream)); });
+  return guard([&] {
+    const size_t sb = groupnorm_scratch_bytes(N, HW, C);
+    if (sb) {
+      float* scr = test_partial(sb);
+      HIPCHK(launch_groupnorm_chunked(x, ld, N, HW, C, gamma, beta, eps, silu, out, C, nullptr, scr, (hipStream_t)stream));
+    } else {
+      HIPCHK(launch_groupnorm(x, ld, N, HW, C, gamma, beta, eps, silu, out, C, nullptr, (hipStream_t)stream));
+    }
+  });
 }
 int df_test_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, uint16_t* out, void* stream) {
   return guard([&] { HIPCHK(launch_layernorm(x, C, rows, C, gamma, beta, 1e-5f, out, (hipStream_t)stream)); });

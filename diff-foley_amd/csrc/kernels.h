@@ -15,6 +15,13 @@ hipError_t launch_groupnorm_slabs(const float* x, int ld, int N, int HW, int C, 
                                   long slab_stride, const float* bias, const float* rowbias, int ld_rowbias, hipStream_t s);
 bool groupnorm_accepts_slabs(int HW, int C);
 
+// Large slabs (VAE decoder, C in {128, 256, 512}, more than 16384 float2 per group): pixel-chunked three-launch form with
+// fully coalesced rows; `scratch` holds groupnorm_scratch_bytes(N, HW, C) bytes (0 = shape not handled: use launch_groupnorm).
+size_t groupnorm_scratch_bytes(int N, int HW, int C);
+hipError_t launch_groupnorm_chunked(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
+                                    float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, float* scratch,
+                                    hipStream_t s);
+
 // LayerNorm over the last dim of fp32 [rows][ld] -> bf16 [rows][C]   (eps 1e-5, affine)
 hipError_t launch_layernorm(const float* x, int ld, int rows, int C, const float* gamma, const float* beta,
                             float eps, uint16_t* out, hipStream_t s);

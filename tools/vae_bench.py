@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""decode_first_stage at B=4 a few times (for rocprofv3 --kernel-trace --stats and the --pmc traffic passes of the
+VAE decoder; BASELINE.json configs[1] decodes 4 clips per sample() call).  usage: python tools/vae_bench.py [reps]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import diff_foley_amd as P
+from diff_foley_amd import synth
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+m = P.LatentDiffusion(**P.stage2_config())
+m.load_state_dict(synth.make_state_dict(synth.state_dict_spec(), 0))
+m.cuda()
+m.autotune(True)
+z = synth.synthetic_xT(4).cuda()
+for _ in range(3):
+    m.decode_first_stage(z)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    m.decode_first_stage(z)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+print(f"vae decode B=4: {ms:.3f} ms  ({622.2 * 4 / ms:.1f} TFLOP/s algorithmic, {(0.0989 + 0.6096 * 4) / ms * 1e3:.0f} GB/s algorithmic)")
