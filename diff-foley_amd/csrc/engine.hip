@@ -2539,6 +2539,15 @@ int df_import_packed(df_ctx* c, const void* manifest_host, size_t manifest_bytes
   });
 }
 
+int df_frames_to_tensor(const uint8_t* frames, float* out, uint8_t* tmp, int T, int H, int W, int OH, int OW,
+                        const int32_t* bounds_w, const int32_t* coef_w, int ksize_w, const int32_t* bounds_h,
+                        const int32_t* coef_h, int ksize_h, void* stream) {
+  return guard([&] {
+    HIPCHK(launch_frames_to_tensor(frames, out, tmp, T, H, W, OH, OW, bounds_w, coef_w, ksize_w, bounds_h, coef_h, ksize_h,
+                                   (hipStream_t)stream));
+  });
+}
+
 int df_cfg_combine(const float* e2, float* e, int64_t n, float scale, void* stream) {
   return guard([&] { HIPCHK(launch_cfg_combine(e2, e, (long)n, scale, (hipStream_t)stream)); });
 }

@@ -118,3 +118,11 @@ hipError_t launch_pack_conv3d_bn(const float* w, const float* gamma, const float
                                  const float* var, float eps, uint16_t* out, float* bias, int O, int I, int KT, int KH,
                                  int KW, int KP, hipStream_t s);
 hipError_t launch_l2norm_rows(float* x, int rows, int C, hipStream_t s);
+
+// Frame pre-processing in front of the CAVP encoder (Extract_CAVP_Features.forward, demo_util.py:100-104, 150-151):
+// frames uint8 [T][H][W][3] RGB -> float [T][3][OH][OW] in [0,1] = torchvision Resize((OH,OW)) on a PIL image
+// (PIL.Image.resize BILINEAR, antialiased, 8-bit fixed point) + ToTensor(), bit-identical to Pillow.
+// bounds_* [out][2] = (first input index, taps), coef_* int32 [out][ksize] 22-bit fixed point; tmp uint8 [T][H][OW][3].
+hipError_t launch_frames_to_tensor(const uint8_t* frames, float* out, uint8_t* tmp, int T, int H, int W, int OH, int OW,
+                                   const int* bounds_w, const int* coef_w, int ksize_w, const int* bounds_h,
+                                   const int* coef_h, int ksize_h, hipStream_t s);

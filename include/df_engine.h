@@ -129,6 +129,16 @@ int df_classifier_forward(df_ctx* ctx, const float* x_dev, const float* t_dev, c
 int df_classifier_grad(df_ctx* ctx, const float* x_dev, const float* t_dev, const float* feat_dev, float* prob_dev,
                        float* grad_dev, int B, int H, int W, int T, void* stream);
 
+/* ---- video frame pre-processing in front of the CAVP encoder (Extract_CAVP_Features.forward, inference/demo_util.py:
+ * 100-104, 150-151): per frame torchvision Resize((OH, OW)) on a PIL image (= PIL.Image.resize BILINEAR: antialiased,
+ * 8-bit fixed point, horizontal pass then vertical pass) + ToTensor().  frames uint8 [T][H][W][3] RGB ->
+ * out fp32 [T][3][OH][OW] in [0, 1], bit-identical to Pillow.  bounds_* int32 [out][2] = (first input index, taps),
+ * coef_* int32 [out][ksize] 22-bit fixed-point filter weights (computed in double precision on the host:
+ * diff_foley_amd/video.py); tmp uint8 [T][H][OW][3] scratch.  All pointers device memory. */
+int df_frames_to_tensor(const uint8_t* frames_dev, float* out_dev, uint8_t* tmp_dev, int T, int H, int W, int OH, int OW,
+                        const int32_t* bounds_w_dev, const int32_t* coef_w_dev, int ksize_w, const int32_t* bounds_h_dev,
+                        const int32_t* coef_h_dev, int ksize_h, void* stream);
+
 /* ---- packed-operand blob (multi-GPU weight distribution; replaces SURVEY's df_bcast_weights: the RCCL
  * communicator belongs to torch.distributed, so the library exports / imports and the host side broadcasts).
  * Root rank: load tensors, df_finalize, df_prepack (builds every operand packing the UNet CFG-batch 2B / VAE / cond plans

@@ -280,6 +280,33 @@ def cavp():
         save(f"g7_cavp_{tag}.npz", feats=f, feats_raw=f_raw)
 
 
+def video_frames():
+    """G9: frame pre-processing of Extract_CAVP_Features (demo_util.py:100-104, 150-151).  The per-frame transform is
+    torchvision Resize + ToTensor on a PIL image, i.e. Pillow's antialiased BILINEAR resize; Pillow is installed here, so
+    the fixture holds PILLOW'S OWN outputs: full uint8 results for a small case and SHA-256 digests of the results for the
+    sizes the pipeline actually sees (360x640 and 1080x1920 sources -> 224x224)."""
+    import hashlib
+    from PIL import Image
+    out = {}
+
+    def frames(seed, T, H, W):
+        rng = np.random.default_rng(seed)
+        f = rng.integers(0, 256, (T, H, W, 3), dtype=np.uint8)
+        yy, xx = np.mgrid[0:H, 0:W]
+        f[0] = np.stack([(xx * 255 // max(W - 1, 1)), (yy * 255 // max(H - 1, 1)), ((xx + yy) % 256)], -1).astype(np.uint8)
+        return f
+    f = frames(900, 3, 90, 160)
+    out["small_90x160_to_64x64"] = np.stack([np.asarray(Image.fromarray(x).resize((64, 64), Image.BILINEAR)) for x in f])
+    for tag, (seed, T, H, W, oh, ow) in {"d360": (901, 2, 360, 640, 224, 224), "d1080": (902, 1, 1080, 1920, 224, 224),
+                                         "up": (903, 2, 100, 120, 224, 224), "same": (904, 1, 224, 224, 224, 224),
+                                         "tall": (905, 1, 480, 270, 224, 224)}.items():
+        f = frames(seed, T, H, W)
+        r = np.stack([np.asarray(Image.fromarray(x).resize((ow, oh), Image.BILINEAR)) for x in f])
+        out[f"sha_{tag}"] = np.frombuffer(hashlib.sha256(r.tobytes()).digest(), dtype=np.uint8)
+        out[f"spec_{tag}"] = np.array([seed, T, H, W, oh, ow])
+    save("g9_video_frames.npz", **out)
+
+
 def configs():
     """G8: the single-GPU BASELINE configurations that no other fixture exercises at full size.
     configs[2]: 50-step DPM-Solver++(2M) with the double-guidance classifier in the loop (CFG 4.5, classifier scale 50),
@@ -336,6 +363,7 @@ if __name__ == "__main__":
     ap.add_argument("--tiny", action="store_true")
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--cavp", action="store_true", help="CAVP video encoder vectors (reference topology, mmcv stand-in)")
+    ap.add_argument("--video", action="store_true", help="G9: frame pre-processing vectors (Pillow's own resize outputs)")
     ap.add_argument("--configs", action="store_true", help="G8: BASELINE configs[2] / configs[4] at full size (~8 min)")
     a = ap.parse_args()
     torch.set_num_threads(8)
@@ -345,5 +373,7 @@ if __name__ == "__main__":
         full()
     if a.cavp:
         cavp()
+    if a.video:
+        video_frames()
     if a.configs:
         configs()
