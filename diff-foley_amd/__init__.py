@@ -10,6 +10,7 @@ from . import engine  # noqa: F401
 from .ldm import LatentDiffusion, AlignmentClassifier, CAVPInference, instantiate_from_config  # noqa: F401
 from .samplers import DDIMSampler, PLMSSampler, DPMSolverSampler  # noqa: F401
 from .video import ExtractCAVPFeatures, frames_to_tensor  # noqa: F401
+from .vocoder import inverse_op, mel_to_wave  # noqa: F401
 
 
 def stage2_config(unet=None, vae=None, cond=None):

@@ -2548,6 +2548,19 @@ int df_frames_to_tensor(const uint8_t* frames, float* out, uint8_t* tmp, int T, 
   });
 }
 
+int df_mel_to_stft(const float* mel, int B, int n_mels, int T, const float* A, const float* At, const float* Pt, float inv_L,
+                   int iters, float* S, void* stream) {
+  return guard([&] { HIPCHK(launch_mel_to_stft(mel, B, n_mels, T, A, At, Pt, inv_L, iters, S, (hipStream_t)stream)); });
+}
+int df_griffinlim(const float* S, const float* phase0, int B, int T, int n_iter, float momentum, const float* twiddles,
+                  const float* window, const float* wss, float* angles, float* reb0, float* reb1, float* frames, float* wav,
+                  void* stream) {
+  return guard([&] {
+    HIPCHK(launch_griffinlim(S, phase0, B, T, n_iter, momentum, (const float2*)twiddles, window, wss, (float2*)angles,
+                             (float2*)reb0, (float2*)reb1, frames, wav, (hipStream_t)stream));
+  });
+}
+
 int df_cfg_combine(const float* e2, float* e, int64_t n, float scale, void* stream) {
   return guard([&] { HIPCHK(launch_cfg_combine(e2, e, (long)n, scale, (hipStream_t)stream)); });
 }

@@ -126,3 +126,15 @@ hipError_t launch_l2norm_rows(float* x, int rows, int C, hipStream_t s);
 hipError_t launch_frames_to_tensor(const uint8_t* frames, float* out, uint8_t* tmp, int T, int H, int W, int OH, int OW,
                                    const int* bounds_w, const int* coef_w, int ksize_w, const int* bounds_h,
                                    const int* coef_h, int ksize_h, hipStream_t s);
+
+// ---- mel -> waveform (csrc/vocoder.hip; inverse_op of inference/demo_util.py:196-211) ---------------------------------
+// NNLS inversion of the mel filterbank (librosa mel_to_stft, power 1) by FISTA: mel [B][NM][T] normalised log-mel ->
+// S [B][T][513] linear magnitude.  A [NM][513], At [513][NM], Pt [NM][513] = pinv(A)^T, inv_L = 1 / sigma_max(A)^2.
+hipError_t launch_mel_to_stft(const float* mel, int B, int NM, int T, const float* A, const float* At, const float* Pt,
+                              float inv_L, int iters, float* S, hipStream_t s);
+// Fast Griffin-Lim (librosa griffinlim: n_fft 1024, hop 256, hann, centre): S [B][T][513], phase0 [B][513][T] in [0,1)
+// (the rng.rand draw of init="random"), tw[512] = exp(-2 pi i k/1024), window[1024], wss[1024 + 256 (T-1)] window
+// sum-square; workspaces angles / reb0 / reb1 complex [B][T][513], frames [B][T][1024]; y [B][256 (T-1)] = the waveform.
+hipError_t launch_griffinlim(const float* S, const float* phase0, int B, int T, int n_iter, float momentum, const float2* tw,
+                             const float* window, const float* wss, float2* angles, float2* reb0, float2* reb1, float* frames,
+                             float* y, hipStream_t s);

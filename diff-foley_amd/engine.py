@@ -73,6 +73,9 @@ _SIGS = {
     "df_import_packed": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p],
     "df_frames_to_tensor": [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                                                   C.c_void_p, C.c_int, C.c_void_p],
+    "df_mel_to_stft": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p,
+                       C.c_void_p],
+    "df_griffinlim": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 9,
     "df_cfg_combine": [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p],
     "df_lincomb": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_void_p],
     "df_ddim_update": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,

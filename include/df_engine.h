@@ -139,6 +139,21 @@ int df_frames_to_tensor(const uint8_t* frames_dev, float* out_dev, uint8_t* tmp_
                         const int32_t* bounds_w_dev, const int32_t* coef_w_dev, int ksize_w, const int32_t* bounds_h_dev,
                         const int32_t* coef_h_dev, int ksize_h, void* stream);
 
+/* ---- mel -> waveform (inverse_op, inference/demo_util.py:196-211; algorithms of librosa 0.8.0, the
+ * reference's pinned dependency).  df_mel_to_stft: undo the log-mel normalisation and invert the mel filterbank by
+ * non-negative least squares (librosa.feature.inverse.mel_to_stft, power 1): mel [B][n_mels][T] -> S [B][T][513].
+ * A [n_mels][513] = librosa.filters.mel(22050, 1024, n_mels, 125, 7600), At its transpose, Pt [n_mels][513] = pinv(A)^T
+ * (the clipped least-squares start of librosa.util.nnls), inv_L = 1 / sigma_max(A)^2, iters FISTA iterations.
+ * df_griffinlim: librosa.griffinlim(S, hop_length=256): 32 fast Griffin-Lim iterations, momentum 0.99; phase0
+ * [B][513][T] uniform in [0,1) is the random initial phase; twiddles complex [512] exp(-2 pi i k/1024), window [1024]
+ * periodic hann, wss [1024 + 256 (T-1)] window sum-square; workspaces: angles / reb0 / reb1 complex [B][T][513], frames
+ * [B][T][1024]; wav [B][256 (T-1)].  All pointers device memory, all launches asynchronous on `stream`. */
+int df_mel_to_stft(const float* mel_dev, int B, int n_mels, int T, const float* A_dev, const float* At_dev,
+                   const float* Pt_dev, float inv_L, int iters, float* S_dev, void* stream);
+int df_griffinlim(const float* S_dev, const float* phase0_dev, int B, int T, int n_iter, float momentum,
+                  const float* twiddles_dev, const float* window_dev, const float* wss_dev, float* angles_dev,
+                  float* reb0_dev, float* reb1_dev, float* frames_dev, float* wav_dev, void* stream);
+
 /* ---- packed-operand blob (multi-GPU weight distribution; replaces SURVEY's df_bcast_weights: the RCCL
  * communicator belongs to torch.distributed, so the library exports / imports and the host side broadcasts).
  * Root rank: load tensors, df_finalize, df_prepack (builds every operand packing the UNet CFG-batch 2B / VAE / cond plans
