@@ -219,6 +219,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the second operand type and the in-bench golden check")
+    ap.add_argument("--no-vae", action="store_true", help="skip the VAE decode roofline block (profiling runs of the step only)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
                     help="MFMA operand type of the headline value (bf16 = BASELINE configs[1]; fp16 = libdfengine_f16.so)")
     ap.add_argument("--dump-ops", default="", help="write a per-op CSV of the instrumented pass")
@@ -294,7 +295,7 @@ def main():
             "kernel_launches_per_step": {k: int(v["launches"] // a.steps) for k, v in prof.items()},
             "plan": stats,
         }
-        if world == 1:
+        if world == 1 and not a.no_vae:
             out["vae_decode_roofline"] = vae_roofline(main_run["model"], dev, B)
         if world == 1 and not a.no_modes:
             # both MFMA operand types in ONE driver-run line: steps/s of the same workload + the north-star parity metric
