@@ -13,6 +13,7 @@
 //   attention V                     : bf16 transposed [N][C][T] (produced directly by a batched GEMM)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -139,6 +140,8 @@ struct df_ctx {
   std::map<std::string, int> emb_off[2];   // resblock prefix -> column offset in the fused emb projection
   int emb_total[2] = {0, 0};
   std::map<std::string, std::unique_ptr<Plan>> plans;
+  std::map<std::string, uint64_t> plan_tick;     // last use of every plan (least-recently-used eviction, DF_MAX_PLANS)
+  uint64_t tick = 0;
   Plan* last_unet = nullptr;
   int ctx_N = 0, ctx_T = 0;
   float* ctx_copy = nullptr;
@@ -2125,8 +2128,22 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
 
 Plan* get_plan(df_ctx* c, const std::string& key, const std::function<void(Plan*)>& build) {
   auto it = c->plans.find(key);
+  c->plan_tick[key] = ++c->tick;
   if (it != c->plans.end()) return it->second.get();
   if (!c->finalized) fail("df_finalize() has not been called");
+  // Plans own their workspaces (up to a few GB for large batches): a service that sees many (batch, latent, context)
+  // shapes must not grow without bound.  Beyond DF_MAX_PLANS (default 32) the least recently used plan is dropped.
+  static const size_t max_plans = getenv("DF_MAX_PLANS") ? (size_t)std::max(2, atoi(getenv("DF_MAX_PLANS"))) : 32;
+  while (c->plans.size() >= max_plans) {
+    auto victim = c->plans.end();
+    for (auto p = c->plans.begin(); p != c->plans.end(); ++p)
+      if (p->second.get() != c->last_unet && (victim == c->plans.end() || c->plan_tick[p->first] < c->plan_tick[victim->first]))
+        victim = p;
+    if (victim == c->plans.end()) break;
+    HIPCHK(hipDeviceSynchronize());               // the plan's buffers may still be read by queued launches
+    c->plan_tick.erase(victim->first);
+    c->plans.erase(victim);
+  }
   std::unique_ptr<Plan> p(new Plan());
   build(p.get());
   if (c->autotune) {
@@ -2573,6 +2590,18 @@ int df_ddim_update(const float* x, const float* e, const float* noise, float* x_
     const float dir = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
     HIPCHK(launch_ddim_update(x, e, noise, x_prev, pred_x0, (long)n, sqrtf(a_t), sqrt_one_minus_at, sqrtf(a_prev), dir,
                               sigma_t, (hipStream_t)stream));
+  });
+}
+
+int df_plan_count(df_ctx* c, int64_t* n_plans, int64_t* workspace_bytes) {
+  return guard([&] {
+    *n_plans = (int64_t)c->plans.size();
+    int64_t b = 0;
+    for (auto& kv : c->plans) {
+      for (auto& blk : kv.second->owned) b += (int64_t)blk.bytes;
+      b += (int64_t)kv.second->partial_bytes;
+    }
+    *workspace_bytes = b;
   });
 }
 

@@ -80,6 +80,7 @@ _SIGS = {
     "df_lincomb": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_void_p],
     "df_ddim_update": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                        C.c_float, C.c_float, C.c_void_p],
+    "df_plan_count": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "df_unet_plan_stats": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "df_profile_begin": [C.c_void_p],
     "df_profile_end": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
@@ -365,6 +366,11 @@ class Engine:
 
     def profile_dump(self, path):
         _chk(self.L.df_profile_dump(self._h, path.encode()), self.L)
+
+    def plan_count(self):
+        n, b = C.c_int64(), C.c_int64()
+        _chk(self.L.df_plan_count(self._h, C.byref(n), C.byref(b)), self.L)
+        return n.value, b.value
 
     def plan_stats(self):
         n, f, w = C.c_int64(), C.c_double(), C.c_double()

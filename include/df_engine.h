@@ -179,6 +179,9 @@ int df_ddim_update(const float* x_dev, const float* e_dev, const float* noise_de
                    void* stream);
 
 /* ---- introspection for bench.py / tests --------------------------------------------------------- */
+/* Plans (static launch lists + workspaces, one per (network, batch, latent, context) shape) currently cached and the bytes
+ * of HBM they own.  The cache is bounded: beyond DF_MAX_PLANS (env, default 32) the least recently used plan is dropped. */
+int df_plan_count(df_ctx* ctx, int64_t* n_plans, int64_t* workspace_bytes);
 /* Number of kernel launches of the last UNet plan executed and its algorithmic GEMM FLOPs. */
 int df_unet_plan_stats(df_ctx* ctx, int64_t* n_launches, double* gemm_flops, double* weight_bytes);
 /* Per-op-family HIP-event timing of everything executed between begin and end (events are recorded on the
