@@ -430,6 +430,18 @@ __global__ __launch_bounds__(256, MR <= 8 ? 4 : 2) void linear_rows_lds_kernel(c
   }
 }
 
+// operand-type variant: row n uses t[n % t_B] (CFG batch duplication folded in); feeds the MFMA time-embedding MLP
+__global__ void timestep_embedding_b16_kernel(const float* __restrict__ t, int t_B, bf16_t* __restrict__ out, int N, int dim) {
+  const int half = dim >> 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * half) return;
+  const int n = i / half, k = i - n * half;
+  const float f = expf(-9.210340371976184f * (float)k / (float)half);
+  const float a = t[n % t_B] * f;
+  out[(long)n * dim + k] = f2bf(cosf(a));
+  out[(long)n * dim + half + k] = f2bf(sinf(a));
+}
+
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int N, int dim) {
   const int half = dim >> 1;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -724,6 +736,12 @@ hipError_t launch_linear_rows_lds(const float* a, int lda, const float* tvals, i
   else if (M <= 8) DF_LRL(8)
   else DF_LRL(16)
 #undef DF_LRL
+  return hipGetLastError();
+}
+
+hipError_t launch_timestep_embedding_b16(const float* t, int t_B, uint16_t* out, int N, int dim, hipStream_t s) {
+  const int n = N * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_b16_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, t_B, out, N, dim);
   return hipGetLastError();
 }
 

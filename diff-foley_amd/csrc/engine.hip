@@ -1015,7 +1015,35 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
     }
     const bf16_t* w = c->w_stack(pre + "#embw", wn);
     const float* bb = c->b_stack(pre + "#embb", bn);
-    if (N <= 16) {
+    static const bool emb_mfma = !(getenv("DF_EMB_GEMV") && atoi(getenv("DF_EMB_GEMV")));
+    if (emb_mfma && mc % 64 == 0) {
+      // The time-embedding MLP and the stacked emb projections as three MFMA GEMMs (M = N rows, rows beyond M are
+      // out-of-bounds zero fill): the 52 MB emb weight stream goes through the LDS-DMA ring of the GEMM kernel at the HBM
+      // rate, where the GEMV kernels reach 0.9 TB/s.  Activations take the operand type here (they are O(1) sinusoids /
+      // SiLU outputs; the projections' fp32 results E are what the ResBlocks consume).
+      bf16_t* teb = b.buf<bf16_t>((size_t)N * mc);
+      bf16_t* e1b = b.buf<bf16_t>((size_t)N * temb);
+      bf16_t* seb = b.buf<bf16_t>((size_t)N * temb);
+      b.other("t.embed", [=](hipStream_t s, const RunArgs& a) { return launch_timestep_embedding_b16(a.t, B_ext, teb, N, mc, s); });
+      {
+        GemmParams g = Builder::gp_linear(teb, N, mc, w0, temb);
+        Builder::out_b16(g, e1b, temb);
+        g.bias = b0; g.silu = 1;
+        b.gemm(g, 1, "t.mlp0");
+      }
+      {
+        GemmParams g = Builder::gp_linear(e1b, N, temb, w2, temb);
+        Builder::out_b16(g, seb, temb);
+        g.bias = b2; g.silu = 1;          // emb is only ever consumed through SiLU (emb_layers = SiLU -> Linear)
+        b.gemm(g, 1, "t.mlp2");
+      }
+      {
+        GemmParams g = Builder::gp_linear(seb, N, temb, w, etot);
+        Builder::out_f32(g, E, etot);
+        g.bias = bb;
+        b.gemm(g, 1, "t.embproj");
+      }
+    } else if (N <= 16) {
       // three weight-streaming launches: [timestep embedding (CFG duplication folded in) -> Linear -> SiLU] (LDS-staged
       // activations), [Linear -> SiLU] (emb is only ever consumed through SiLU: emb_layers = SiLU -> Linear), and the
       // stacked emb_layers projections of all ResBlocks (register kernel: measured faster for the 52 MB stream)
@@ -1918,7 +1946,7 @@ struct TuneCand { int tile, sk; float iso_ms; double situ_ms; };
 static std::string tune_key(const Op& o) {
   const GemmParams& g = o.gp;
   char key[160];
-  const int epi = (g.ln_stats ? 1 : 0) | (g.stats ? 2 : 0) | (g.vt ? 4 : 0) | (g.aux ? 8 : 0) | (g.res ? 16 : 0) | (g.Cin2 ? 32 : 0) |
+  const int epi = (g.silu ? 128 : 0) | (g.ln_stats ? 1 : 0) | (g.stats ? 2 : 0) | (g.vt ? 4 : 0) | (g.aux ? 8 : 0) | (g.res ? 16 : 0) | (g.Cin2 ? 32 : 0) |
                   (o.defer ? 64 : 0);
   snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d_%d_e%d", g.M, g.N, g.K, g.taps, g.stride, g.ups, o.batch, g.geglu, epi);
   return key;

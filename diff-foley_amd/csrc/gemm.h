@@ -37,6 +37,7 @@ struct GemmParams {
   const float* rowbias; int ld_rowbias; int rows_per_sample; int rowbias_mode;  // 1: by sample, 2: by position
   const float* res; long res_bs; int ldr;   // fp32 residual, may alias C
   int relu;                          // max(v, 0) after bias / residual (CAVP encoder ConvModule activation)
+  int silu;                          // v * sigmoid(v) after bias (time-embedding MLP layers); LEAN / ANY epilogues
   uint16_t* aux; int ld_aux;         // optional second output: operand-type copy of the stored value, [row][ld_aux]
   int geglu;                         // columns come in (x:32 | gate:32) groups, output width N/2
   // LayerNorm folded into this GEMM (A = raw operand copy of x, W = gamma-scaled weights):

@@ -169,7 +169,7 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
   else if (p.stats) epi = EPI_PROD;
   else if (!vec || p.relu || p.aux || p.alpha != 1.f) epi = EPI_ANY;
   else epi = EPI_LEAN;
-  if ((epi == EPI_GEGLU || epi == EPI_LNC || epi == EPI_PROD) && (p.taps != 1 || p.alpha != 1.f || p.relu || !vec))
+  if ((epi == EPI_GEGLU || epi == EPI_LNC || epi == EPI_PROD) && (p.taps != 1 || p.alpha != 1.f || p.relu || p.silu || !vec))
     return hipErrorInvalidValue;
   if (epi == EPI_LNC && (!p.ln_stats || p.aux)) return hipErrorInvalidValue;
   hipError_t e;

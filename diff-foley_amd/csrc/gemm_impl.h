@@ -318,6 +318,9 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       const float4 b = *reinterpret_cast<const float4*>(&p.res[(long)batch * p.res_bs + (long)rc * p.ldr + cc]);    \
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
     }                                                                                                               \
+    if (!((FL) & (2 | 4)) && p.silu) {                                                                              \
+      v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);                                   \
+    }                                                                                                               \
     if (((FL) & 1) && p.relu) {                                                                                     \
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);                   \
     }                                                                                                               \

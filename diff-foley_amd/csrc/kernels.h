@@ -51,6 +51,9 @@ hipError_t launch_linear_rows_lds(const float* a, int lda, const float* tvals, i
 // Sinusoidal timestep embedding [cos | sin] (util.py:151-171), t fp32 (may be fractional) -> [N][dim] fp32
 hipError_t launch_timestep_embedding(const float* t, float* out, int N, int dim, hipStream_t s);
 
+// Same as operand-type rows [N][dim]; row n embeds t[n % t_B] (CFG batch duplication)
+hipError_t launch_timestep_embedding_b16(const float* t, int t_B, uint16_t* out, int N, int dim, hipStream_t s);
+
 // NCHW fp32 latent -> NHWC bf16 padded to cpad channels.  `rep` copies of the batch are written back to
 // back (rep=2 builds the CFG batch cat([x, x])).  Optional affine pre-1x1 conv (VAE post_quant_conv):
 // y = Wpq * (x * in_scale) + bpq.
