@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds the engine (gfx950) in-tree, twice from the same sources:
-#   diff-foley_amd/libdfengine.so      bf16 MFMA operands (default)
-#   diff-foley_amd/libdfengine_f16.so  fp16 MFMA operands (-DDF_OPERAND_F16)
+#   diff_foley_amd/libdfengine.so      bf16 MFMA operands (default)
+#   diff_foley_amd/libdfengine_f16.so  fp16 MFMA operands (-DDF_OPERAND_F16)
 set -e
 cd "$(dirname "$0")"
 # -amdgpu-mfma-vgpr-form: MFMA accumulators live in architectural VGPRs (gfx950 has a unified register file), which

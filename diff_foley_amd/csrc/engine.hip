@@ -2460,11 +2460,21 @@ int df_unet_forward_cfg(df_ctx* c, const float* x, const float* t, float* out, i
 int df_vae_decode(df_ctx* c, const float* z, float* out, int B, int H, int W, void* stream) {
   return guard([&] {
     if (!c->has_vae) fail("vae not configured");
-    Plan* p = get_plan(c, keyf("vae_%d_%d_%d", B, H, W), [&](Plan* pl) { build_vae(c, pl, B, H, W); });
-    RunArgs a;
-    a.x = z;
-    a.out = out;
-    run_ops(c, p, 0, p->ops.size(), (hipStream_t)stream, a);
+    // One GEMM operand is addressed with 32-bit buffer offsets (< 2 GiB): the decoder's widest activation is
+    // 8 x H x 8 x W pixels x 2*ch channels per sample, so large batches run as slices of at most `chunk` samples through
+    // the plan of that size (same kernels, same results; no host round trip between slices).
+    const size_t per_sample = (size_t)(H << (c->vcfg.n_mult - 1)) * (W << (c->vcfg.n_mult - 1)) * (size_t)c->vcfg.ch * 2 * 2;
+    int chunk = (int)std::max<size_t>(1, (((size_t)1 << 31) - 1) / std::max<size_t>(per_sample, 1));
+    chunk = std::min(chunk, 16);
+    const int zc = c->vcfg.z_channels, up = 1 << (c->vcfg.n_mult - 1);
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+      const int nb = std::min(chunk, B - b0);
+      Plan* p = get_plan(c, keyf("vae_%d_%d_%d", nb, H, W), [&](Plan* pl) { build_vae(c, pl, nb, H, W); });
+      RunArgs a;
+      a.x = z + (size_t)b0 * zc * H * W;
+      a.out = out + (size_t)b0 * c->vcfg.out_ch * (H * up) * (W * up);
+      run_ops(c, p, 0, p->ops.size(), (hipStream_t)stream, a);
+    }
   });
 }
 

@@ -110,7 +110,7 @@ def lib(precision=None):
     if precision not in _libs:
         path = os.environ.get("DF_LIB_OVERRIDE") or LIB_PATHS[precision]      # tools: A/B against another build
         if not os.path.exists(path):
-            raise RuntimeError(f"{path} not found: build it with diff-foley_amd/csrc/build.sh "
+            raise RuntimeError(f"{path} not found: build it with diff_foley_amd/csrc/build.sh "
                                "(there is no CPU/torch fallback for the sampling path)")
         L = C.CDLL(path)
         for name, args in _SIGS.items():

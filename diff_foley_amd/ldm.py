@@ -222,12 +222,8 @@ class LatentDiffusion:
     def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):
         if predict_cids:
             raise NotImplementedError("VQ code-book decoding is not on the path (AutoencoderKL first stage)")
-        eng = self._require()
-        # the decoder's widest activation is 128x512 px x 256 ch per sample; one GEMM operand is addressed with 32-bit
-        # offsets (< 2 GiB), so large batches go through the engine in chunks of 16 samples (same plan, same results)
-        if z.shape[0] <= 16:
-            return eng.vae_decode(z)
-        return torch.cat([eng.vae_decode(z[i:i + 16]) for i in range(0, z.shape[0], 16)])
+        # any batch size: df_vae_decode slices batches above 16 samples itself (2 GiB operand addressing, include/df_engine.h)
+        return self._require().vae_decode(z)
 
     @torch.no_grad()
     def sample(self, cond, batch_size=16, return_intermediates=False, x_T=None, verbose=True, timesteps=None,

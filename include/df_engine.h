@@ -4,7 +4,7 @@
  * The reference (luosiallen/Diff-Foley) has NO FFI/plugin boundary: the hot path is a tree of
  * torch.nn modules driven from Python.  Each entry point below replaces one Python-level call
  * of the reference; the reference-side binding a maintainer would add is the ctypes stub shown
- * in INTEGRATION.md (and implemented in diff-foley_amd/engine.py).
+ * in INTEGRATION.md (and implemented in diff_foley_amd/engine.py).
  *
  * Conventions
  *   - every function returns 0 on success, non-zero on failure; df_last_error() gives the message
@@ -115,7 +115,8 @@ int df_unet_forward_cfg(df_ctx* ctx, const float* x_dev, const float* t_dev, flo
                         float guidance_scale, void* stream);
 
 /* ---- LatentDiffusion.decode_first_stage (ddpm.py:739-797 -> autoencoder.py:330-333 -> model.py:630-663)
- * z [B][z_channels][H][W] fp32 -> out [B][out_ch][H*2^(n_mult-1)][W*2^(n_mult-1)] fp32 */
+ * z [B][z_channels][H][W] fp32 -> out [B][out_ch][H*2^(n_mult-1)][W*2^(n_mult-1)] fp32.  Any B: batches whose widest
+ * activation would exceed the 2 GiB operand addressing (B > 16 at the full decoder) run as slices inside this call. */
 int df_vae_decode(df_ctx* ctx, const float* z_dev, float* out_dev, int B, int H, int W, void* stream);
 
 /* ---- Alignment classifier forward (alignment_classifier.py:269-271 -> alignment_backbone.py:656-686)

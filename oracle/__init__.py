@@ -3,7 +3,7 @@
 This package is a plain torch-fp32 *restatement* of the reference algorithm
 (file:line citations in every function).  It exists to check the HIP path:
 only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
-leg may import it.  The product package (``diff-foley_amd/``) never imports it
+leg may import it.  The product package (``diff_foley_amd/``) never imports it
 and has no CPU fallback.
 
 Pinning: the reference ships no tests, so the oracle is

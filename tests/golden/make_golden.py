@@ -3,7 +3,7 @@
 
 Runs ONLY in the build container: it imports the reference implementation from
 /root/reference (via oracle/ref_import.py stubs) on CPU, feeds it procedurally
-generated weights (diff-foley_amd/synth.py) and seeded inputs, and stores the
+generated weights (diff_foley_amd/synth.py) and seeded inputs, and stores the
 reference's *outputs* as small .npz fixtures next to this script.  Inputs are
 regenerated from seeds by the tests; no reference source is copied.
 
