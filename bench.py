@@ -105,7 +105,15 @@ def golden_mel_mae(model, dev):
                                          unconditional_conditioning=torch.zeros_like(c), x_T=xT)
     mel = model.decode_first_stage(z)[:, 0].cpu().numpy()
     ref = g["ddim25_mel_21"]
-    return dict(mel_mae=float(np.abs(mel - ref).mean()), mel_range=float(ref.max() - ref.min()), mel_std=float(ref.std()),
+    mae = float(np.abs(mel - ref).mean())
+    span = float(ref.max() - ref.min())
+    # same bound as tests/test_path_gpu.py::test_full_ddim25_mel_mae: MAE below 1e-3 of the mel range of this
+    # random-weight model (training mels live in [0, 1]); a regression in any kernel of the path shows up here
+    ok = mae / span < 1e-3
+    if not ok:
+        print(f"bench.py: PARITY REGRESSION -- mel MAE {mae:.3e} over a range of {span:.2f} exceeds 1e-3 of the range",
+              file=sys.stderr, flush=True)
+    return dict(mel_mae=mae, mel_range=span, mel_std=float(ref.std()), parity_ok=bool(ok),
                 z_rel_l2=float(np.linalg.norm(z.cpu().numpy() - g["ddim25_z_21"]) / np.linalg.norm(g["ddim25_z_21"])))
 
 

@@ -2729,6 +2729,25 @@ int df_test_gemm(const uint16_t* A, const uint16_t* W, float* C, int M, int N, i
   });
 }
 
+// The GEMM with its simple epilogue features switched on: bias, residual, activation (1 = SiLU, 2 = ReLU), fp32 or
+// operand-type output, with and without split-K -- every tile must give the same answer for every combination.
+int df_test_gemm_epi(const uint16_t* A, const uint16_t* W, const float* bias, const float* res, void* C, int M, int N, int K,
+                     int act, int out_operand, int tile, int splitk, void* stream) {
+  return guard([&] {
+    GemmParams g = Builder::gp_linear(A, M, K, W, N);
+    if (out_operand) Builder::out_b16(g, (bf16_t*)C, N);
+    else Builder::out_f32(g, (float*)C, N);
+    g.bias = bias;
+    if (res) { g.res = res; g.ldr = N; }
+    g.silu = act == 1;
+    g.relu = act == 2;
+    g.splitk = splitk;
+    if (splitk > 1) g.partial = test_partial((size_t)splitk * M * N * 4);
+    if (!gemm_tile_valid(g, tile, 1, splitk)) fail("tile %d / split-K %d refused this problem", tile, splitk);
+    HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
+  });
+}
+
 // Producer GEMM (t0 = A0 W0^T + b0 [+ t0_in], fp32 + operand copy + per-row partial statistics) followed by a
 // LayerNorm-folded consumer GEMM (y = LN(t0; gamma, beta) W1^T + b1), exactly the pair the SpatialTransformer plan uses.
 // mode 0: y fp32 [M][N1];  mode 1: GEGLU (W1 = [x ; gate] rows, y operand-type [M][N1/2]);  mode 2: fused QKV --

@@ -95,6 +95,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
       const float4 b = *reinterpret_cast<const float4*>(&p.res[(long)row * p.ldr + col]);
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
     }
+    if (p.silu && !p.ln_stats && !p.stats) {      // same rule as the in-kernel epilogue (gemm_impl.h DF_EPI_LOOP)
+      v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w);
+    }
     if (p.relu) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }

@@ -64,6 +64,7 @@ __device__ __forceinline__ float epi_bias(const GemmParams& p, int row, int col,
 }
 
 __device__ __forceinline__ void epi_store(const GemmParams& p, int z, int row, int col, int nout, float v) {
+  if (p.silu) v = silu_f(v);
   if (p.relu) v = fmaxf(v, 0.f);
   if (p.aux) p.aux[(long)row * p.ld_aux + col] = f2bf(v);
   long idx;

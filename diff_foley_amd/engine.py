@@ -85,6 +85,8 @@ _SIGS = {
     "df_profile_begin": [C.c_void_p],
     "df_profile_end": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "df_profile_dump": [C.c_void_p, C.c_char_p],
+    "df_test_gemm_epi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                         C.c_int, C.c_int, C.c_int, C.c_void_p],
     "df_test_gemm": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "df_test_ln_chain": [C.c_void_p] * 11 + [C.c_int] * 10 + [C.c_void_p],
     "df_test_linear_rows": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6

@@ -194,6 +194,9 @@ int df_profile_end(df_ctx* ctx, double* ms_by_family, int64_t* count_by_family);
 /* CSV (tag,M,N,K,taps,stride,ups,batch,tile,splitk,ms) of every op of the region last closed by df_profile_end. */
 int df_profile_dump(df_ctx* ctx, const char* path);
 /* Run ONE op family in isolation for unit tests (see tests/test_kernels_gpu.py). */
+int df_test_gemm_epi(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, const float* res_dev, void* C_dev,
+                     int M, int N, int K, int act /*0 none, 1 SiLU, 2 ReLU*/, int out_operand, int tile, int splitk,
+                     void* stream);
 int df_test_gemm(const uint16_t* A_dev, const uint16_t* W_dev, float* C_dev, int M, int N, int K, int tile, int splitk,
                  void* stream);
 /* SpatialTransformer GEMM pair: producer (fp32 t0 + operand copy + per-row partial statistics from the epilogue) and

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import torch
 
-import diff_foley_amd  # noqa: F401  (import shim)
+import diff_foley_amd  # noqa: F401
 from diff_foley_amd import synth
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")

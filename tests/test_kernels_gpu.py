@@ -79,6 +79,32 @@ def test_gemm(tile, M, N, K, splitk):
     assert rel_l2(c.cpu(), ref.cpu()) < 2e-3
 
 
+@pytest.mark.parametrize("tile", [0, 3, 4, 8, 13])
+@pytest.mark.parametrize("splitk", [1, 4])
+@pytest.mark.parametrize("act,res,out_operand", [(0, 0, 0), (1, 0, 0), (1, 0, 1), (2, 0, 0), (0, 1, 0), (1, 1, 1), (2, 1, 0)])
+def test_gemm_epilogue_times_splitk(tile, splitk, act, res, out_operand):
+    """Every simple epilogue feature (bias, residual, SiLU / ReLU, operand-type output) must give the same answer from the
+    in-kernel epilogue and from the split-K reduce kernel (round 2: SiLU was missing from the reduce, only the autotuned
+    time-embedding GEMM ever took that path)."""
+    E = _eng()
+    M, N, K = 72, 320, 1280
+    a = bf(rnd((M, K), 11)).cuda()
+    w = bf(rnd((N, K), 12) / K ** 0.5).cuda()
+    bias = rnd((N,), 13).cuda()
+    r = rnd((M, N), 14).cuda() if res else None
+    c = torch.full((M, N), float("nan"), device="cuda", dtype=odt() if out_operand else torch.float32)
+    rc = E.lib(PREC).df_test_gemm_epi(ptr(a), ptr(w), ptr(bias), ptr(r) if res else None, ptr(c), M, N, K, act, out_operand,
+                                      tile, splitk, stream())
+    assert rc == 0, E.lib(PREC).df_last_error()
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().t() + bias
+    if res:
+        ref = ref + r
+    ref = F.silu(ref) if act == 1 else (F.relu(ref) if act == 2 else ref)
+    assert torch.isfinite(c.float()).all()
+    assert rel_l2(c.float().cpu(), ref.cpu()) < (6e-3 if out_operand else 2e-3)
+
+
 @pytest.mark.parametrize("tile", [0, 1, 3, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16])
 @pytest.mark.parametrize("NB,H,W,Cin,Cout,stride,ups,splitk", [
     (2, 16, 64, 128, 96, 1, 0, 2), (8, 2, 8, 256, 64, 1, 0, 4), (3, 4, 16, 64, 192, 1, 0, 1), (1, 16, 16, 64, 64, 1, 0, 1),

@@ -332,6 +332,26 @@ def test_full_classifier_forward_vs_golden(P, full):
     assert err < 5e-2
 
 
+def test_full_autotuned_plans_vs_golden(full):
+    """The product (bench.py, the notebook path) runs AUTOTUNED plans: at full size the tuner reaches tile / split-K
+    combinations no untuned plan uses (e.g. split-K on the SiLU-epilogue time-embedding GEMMs), so the goldens are checked
+    through a freshly tuned engine as well."""
+    g = gold("g4_full_unet.npz")
+    full.autotune(True)
+    full.engine.finalize()              # drop the untuned plans of the earlier tests
+    try:
+        x, c = rnd((2, 4, 16, 64), 200), rnd((2, 32, 768), 201)
+        y = full.apply_model(x.cuda(), torch.tensor([961, 41]).cuda(), c.cuda()).cpu()
+        err = rel_l2(y, g["unet_y"])
+        print(f"autotuned full UNet forward: rel-L2 {err:.3e}")
+        assert err < FWD_TOL
+        d = full.decode_first_stage(rnd((1, 4, 16, 64), 202).cuda()).cpu()
+        assert rel_l2(d[:, 0], g["decode"]) < FWD_TOL
+    finally:
+        full.autotune(False)
+        full.engine.finalize()
+
+
 def test_tiny_autotuned_plans_match_untuned(P):
     """The on-device autotuner (isolated ranking + in-situ refinement, engine.hip autotune_plan) only changes tile /
     split-K choices: an autotuned engine must reproduce the golden vectors for every plan type."""

@@ -37,7 +37,7 @@ def steady(rows, marker, steps):
     return rows[idx[-steps - 1]:idx[-1]], steps
 
 
-marker = sys.argv[4] if len(sys.argv) > 4 else "linear_rows_lds_kernel"
+marker = sys.argv[4] if len(sys.argv) > 4 else "timestep_embedding_b16_kernel"
 out = {"note": "bytes per launch = 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes, dispatches of the last full steps only",
        "marker_kernel": marker}
 per_kernel = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
