@@ -7,7 +7,8 @@
 //
 //   nnls_fista_kernel   per tile of 16 frames: x >= 0 minimising |A x - b|^2 by FISTA (projected gradient with Nesterov
 //                       momentum, step 1/L), started from the clipped least-squares solution like librosa; x, the
-//                       momentum point and the residual live in LDS, A / A^T stream from L2 every iteration.
+//                       momentum point and the residual live in LDS; both products walk only the non-zero spans of the
+//                       banded mel filterbank (~1000 of 65 664 entries).
 //                       (librosa drives the same objective with L-BFGS-B; the minimiser of this under-determined problem
 //                       is not unique, so the two agree in the residual, not element by element -- oracle/vocoder.py.)
 //   gl_ifft_kernel      one frame per block: spectrum = S * angles, Hermitian extension, radix-2 FFT in LDS, window.
@@ -21,6 +22,7 @@
 namespace {
 
 constexpr int NFFT = 1024, NBIN = NFFT / 2 + 1, HOPV = 256, TT = 16, FPAD = 516;
+constexpr int NNLS_NT = 1024;      // 16 wavefronts per 16-frame tile: the iteration is a chain of short dependent loops, latency-bound
 
 // ---- in-LDS radix-2 FFT of 1024 complex points, 256 threads; input already in bit-reversed order; tw[k] = exp(-2 pi i k / 1024)
 __device__ __forceinline__ void fft1024(float2* s, const float2* __restrict__ tw, int tid, float sgn) {
@@ -45,7 +47,7 @@ __device__ __forceinline__ void fft1024(float2* s, const float2* __restrict__ tw
 __device__ __forceinline__ int brev10(int i) { return (int)(__brev((unsigned)i) >> 22); }
 
 // ---- NNLS by FISTA on tiles of TT frames.  mel [B][NM][T] (normalised log-mel) ; A [NM][F] ; At [F][NM] ; Pt [NM][F] = pinv(A)^T
-__global__ __launch_bounds__(256) void nnls_fista_kernel(const float* __restrict__ mel, int NM, int T, const float* __restrict__ A,
+__global__ __launch_bounds__(NNLS_NT) void nnls_fista_kernel(const float* __restrict__ mel, int NM, int T, const float* __restrict__ A,
                                                          const float* __restrict__ At, const float* __restrict__ Pt,
                                                          float inv_L, int iters, float* __restrict__ S /*[B][T][NBIN]*/) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void nnls_fista_kernel(const float* __restrict
   float* bm = r + NM * TT;                // [NM][TT]     linear-amplitude mel of this tile
   const int tid = threadIdx.x, t0 = blockIdx.x * TT, b = blockIdx.y;
   const float* melb = mel + (long)b * NM * T;
-  for (int e = tid; e < NM * TT; e += 256) {
+  for (int e = tid; e < NM * TT; e += NNLS_NT) {
     const int m = e / TT, tt = e - m * TT;
     const int t = min(t0 + tt, T - 1);
     const float v = melb[(long)m * T + t];
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void nnls_fista_kernel(const float* __restrict
   }
   __syncthreads();
   // x0 = max(pinv(A) b, 0)
-  for (int k = tid; k < NBIN; k += 256) {
+  for (int k = tid; k < NBIN; k += NNLS_NT) {
     float acc[TT];
 #pragma unroll
     for (int j = 0; j < TT; ++j) acc[j] = 0.f;
@@ -75,52 +77,56 @@ __global__ __launch_bounds__(256) void nnls_fista_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < TT; ++j) x[k * TT + j] = yv[k * TT + j] = fmaxf(acc[j], 0.f);
   }
+  // The mel filterbank is banded: a triangular filter touches 2..16 neighbouring FFT bins and a bin belongs to at most two
+  // filters, i.e. ~1000 of the 128 x 513 entries are non-zero.  Every block derives the non-zero span of each row and each
+  // column from A itself (any matrix works; a dense one just has full spans) and both products of an iteration walk spans
+  // only: 33x less work than the dense products, same summation order over the non-zeros (bit-identical result).
+  __shared__ short klo[128], khi[128], mlo[FPAD], mhi[FPAD];
+  {
+    const int lane = tid & 63, w = tid >> 6;
+    for (int m = w; m < NM; m += NNLS_NT / 64) {                     // one wavefront per row, coalesced along k
+      int lo = NBIN, hi = 0;
+      for (int k = lane; k < NBIN; k += 64)
+        if (A[(long)m * NBIN + k] != 0.f) { lo = min(lo, k); hi = max(hi, k + 1); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+      if (lane == 0) { klo[m] = (short)min(lo, hi); khi[m] = (short)hi; }
+    }
+    for (int k = tid; k < NBIN; k += NNLS_NT) {               // one thread per column, coalesced across threads
+      int lo = NM, hi = 0;
+      for (int m = 0; m < NM; ++m)
+        if (A[(long)m * NBIN + k] != 0.f) { lo = min(lo, m); hi = m + 1; }
+      mlo[k] = (short)min(lo, hi); mhi[k] = (short)hi;
+    }
+  }
   float tn = 1.f;
-  const int m_own = tid & 127, tg = tid >> 7;          // residual rows: thread (m, 8-frame half)
   for (int it = 0; it < iters; ++it) {
     __syncthreads();
-    if (m_own < NM) {
-      float acc[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-      for (int k = 0; k < NBIN; ++k) {
-        const float a = At[(long)k * NM + m_own];
-        const float4 y0 = *reinterpret_cast<const float4*>(&yv[k * TT + tg * 8]);
-        const float4 y1 = *reinterpret_cast<const float4*>(&yv[k * TT + tg * 8 + 4]);
-        acc[0] += a * y0.x; acc[1] += a * y0.y; acc[2] += a * y0.z; acc[3] += a * y0.w;
-        acc[4] += a * y1.x; acc[5] += a * y1.y; acc[6] += a * y1.z; acc[7] += a * y1.w;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) r[m_own * TT + tg * 8 + j] = acc[j] - bm[m_own * TT + tg * 8 + j];
+    for (int e = tid; e < NM * TT; e += NNLS_NT) {            // residual r = A y - b over the row spans
+      const int m = e / TT, j = e - m * TT;
+      float acc = 0.f;
+      const float* Am = A + (long)m * NBIN;
+      for (int k = klo[m]; k < khi[m]; ++k) acc += Am[k] * yv[k * TT + j];
+      r[e] = acc - bm[e];
     }
     __syncthreads();
     const float tnext = 0.5f * (1.f + sqrtf(1.f + 4.f * tn * tn));
     const float beta = (tn - 1.f) / tnext;
-    for (int k = tid; k < NBIN; k += 256) {
-      float g[TT];
-#pragma unroll
-      for (int j = 0; j < TT; ++j) g[j] = 0.f;
-      for (int m = 0; m < NM; ++m) {
-        const float a = A[(long)m * NBIN + k];
-#pragma unroll
-        for (int j4 = 0; j4 < TT; j4 += 4) {
-          const float4 rv = *reinterpret_cast<const float4*>(&r[m * TT + j4]);
-          g[j4] += a * rv.x; g[j4 + 1] += a * rv.y; g[j4 + 2] += a * rv.z; g[j4 + 3] += a * rv.w;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TT; ++j) {
-        const float xo = x[k * TT + j];
-        const float xn = fmaxf(yv[k * TT + j] - inv_L * g[j], 0.f);
-        x[k * TT + j] = xn;
-        yv[k * TT + j] = xn + beta * (xn - xo);
-      }
+    for (int e = tid; e < NBIN * TT; e += NNLS_NT) {          // gradient A^T r over the column spans, projected step, momentum
+      const int k = e / TT, j = e - k * TT;
+      float g = 0.f;
+      const float* Ak = At + (long)k * NM;
+      for (int m = mlo[k]; m < mhi[k]; ++m) g += Ak[m] * r[m * TT + j];
+      const float xo = x[e];
+      const float xn = fmaxf(yv[e] - inv_L * g, 0.f);
+      x[e] = xn;
+      yv[e] = xn + beta * (xn - xo);
     }
     tn = tnext;
   }
   __syncthreads();
   float* Sb = S + ((long)b * T + t0) * NBIN;
-  for (int e = tid; e < TT * NBIN; e += 256) {
+  for (int e = tid; e < TT * NBIN; e += NNLS_NT) {
     const int tt = e / NBIN, k = e - tt * NBIN;
     if (t0 + tt < T) Sb[(long)tt * NBIN + k] = x[k * TT + tt];
   }
@@ -212,7 +218,7 @@ hipError_t launch_mel_to_stft(const float* mel, int B, int NM, int T, const floa
     if (e != hipSuccess) return e;
     attr = lds;
   }
-  hipLaunchKernelGGL(nnls_fista_kernel, dim3((T + TT - 1) / TT, B), dim3(256), lds, s, mel, NM, T, A, At, Pt, inv_L, iters, S);
+  hipLaunchKernelGGL(nnls_fista_kernel, dim3((T + TT - 1) / TT, B), dim3(NNLS_NT), lds, s, mel, NM, T, A, At, Pt, inv_L, iters, S);
   return hipGetLastError();
 }
 
