@@ -778,6 +778,60 @@ hipError_t launch_pack_conv_weight(const float* w, uint16_t* out, int O, int I, 
   return hipGetLastError();
 }
 
+namespace {
+// FeedForward's second Linear followed by proj_out (attention_openai.py:86-98, 261) is ONE linear map of (h, t):
+//   proj_out(t + W2 h + b2) = (Wp W2) h + Wp t + (Wp b2 + bp)
+// packed as the operand [C][4C | C] = [Wp.W2 | Wp] (fp32 product, rounded once) and the fp32 bias Wp.b2 + bp.
+__global__ __launch_bounds__(256) void pack_ffproj_kernel(const float* __restrict__ Wp /*[C][C]*/,
+                                                          const float* __restrict__ W2 /*[C][F]*/, bf16_t* __restrict__ out /*[C][F+C]*/,
+                                                          int C, int F) {
+  __shared__ float sa[32][33], sb[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  if (j0 >= F) {                                   // the Wp columns: plain operand-type copy
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(long)(i0 + ty + 8 * r) * (F + C) + j0 + tx] = f2bf(Wp[(long)(i0 + ty + 8 * r) * C + (j0 - F) + tx]);
+    return;
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < C; k0 += 32) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sa[ty + 8 * r][tx] = Wp[(long)(i0 + ty + 8 * r) * C + k0 + tx];
+      sb[ty + 8 * r][tx] = W2[(long)(k0 + ty + 8 * r) * F + j0 + tx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+      const float b = sb[kk][tx];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += sa[ty + 8 * r][kk] * b;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[(long)(i0 + ty + 8 * r) * (F + C) + j0 + tx] = f2bf(acc[r]);
+}
+__global__ __launch_bounds__(256) void ffproj_bias_kernel(const float* __restrict__ Wp, const float* __restrict__ b2,
+                                                          const float* __restrict__ bp, float* __restrict__ out, int C) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wavefront per output
+  if (i >= C) return;
+  float a = 0.f;
+  for (int k = lane; k < C; k += 64) a += Wp[(long)i * C + k] * b2[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if (lane == 0) out[i] = a + bp[i];
+}
+}  // namespace
+
+hipError_t launch_pack_ffproj(const float* Wp, const float* bp, const float* W2, const float* b2, uint16_t* wout, float* bout,
+                              int C, int F, hipStream_t s) {
+  if (C % 32 != 0 || F % 32 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_ffproj_kernel, dim3((F + C) / 32, C / 32), dim3(256), 0, s, Wp, W2, wout, C, F);
+  hipLaunchKernelGGL(ffproj_bias_kernel, dim3((C + 3) / 4), dim3(256), 0, s, Wp, b2, bp, bout, C);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_conv_skip(const float* w, const float* ws, uint16_t* out, int O, int I, int I2, hipStream_t s) {
   const long n = (long)O * (9 * I + I2);
   hipLaunchKernelGGL(pack_conv_skip_kernel, dim3(grid_for(n)), dim3(256), 0, s, w, ws, out, O, I, I2);

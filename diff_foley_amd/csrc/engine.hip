@@ -256,6 +256,24 @@ struct df_ctx {
     *w = (const bf16_t*)packed[kw];
     *b = (const float*)packed[kb];
   }
+  // FeedForward's second Linear merged with the SpatialTransformer's proj_out (1x1 conv): operand [C][4C + C], summed bias
+  void w_ffproj(const std::string& ff2, const std::string& po, const bf16_t** w, const float** b) {
+    const std::string kw = ff2 + ".weight#ffproj", kb = ff2 + ".bias#ffproj";
+    if (!packed.count(kw)) {
+      const RawT& t2 = rt(ff2 + ".weight");
+      const RawT& tp = rt(po + ".weight");
+      const int C = (int)t2.shape[0], F = (int)t2.shape[1];
+      if ((int)tp.shape[0] != C || (int)tp.shape[1] != C) fail("ffproj: proj_out is not %dx%d", C, C);
+      bf16_t* wo = (bf16_t*)pmalloc((size_t)C * (F + C) * 2);
+      float* bo = (float*)pmalloc((size_t)C * 4);
+      HIPCHK(launch_pack_ffproj(f32(po + ".weight"), f32(po + ".bias"), f32(ff2 + ".weight"), f32(ff2 + ".bias"), wo, bo, C, F,
+                                pack_stream));
+      packed[kw] = wo;
+      packed[kb] = bo;
+    }
+    *w = (const bf16_t*)packed[kw];
+    *b = (const float*)packed[kb];
+  }
   // Linear weights [O_j][I] stacked along O and transposed -> bf16 [I][sum O_j]  (backward-data operand)
   const bf16_t* w_stack_t(const std::string& key, const std::vector<std::string>& names) {
     auto it = packed.find(key);
@@ -812,6 +830,31 @@ struct Builder {
       ln_fold(g, cs, bb);
       g.geglu = 1;
       gemm(g, 1, "st.ff1");
+    }
+    static const bool no_ffproj = getenv("DF_NO_FFPROJ") && atoi(getenv("DF_NO_FFPROJ"));
+    if (!no_ffproj && C % 64 == 0) {
+      // FF's second Linear, the residual add and proj_out are ONE linear map of (h, t): proj_out(t + W2 h + b2) =
+      // (Wp W2) h + Wp t + (Wp b2 + bp).  One GEMM with K = 4C + C over two A tensors -- the GEGLU output and the operand
+      // copy of the residual stream -- with the same FLOPs as the pair it replaces and one launch fewer per block.
+      const bf16_t* w;
+      const float* bsum;
+      c->w_ffproj(nm(tb + ".ff.net.2"), nm(p + ".proj_out"), &w, &bsum);
+      GemmParams g = gp_linear(gl, M, 4 * C, w, C);
+      g.K = 5 * C;
+      g.w_bytes = op_bytes((size_t)C * 5 * C * 2);
+      g.A2 = xb; g.lda2 = C; g.Cin2 = C; g.a2_bytes = op_bytes((size_t)M * C * 2);
+      out_f32(g, out.p, out.ld);
+      g.bias = bsum;
+      g.res = x.p; g.ldr = x.ld;
+      attach_aux(g, M, C);
+      gemm(g, 1, "st.ffproj");
+      pl->release(gl);
+      pl->release(a);
+      pl->release(t0);
+      pl->release(xb);
+      pl->release(st);
+      pl->release(o_own);
+      return;
     }
     {
       GemmParams g = gp_linear(gl, M, 4 * C, c->w_linear(nm(tb + ".ff.net.2.weight")), C);
@@ -2741,6 +2784,22 @@ int df_test_gemm_epi(const uint16_t* A, const uint16_t* W, const float* bias, co
     if (res) { g.res = res; g.ldr = N; }
     g.silu = act == 1;
     g.relu = act == 2;
+    g.splitk = splitk;
+    if (splitk > 1) g.partial = test_partial((size_t)splitk * M * N * 4);
+    if (!gemm_tile_valid(g, tile, 1, splitk)) fail("tile %d / split-K %d refused this problem", tile, splitk);
+    HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
+  });
+}
+
+// C = [A | A2] W^T with the K columns split over two operand tensors (the merged FF2 + proj_out GEMM of the SpatialTransformer).
+int df_test_gemm_dual(const uint16_t* A, const uint16_t* A2, const uint16_t* W, float* C, int M, int N, int K1, int K2, int tile,
+                      int splitk, void* stream) {
+  return guard([&] {
+    GemmParams g = Builder::gp_linear(A, M, K1, W, N);
+    g.K = K1 + K2;
+    g.w_bytes = Builder::op_bytes((size_t)N * (K1 + K2) * 2);
+    g.A2 = A2; g.lda2 = K2; g.Cin2 = K2; g.a2_bytes = Builder::op_bytes((size_t)M * K2 * 2);
+    Builder::out_f32(g, C, N);
     g.splitk = splitk;
     if (splitk > 1) g.partial = test_partial((size_t)splitk * M * N * 4);
     if (!gemm_tile_valid(g, tile, 1, splitk)) fail("tile %d / split-K %d refused this problem", tile, splitk);

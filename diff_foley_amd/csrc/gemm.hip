@@ -134,7 +134,9 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
       if (std::max(ring, stage) + (size_t)bm_ * p.ln_slots * 8 > 160 * 1024) return false;
     }
     if (p.stats && batch > 1) return false;
-    if (p.Cin2 > 0 && (p.taps != 9 || p.stride != 1 || p.ups || batch > 1 || (p.Cin2 & 63) != 0)) return false;
+    if (p.Cin2 > 0 && (batch > 1 || (p.Cin2 & 63) != 0 || !p.A2)) return false;
+    if (p.Cin2 > 0 && p.taps == 9 && (p.stride != 1 || p.ups)) return false;    // conv: the folded 1x1 skip connection
+    if (p.Cin2 > 0 && p.taps != 9 && (p.taps != 1 || p.Cin2 >= p.K)) return false;   // linear: K columns [K-Cin2, K) from A2
     if (splitk > 1 && (p.N & 3) != 0) return false;          // partial slabs are written and reduced as float4
     return splitk == 1 || (batch <= 1 && nk / splitk >= 2);
   }

@@ -435,8 +435,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   constexpr unsigned OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)p.w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == 1 && p.A2 ? p.A2 : Ab), 0,
-                                                                          (int)(MODE == 1 && p.A2 ? p.a2_bytes : 0u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE <= 1 && p.A2 ? p.A2 : Ab), 0,
+                                                                          (int)(MODE <= 1 && p.A2 ? p.a2_bytes : 0u), 0x00020000);
+  // MODE 0 with a second A tensor: K columns [K - Cin2, K) come from A2 [M][lda2] (two linear layers merged into one GEMM)
+  const unsigned k1b = (MODE == 0 && p.Cin2 > 0) ? (unsigned)(p.K - p.Cin2) * 2u : 0xffffffffu;
   const int r0 = tid >> 3;
   const int c8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;   // source chunk that lands in LDS slot (tid&7) of row r0+32i
   unsigned a_off[AP];   // MODE 0: byte offset of (row, chunk); MODE 1: byte offset of the centre-tap pixel;
@@ -454,6 +456,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     a_iy[i] = a_ix[i] = 0;
     if (MODE == 0) {
       a_off[i] = mv ? (unsigned)(((long)m * p.lda + c8) * 2) : OOB;
+      if (p.Cin2 > 0) a_off2[i] = mv ? (unsigned)(((long)m * p.lda2 + c8) * 2) : OOB;
     } else {
       const int ohw = p.OH * p.OW;
       const int nb = m / ohw, rem = m - nb * ohw;
@@ -502,10 +505,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     const bool live = (T) < nt;                                                                 \
     const unsigned k0b = (p.dbg & 1) ? 0u : (unsigned)(kt0 + (T)) * (BK * 2);                         \
     if (MODE == 0) {                                                                            \
-      const unsigned kb = live ? k0b : OOB;                                                     \
-      _Pragma("unroll") for (int i = 0; i < AP; ++i)                                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
-                                                 a_off[i] + kb, 0, 0, 0);                       \
+      if (k0b < k1b) {                                                                          \
+        const unsigned kb = live ? k0b : OOB;                                                   \
+        _Pragma("unroll") for (int i = 0; i < AP; ++i)                                          \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
+                                                   a_off[i] + kb, 0, 0, 0);                     \
+      } else {   /* second tensor (wave-uniform branch) */                                      \
+        const unsigned kb = k0b - k1b;                                                          \
+        _Pragma("unroll") for (int i = 0; i < AP; ++i)                                          \
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
+                                                   (live && a_off2[i] != OOB) ? a_off2[i] + kb : OOB, 0, 0, 0); \
+      }                                                                                         \
     } else if (MODE == 1) {                                                                     \
       if (d_tap < 9) {                                                                          \
         const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                  \

@@ -87,6 +87,8 @@ _SIGS = {
     "df_profile_dump": [C.c_void_p, C.c_char_p],
     "df_test_gemm_epi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                          C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "df_test_gemm_dual": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                          C.c_void_p],
     "df_test_gemm": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "df_test_ln_chain": [C.c_void_p] * 11 + [C.c_int] * 10 + [C.c_void_p],
     "df_test_linear_rows": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6

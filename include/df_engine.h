@@ -197,6 +197,8 @@ int df_profile_dump(df_ctx* ctx, const char* path);
 int df_test_gemm_epi(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, const float* res_dev, void* C_dev,
                      int M, int N, int K, int act /*0 none, 1 SiLU, 2 ReLU*/, int out_operand, int tile, int splitk,
                      void* stream);
+int df_test_gemm_dual(const uint16_t* A_dev, const uint16_t* A2_dev, const uint16_t* W_dev, float* C_dev, int M, int N, int K1,
+                      int K2, int tile, int splitk, void* stream);
 int df_test_gemm(const uint16_t* A_dev, const uint16_t* W_dev, float* C_dev, int M, int N, int K, int tile, int splitk,
                  void* stream);
 /* SpatialTransformer GEMM pair: producer (fp32 t0 + operand copy + per-row partial statistics from the epilogue) and

@@ -79,6 +79,24 @@ def test_gemm(tile, M, N, K, splitk):
     assert rel_l2(c.cpu(), ref.cpu()) < 2e-3
 
 
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("M,N,K1,K2,splitk", [(200, 320, 1280, 320, 1), (72, 192, 512, 128, 2), (512, 1280, 5120, 1280, 4),
+                                              (64, 64, 64, 64, 1)])
+def test_gemm_two_operand_tensors(tile, M, N, K1, K2, splitk):
+    """K columns [0, K1) from A, [K1, K1+K2) from A2: the merged FF2 + proj_out GEMM (engine.hip st.ffproj)."""
+    E = _eng()
+    a = bf(rnd((M, K1), 21)).cuda()
+    a2 = bf(rnd((M, K2), 22)).cuda()
+    w = bf(rnd((N, K1 + K2), 23) / (K1 + K2) ** 0.5).cuda()
+    c = torch.full((M, N), float("nan"), device="cuda")
+    rc = E.lib(PREC).df_test_gemm_dual(ptr(a), ptr(a2), ptr(w), ptr(c), M, N, K1, K2, tile, splitk, stream())
+    assert rc == 0, E.lib(PREC).df_last_error()
+    torch.cuda.synchronize()
+    ref = torch.cat([a, a2], 1).float() @ w.float().t()
+    assert torch.isfinite(c).all()
+    assert rel_l2(c.cpu(), ref.cpu()) < 2e-3
+
+
 @pytest.mark.parametrize("tile", [0, 3, 4, 8, 13])
 @pytest.mark.parametrize("splitk", [1, 4])
 @pytest.mark.parametrize("act,res,out_operand", [(0, 0, 0), (1, 0, 0), (1, 0, 1), (2, 0, 0), (0, 1, 0), (1, 1, 1), (2, 1, 0)])
