@@ -832,6 +832,86 @@ hipError_t launch_pack_ffproj(const float* Wp, const float* bp, const float* W2,
   return hipGetLastError();
 }
 
+namespace {
+// ---- cross-attention with the context folded into per-sample "weights" (engine.hip: context_px).
+// kv [NB*Tc][2C] = (K | V) of the context tokens.  Kexp / Vexp [NB][H*Tcp][C]: row (h, tc) holds the head-h slice of token
+// tc's K (V) in columns [h*D, (h+1)*D) and zeros elsewhere, so that ONE dense GEMM against a C x C weight yields every head's
+// (K_h Wq_h) resp. (Wo_h V_h^T) block.  Rows tc >= Tc are padding (zero).
+__global__ __launch_bounds__(256) void xattn_expand_kernel(const bf16_t* __restrict__ kv, bf16_t* __restrict__ Kexp,
+                                                           bf16_t* __restrict__ Vexp, int Tc, int Tcp, int C, int H, long total8) {
+  const int D = C / H, c8n = C / 8;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total8; e += (long)gridDim.x * 256) {
+    const int j8 = (int)(e % c8n);
+    const long row = e / c8n;                      // (n, h, tp)
+    const int tp = (int)(row % Tcp), h = (int)((row / Tcp) % H);
+    const long n = row / ((long)Tcp * H);
+    uint4 k4 = make_uint4(0, 0, 0, 0), v4 = make_uint4(0, 0, 0, 0);
+    if (tp < Tc) {
+      const bf16_t* src = kv + ((n * Tc + tp) * 2l * C) + j8 * 8;
+      k4 = *reinterpret_cast<const uint4*>(src);
+      v4 = *reinterpret_cast<const uint4*>(src + C);
+      // 8 consecutive columns may straddle a head boundary when D % 8 != 0 is impossible here: D is a multiple of 8
+      const int hj = (j8 * 8) / D;
+      if (hj != h) { k4 = make_uint4(0, 0, 0, 0); v4 = k4; }
+    }
+    *reinterpret_cast<uint4*>(Kexp + row * C + j8 * 8) = k4;
+    *reinterpret_cast<uint4*>(Vexp + row * C + j8 * 8) = v4;
+  }
+}
+// WqT[c][j] = scale * gamma[c] * Wq[j][c]  (operand type): the LayerNorm-folded query projection, transposed, as the
+// "weight" operand of  G' = Kexp . WqT^T  (G'[row][c] = scale * sum_j Kexp[row][j] gamma[c] Wq[j][c])
+__global__ __launch_bounds__(256) void pack_lnq_t_kernel(const float* __restrict__ Wq, const float* __restrict__ gamma,
+                                                         bf16_t* __restrict__ out, int C, float scale) {
+  __shared__ float t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[ty + 8 * r][tx] = Wq[(long)(j0 + ty + 8 * r) * C + c0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = c0 + ty + 8 * r;
+    out[(long)c * C + j0 + tx] = f2bf(scale * gamma[c] * t[tx][ty + 8 * r]);
+  }
+}
+// per row of G' [rows][C]: cs = sum_c G'[row][c] (of the operand-rounded values the MFMA multiplies) and
+// bb = scale * sum_j Kexp[row][j] * bq[j]  with bq = Wq . beta (the LayerNorm shift through the query projection)
+__global__ __launch_bounds__(256) void xattn_rowstats_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ Kexp,
+                                                             const float* __restrict__ bq, float scale, int C, long rows,
+                                                             float* __restrict__ cs, float* __restrict__ bb) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float a = 0.f, b = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    a += bf2f(G[row * C + c]);
+    b += bf2f(Kexp[row * C + c]) * bq[c];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  if (lane == 0) { cs[row] = a; bb[row] = scale * b; }
+}
+}  // namespace
+
+hipError_t launch_xattn_expand(const uint16_t* kv, uint16_t* Kexp, uint16_t* Vexp, int NB, int Tc, int Tcp, int C, int H,
+                               hipStream_t s) {
+  if (C % H != 0 || (C / H) % 8 != 0 || C % 8 != 0) return hipErrorInvalidValue;
+  const long total8 = (long)NB * H * Tcp * (C / 8);
+  const int blocks = (int)std::min<long>((total8 + 255) / 256, 8192);
+  hipLaunchKernelGGL(xattn_expand_kernel, dim3(blocks), dim3(256), 0, s, kv, Kexp, Vexp, Tc, Tcp, C, H, total8);
+  return hipGetLastError();
+}
+hipError_t launch_pack_lnq_t(const float* Wq, const float* gamma, uint16_t* out, int C, float scale, hipStream_t s) {
+  if (C % 32 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_lnq_t_kernel, dim3(C / 32, C / 32), dim3(256), 0, s, Wq, gamma, out, C, scale);
+  return hipGetLastError();
+}
+hipError_t launch_xattn_rowstats(const uint16_t* G, const uint16_t* Kexp, const float* bq, float scale, int C, long rows, float* cs,
+                                 float* bb, hipStream_t s) {
+  hipLaunchKernelGGL(xattn_rowstats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, G, Kexp, bq, scale, C, rows, cs, bb);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_conv_skip(const float* w, const float* ws, uint16_t* out, int O, int I, int I2, hipStream_t s) {
   const long n = (long)O * (9 * I + I2);
   hipLaunchKernelGGL(pack_conv_skip_kernel, dim3(grid_for(n)), dim3(256), 0, s, w, ws, out, O, I, I2);

@@ -88,6 +88,7 @@ struct Plan {
   size_t partial_bytes = 0;
   double gemm_flops = 0, weight_bytes = 0;
   size_t ext_hint = 0;           // largest external (caller-owned) buffer the plan touches, when above 32 MB (autotune dummies)
+  size_t n_ctx = 0;              // UNet plans: ops [0, n_ctx) depend on the context only (run by df_unet_set_context)
   ~Plan() {
     for (auto& b : owned) (void)hipFree(b.p);
     if (partial) (void)hipFree(partial);
@@ -274,6 +275,19 @@ struct df_ctx {
     *w = (const bf16_t*)packed[kw];
     *b = (const float*)packed[kb];
   }
+  // scale * gamma[c] * Wq[j][c] as operand [c][j]: the LayerNorm-folded cross-attention query projection, transposed
+  const bf16_t* w_lnq_t(const std::string& wq, const std::string& norm, float scale) {
+    const std::string key = wq + "#lnqT";
+    auto it = packed.find(key);
+    if (it != packed.end()) return (const bf16_t*)it->second;
+    const RawT& t = rt(wq);
+    const int C = (int)t.shape[0];
+    if ((int)t.shape[1] != C) fail("w_lnq_t %s: not square", wq.c_str());
+    bf16_t* o = (bf16_t*)pmalloc((size_t)C * C * 2);
+    HIPCHK(launch_pack_lnq_t(t.d, f32(norm + ".weight"), o, C, scale, pack_stream));
+    packed[key] = o;
+    return o;
+  }
   // Linear weights [O_j][I] stacked along O and transposed -> bf16 [I][sum O_j]  (backward-data operand)
   const bf16_t* w_stack_t(const std::string& key, const std::vector<std::string>& names) {
     auto it = packed.find(key);
@@ -413,6 +427,8 @@ struct Builder {
   int which = 0;       // 0 = unet, 1 = classifier (emb offset table)
 
   std::string nm(const std::string& s) const { return pre + s; }
+
+  struct PX;     // cross-attention operands precomputed from the context (context_px below)
 
   // A consumer that needs the operand-type copy of a block's fp32 output (Downsample / Upsample convs) sets
   // want_aux before the block is built; the block's last GEMM then writes the copy from its epilogue (no cast pass)
@@ -719,7 +735,7 @@ struct Builder {
   // SpatialTransformer (attention_openai.py:250-261) with one BasicTransformerBlock (:211-215).
   // ctxK [NB*Tc][C] bf16 and ctxVt [NB][C][ldvt] bf16 are the hoisted cross-attention K / V^T.
   void spatial_transformer(const F32& x, const F32& out, int NB, int T, const std::string& p, int heads,
-                           const bf16_t* ctxK, const bf16_t* ctxVt, int Tc, int ldvtc) {
+                           const bf16_t* ctxK, const bf16_t* ctxVt, int Tc, int ldvtc, const PX* px = nullptr) {
     static const bool no_fold = getenv("DF_NO_LNFOLD") && atoi(getenv("DF_NO_LNFOLD"));
     if (no_fold) return spatial_transformer_unfused(x, out, NB, T, p, heads, ctxK, ctxVt, Tc, ldvtc);
     const int C = x.C, M = x.rows, D = C / heads;
@@ -795,7 +811,33 @@ struct Builder {
       g.res = t0; g.ldr = C;
       gemm(g, 1, "st.attn1.out");
     }
-    // ---- cross attention (K / V^T of the context were computed by set_context)
+    // ---- cross attention
+    if (px && px->G) {
+      // the context-dependent half was folded into per-sample operands by set_context (context_px): scores + softmax in one
+      // LayerNorm-folded GEMM (N = heads * 32), then probabilities x (Wo V^T) with the residual / statistics epilogue
+      const int HT = px->HT;
+      bf16_t* pr = qk;                               // [M][HT] probabilities (qk holds M x 2C >= M x HT elements)
+      if ((size_t)HT > (size_t)2 * C) fail("cross-attention: %d probability columns do not fit the q|k buffer", HT);
+      {
+        GemmParams g = gp_linear(xb, M, C, px->G, HT);
+        g.w_bs = (long)HT * C; g.w_rows = T;
+        g.w_bytes = op_bytes((size_t)HT * C * 2);
+        out_b16(g, pr, HT);
+        ln_fold(g, px->cs, px->bb);
+        g.sm_w = 32; g.sm_valid = Tc;
+        gemm(g, 1, "st.xs");
+      }
+      {
+        GemmParams g = gp_linear(pr, M, HT, px->Vo, C);
+        g.w_bs = (long)C * HT; g.w_rows = T;
+        g.w_bytes = op_bytes((size_t)C * HT * 2);
+        produces_t0(g);
+        g.bias = c->f32(nm(tb + ".attn2.to_out.0.bias"));
+        g.res = t0; g.ldr = C;
+        gemm(g, 1, "st.xo");
+      }
+    } else {
+    // (K / V^T of the context were computed by set_context)
     bf16_t* q2 = qk;
     {
       const bf16_t* w;
@@ -815,6 +857,7 @@ struct Builder {
       g.bias = c->f32(nm(tb + ".attn2.to_out.0.bias"));
       g.res = t0; g.ldr = C;
       gemm(g, 1, "st.attn2.out");
+    }
     }
     pl->release(qk);
     pl->release(vt);
@@ -880,6 +923,68 @@ struct Builder {
   }
 
   // context -> per-ST K [NB*Tc][C] and V^T [NB][C][ldvt]
+  // Cross-attention with the context folded into per-sample "weights".  The context is fixed for a whole sample() call while
+  // the queries change every step, so everything that does not depend on the query is precomputed by set_context:
+  //   scores_h = LN(t) Wq_h^T K_h^T / sqrt(D) = LN(t) . G_h,   G = [G_0 .. G_H-1]  ([C] x [H*32] per sample, LayerNorm-folded)
+  //   out      = sum_h P_h V_h Wo_h^T + bo   = P . Vo,          Vo = [Wo_h V_h^T]_h ([H*32] x [C] per sample)
+  // which turns  q-projection -> attention kernel -> out-projection  (2 M C^2 + 2 M C^2 FLOPs, 3 launches) into two GEMMs
+  // of 2 M C (32 H) FLOPs each with a softmax in the first one's epilogue (context length <= 32: padded to 32 per head).
+  struct PX {
+    const bf16_t* G = nullptr;    // [NB][H*32][C]   operand of the score GEMM (rows = (head, context token))
+    const float* cs = nullptr;    // [NB][H*32]      column sums of G (LayerNorm fold)
+    const float* bb = nullptr;    // [NB][H*32]      beta . G
+    const bf16_t* Vo = nullptr;   // [NB][C][H*32]   operand of the output GEMM
+    int HT = 0;                   // H * 32
+  };
+  static bool px_ok(int C, int heads, int Tc, int tokens) {
+    static const bool off = getenv("DF_NO_XPRE") && atoi(getenv("DF_NO_XPRE"));
+    return !off && Tc >= 1 && Tc <= 32 && C % 64 == 0 && C % heads == 0 && (C / heads) % 8 == 0 && (heads * 32) % 64 == 0 &&
+           tokens % 64 == 0;
+  }
+  PX context_px(const bf16_t* ctx, int NB, int Tc, int Dc, const std::string& st_prefix, int C, int heads) {
+    const std::string tb = st_prefix + ".transformer_blocks.0", a2 = tb + ".attn2";
+    const int HT = heads * 32;
+    const float scale = 1.0f / sqrtf((float)(C / heads));
+    PX px;
+    px.HT = HT;
+    bf16_t* kvb = buf<bf16_t>((size_t)NB * Tc * 2 * C);
+    {
+      const bf16_t* w = c->w_stack(nm(a2 + ".kv"), {nm(a2 + ".to_k.weight"), nm(a2 + ".to_v.weight")});
+      GemmParams g = gp_linear(ctx, NB * Tc, Dc, w, 2 * C);
+      out_b16(g, kvb, 2 * C);
+      gemm(g, 1, "ctx.kv");
+    }
+    bf16_t* Kexp = buf<bf16_t>((size_t)NB * HT * C);
+    bf16_t* Vexp = buf<bf16_t>((size_t)NB * HT * C);
+    other("ctx.expand", [=](hipStream_t s, const RunArgs&) { return launch_xattn_expand(kvb, Kexp, Vexp, NB, Tc, 32, C, heads, s); });
+    bf16_t* G = buf<bf16_t>((size_t)NB * HT * C);
+    {
+      GemmParams g = gp_linear(Kexp, NB * HT, C, c->w_lnq_t(nm(a2 + ".to_q.weight"), nm(tb + ".norm2"), scale), C);
+      out_b16(g, G, C);
+      gemm(g, 1, "ctx.g");
+    }
+    float* cs = buf<float>((size_t)NB * HT);
+    float* bb = buf<float>((size_t)NB * HT);
+    {
+      const bf16_t* wq;
+      const float *csq, *bq;
+      c->w_ln_stack(nm(tb + ".attn2.q"), nm(tb + ".norm2"), {nm(a2 + ".to_q.weight")}, {}, false, &wq, &csq, &bq);
+      const long rows = (long)NB * HT;
+      other("ctx.gstats", [=](hipStream_t s, const RunArgs&) { return launch_xattn_rowstats(G, Kexp, bq, scale, C, rows, cs, bb, s); });
+    }
+    bf16_t* Vo = buf<bf16_t>((size_t)NB * C * HT);
+    {  // Vo[n] = Wo . Vexp[n]^T  (batched: A = Wo shared, "W" operand = this sample's expanded values)
+      GemmParams g = gp_linear(c->w_linear(nm(a2 + ".to_out.0.weight")), C, C, Vexp, HT);
+      g.w_bs = (long)HT * C;
+      out_b16(g, Vo, HT);
+      g.c_bs = (long)C * HT;
+      gemm(g, NB, "ctx.vo");
+    }
+    // kvb / Kexp / Vexp stay allocated: set_context re-runs these ops for every new context
+    px.G = G; px.cs = cs; px.bb = bb; px.Vo = Vo;
+    return px;
+  }
+
   void context_kv(const bf16_t* ctx, int NB, int Tc, int Dc, const std::string& st_prefix, int C, bf16_t** K,
                   bf16_t** Vt, int ldvt) {
     const std::string a2 = st_prefix + ".transformer_blocks.0.attn2";
@@ -906,6 +1011,7 @@ struct BlockDesc {
   enum Kind { CONV_IN, RES, ST, DOWN, UP } kind;
   std::string prefix;
   int cin, cout;
+  int ds = 1;           // downsample factor of the feature map the block runs on (filled for ST blocks)
 };
 struct UNetTopo {
   std::vector<std::vector<BlockDesc>> input, output;
@@ -934,7 +1040,7 @@ UNetTopo make_topo(const df_unet_config& u, bool encoder_only) {
       const int co = u.channel_mult[level] * mc;
       b.push_back({BlockDesc::RES, "input_blocks." + std::to_string(idx) + ".0", ch, co});
       ch = co;
-      if (in_attn(ds)) b.push_back({BlockDesc::ST, "input_blocks." + std::to_string(idx) + ".1", ch, ch});
+      if (in_attn(ds)) b.push_back({BlockDesc::ST, "input_blocks." + std::to_string(idx) + ".1", ch, ch, ds});
       t.input.push_back(b);
       t.in_ch.push_back(ch);
       t.in_ds.push_back(ds);
@@ -949,7 +1055,7 @@ UNetTopo make_topo(const df_unet_config& u, bool encoder_only) {
     }
   }
   t.middle = {{BlockDesc::RES, "middle_block.0", ch, ch},
-              {BlockDesc::ST, "middle_block.1", ch, ch},
+              {BlockDesc::ST, "middle_block.1", ch, ch, ds},
               {BlockDesc::RES, "middle_block.2", ch, ch}};
   t.final_ch = ch;
   if (encoder_only) return t;
@@ -965,7 +1071,7 @@ UNetTopo make_topo(const df_unet_config& u, bool encoder_only) {
       ch = co;
       int j = 1;
       t.out_ds.push_back(ds);
-      if (in_attn(ds)) b.push_back({BlockDesc::ST, "output_blocks." + std::to_string(idx) + "." + std::to_string(j++), ch, ch});
+      if (in_attn(ds)) b.push_back({BlockDesc::ST, "output_blocks." + std::to_string(idx) + "." + std::to_string(j++), ch, ch, ds});
       if (level && i == u.num_res_blocks) {
         b.push_back({BlockDesc::UP, "output_blocks." + std::to_string(idx) + "." + std::to_string(j), ch, ch});
         ds /= 2;
@@ -1023,17 +1129,28 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
   const int ldvtc = rup(Tc, 32);
   bf16_t* ctxb = b.buf<bf16_t>((size_t)N * Tc * Dc);
   std::map<std::string, std::pair<bf16_t*, bf16_t*>> kv;
+  std::map<std::string, Builder::PX> pxs;
+  static const bool no_lnfold = getenv("DF_NO_LNFOLD") && atoi(getenv("DF_NO_LNFOLD"));
   const size_t ctx_ops_begin = pl->ops.size();
   {
     const long n = (long)N * Tc * Dc;
     b.other("ctx.cast", [=](hipStream_t s, const RunArgs& a) { return launch_cast_bf16(a.aux, ctxb, n, s); });
     for (auto& d : sts) {
+      const int tokens = (H / d.ds) * (W / d.ds);
+      // the denoiser's context is set once per sample() call: fold it into per-sample operands where the shapes allow;
+      // the classifier gets new features with every call and keeps the K / V^T form
+      if (which == 0 && !no_lnfold && Builder::px_ok(d.cin, heads, Tc, tokens)) {
+        pxs[d.prefix] = b.context_px(ctxb, N, Tc, Dc, d.prefix, d.cin, heads);
+        kv[d.prefix] = {nullptr, nullptr};
+        continue;
+      }
       bf16_t *K, *Vt;
       b.context_kv(ctxb, N, Tc, Dc, d.prefix, d.cin, &K, &Vt, ldvtc);
       kv[d.prefix] = {K, Vt};
     }
   }
   const size_t ctx_ops_end = pl->ops.size();
+  pl->n_ctx = ctx_ops_end;
   if (!ctx_inline) {
     // move the context ops into a separate plan entry "…#ctx" is handled by the caller: it splits [begin,end)
   }
@@ -1170,7 +1287,8 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
                    c->emb_off[which].at(d.prefix));
       } else if (d.kind == BlockDesc::ST) {
         dst = mk(h.rows, d.cout);
-        b.spatial_transformer(h, dst, N, hh * ww, d.prefix, heads, kv[d.prefix].first, kv[d.prefix].second, Tc, ldvtc);
+        b.spatial_transformer(h, dst, N, hh * ww, d.prefix, heads, kv[d.prefix].first, kv[d.prefix].second, Tc, ldvtc,
+                              pxs.count(d.prefix) ? &pxs[d.prefix] : nullptr);
       } else if (d.kind == BlockDesc::DOWN) {
         dst = mk(h.rows / 4, d.cout);
         bf16_t* hb = in_aux ? in_aux : b.cast2d(h);
@@ -2432,13 +2550,6 @@ int df_cond_encode(df_ctx* c, const float* feats, float* out, int B, int T, void
   });
 }
 
-// UNet plans keep their context ops at the front of the op list: [0, n_ctx) = context, rest = forward.
-static size_t n_ctx_ops(df_ctx* c, int which) {
-  const df_unet_config& u = which ? c->ccfg : c->ucfg;
-  UNetTopo t = make_topo(u, which == 1);
-  return 1 + 2 * topo_sts(t).size();
-}
-
 static Plan* unet_plan(df_ctx* c, int N, int H, int W, int T, bool cfg) {
   if (!c->has_unet) fail("unet not configured");
   if (H % (1 << (c->ucfg.n_mult - 1)) || W % (1 << (c->ucfg.n_mult - 1))) fail("latent %dx%d not divisible by the UNet downsampling", H, W);
@@ -2454,12 +2565,11 @@ int df_unet_set_context(df_ctx* c, const float* context, int N, int T, void* str
     // for every plan that is used with this context.  Simple and exact: stash the pointer, mark plans stale.
     RunArgs a;
     a.aux = context;
-    const size_t nctx = n_ctx_ops(c, 0);
     for (auto& kv : c->plans) {
       if (kv.first.rfind("unet_", 0) != 0) continue;
       int n, h, w, t, g;
       if (sscanf(kv.first.c_str(), "unet_%d_%d_%d_%d_%d", &n, &h, &w, &t, &g) == 5 && n == N && t == T)
-        run_ops(c, kv.second.get(), 0, nctx, (hipStream_t)stream, a);
+        run_ops(c, kv.second.get(), 0, kv.second->n_ctx, (hipStream_t)stream, a);
     }
     // keep a device copy so plans created later can still be primed
     const size_t bytes = (size_t)N * T * c->ucfg.context_dim * 4;
@@ -2477,7 +2587,7 @@ static void unet_run(df_ctx* c, const float* x, const float* t, float* out, int 
   const std::string key = keyf("unet_%d_%d_%d_%d_%d", N, H, W, c->ctx_T, (int)cfg);
   const bool fresh = c->plans.count(key) == 0;
   Plan* p = unet_plan(c, N, H, W, c->ctx_T, cfg);
-  const size_t nctx = n_ctx_ops(c, 0);
+  const size_t nctx = p->n_ctx;
   RunArgs a;
   a.x = x;
   a.t = t;
@@ -2689,7 +2799,7 @@ int df_plan_count(df_ctx* c, int64_t* n_plans, int64_t* workspace_bytes) {
 int df_unet_plan_stats(df_ctx* c, int64_t* n_launches, double* gemm_flops, double* weight_bytes) {
   return guard([&] {
     if (!c->last_unet) fail("no UNet plan has been executed yet");
-    const size_t nctx = n_ctx_ops(c, 0);
+    const size_t nctx = c->last_unet->n_ctx;
     int64_t n = 0;
     for (size_t i = nctx; i < c->last_unet->ops.size(); ++i) n += 1 + (c->last_unet->ops[i].is_gemm && c->last_unet->ops[i].gp.splitk > 1);
     *n_launches = n;
@@ -2900,9 +3010,15 @@ int df_test_unet_block(df_ctx* c, const char* prefix, int kind, const float* x, 
       bf16_t* ctxb = b.buf<bf16_t>((size_t)N * T * Dc);
       const long n = (long)N * T * Dc;
       b.other("ctx.cast", [=](hipStream_t st, const RunArgs&) { return launch_cast_bf16(context, ctxb, n, st); });
-      bf16_t *K, *Vt;
-      b.context_kv(ctxb, N, T, Dc, p, Cin, &K, &Vt, ldvtc);
-      b.spatial_transformer(xin, dst, N, H * W, p, u.num_heads, K, Vt, T, ldvtc);
+      static const bool no_lnfold = getenv("DF_NO_LNFOLD") && atoi(getenv("DF_NO_LNFOLD"));
+      if (!no_lnfold && Builder::px_ok(Cin, u.num_heads, T, H * W)) {     // same choice as build_unet_like
+        Builder::PX px = b.context_px(ctxb, N, T, Dc, p, Cin, u.num_heads);
+        b.spatial_transformer(xin, dst, N, H * W, p, u.num_heads, nullptr, nullptr, T, ldvtc, &px);
+      } else {
+        bf16_t *K, *Vt;
+        b.context_kv(ctxb, N, T, Dc, p, Cin, &K, &Vt, ldvtc);
+        b.spatial_transformer(xin, dst, N, H * W, p, u.num_heads, K, Vt, T, ldvtc);
+      }
     } else {
       bf16_t* hb = b.cast2d(xin);
       const std::string wn = pre + p + (kind == 2 ? ".op" : ".conv");

@@ -46,6 +46,12 @@ struct GemmParams {
   // over 64-column slots of the fp32 tensor the operand copy was made from (ln_C columns in total).
   const float2* ln_stats; int ln_slots; int ln_C; float ln_eps;
   const float* ln_cs;                // [N] column sums of the (operand-rounded) gamma-scaled weights
+  // Row-block weights: rows [i*w_rows, (i+1)*w_rows) multiply W + i*w_bs (one weight matrix per SAMPLE in one launch: the
+  // cross-attention GEMMs whose "weights" are precomputed from each sample's context).  w_rows % BM == 0.
+  int w_rows;
+  // Cross-attention score epilogue (with ln_stats): ln_cs and bias are per sample, [M / w_rows][N]; every group of sm_w = 32
+  // columns (one head) gets a softmax over its first sm_valid columns (the rest is padding and stores 0); operand-type output.
+  int sm_w, sm_valid;
   // per-row partial statistics of the STORED fp32 value (after bias / residual): stats[row][col/64] = (sum, sumsq)
   float2* stats; int stats_slots;
   // columns >= vt_col0 are stored TRANSPOSED per sample into vt[(row/vt_T)*(N-vt_col0) + col-vt_col0][ldvt] at

@@ -134,6 +134,10 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
       if (std::max(ring, stage) + (size_t)bm_ * p.ln_slots * 8 > 160 * 1024) return false;
     }
     if (p.stats && batch > 1) return false;
+    if (p.w_rows > 0 && (batch > 1 || p.taps != 1 || p.w_rows % bm_ != 0 || p.M % p.w_rows != 0)) return false;
+    if (p.sm_w > 0 && (p.sm_w != 32 || splitk > 1 || !p.ln_stats || !p.out_bf16 || p.w_rows <= 0 || (p.N & 31) != 0 || p.geglu ||
+                       p.vt || p.res || p.rowbias || p.aux || p.alpha != 1.f || !p.bias))
+      return false;
     if (p.Cin2 > 0 && (batch > 1 || (p.Cin2 & 63) != 0 || !p.A2)) return false;
     if (p.Cin2 > 0 && p.taps == 9 && (p.stride != 1 || p.ups)) return false;    // conv: the folded 1x1 skip connection
     if (p.Cin2 > 0 && p.taps != 9 && (p.taps != 1 || p.Cin2 >= p.K)) return false;   // linear: K columns [K-Cin2, K) from A2
@@ -169,6 +173,7 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
                    (p.res_bs & 3) == 0 && (p.c_bs & 3) == 0 && (p.ld_aux & 3) == 0;
   int epi;
   if (p.splitk > 1) epi = EPI_SPLITK;
+  else if (p.sm_w > 0) epi = EPI_XS;
   else if (p.geglu) epi = EPI_GEGLU;
   else if (p.ln_stats || p.vt) epi = EPI_LNC;
   else if (p.stats) epi = EPI_PROD;
@@ -177,6 +182,7 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
   if ((epi == EPI_GEGLU || epi == EPI_LNC || epi == EPI_PROD) && (p.taps != 1 || p.alpha != 1.f || p.relu || p.silu || !vec))
     return hipErrorInvalidValue;
   if (epi == EPI_LNC && (!p.ln_stats || p.aux)) return hipErrorInvalidValue;
+  if (epi == EPI_XS && (!p.ln_stats || p.taps != 1 || !vec || (p.N & 63) != 0)) return hipErrorInvalidValue;
   hipError_t e;
   // MODE 0: linear / 1x1;  1: 3x3 stride 1 (tap offsets are linear, 2 VALU per request);  2: 3x3 stride 2 / upsampled
   const int mode = (p.taps != 9) ? 0 : ((p.stride == 1 && !p.ups) ? 1 : 2);

@@ -29,7 +29,7 @@ constexpr int BK = 64;
 //   PROD   LEAN + per-row partial statistics + operand-type copy (producers of a LayerNorm-folded consumer)
 //   LNC    LayerNorm-folded consumer, optionally with the transposed V^T column range (fused QKV)
 //   ANY    everything else: alpha, ReLU, aux copy, NCHW store, unaligned shapes (scalar fallback)
-enum { EPI_LEAN = 0, EPI_SPLITK = 1, EPI_GEGLU = 2, EPI_PROD = 3, EPI_LNC = 4, EPI_ANY = 5 };
+enum { EPI_LEAN = 0, EPI_SPLITK = 1, EPI_GEGLU = 2, EPI_PROD = 3, EPI_LNC = 4, EPI_ANY = 5, EPI_XS = 6 };
 
 // Spatial patch (th x tw output pixels) owned by one block of a halo kernel with BM rows.
 bool halo_patch(int H, int W, int BM, int* th, int* tw) {
@@ -188,7 +188,7 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
   const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   float2* sRow = reinterpret_cast<float2*>(sC + BM * LDC);   // (mean, rstd) of tile row r (LayerNorm-folded GEMMs)
   __builtin_amdgcn_s_barrier();            // every wave is done reading the operand ring
-  if ((EPI == EPI_LNC || EPI == EPI_GEGLU) && p.ln_stats && tid < BM) sRow[tid] = ln_mr;
+  if ((EPI == EPI_LNC || EPI == EPI_GEGLU || EPI == EPI_XS) && p.ln_stats && tid < BM) sRow[tid] = ln_mr;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -207,6 +207,47 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       const int row = rowmap(r), col = n0 + c4;
       const float4 v = *reinterpret_cast<const float4*>(&sC[r * LDC + c4]);
       if (row < p.M && col < p.N) *reinterpret_cast<float4*>(&part[(long)row * p.N + col]) = v;
+    }
+    return;
+  } else if constexpr (EPI == EPI_XS) {
+    // cross-attention scores: LayerNorm fold with this sample's column sums / bias, then softmax over every 32-column head
+    // group (8 consecutive lanes hold one group of one row), operand-type probabilities out
+    constexpr int CPR = BN / 4;
+#pragma unroll 2
+    for (int ei = 0; ei < BM * CPR / NT; ++ei) {
+      const int e = tid + ei * NT;
+      const int r = e / CPR, c4 = (e - r * CPR) * 4;
+      const int row = rowmap(r), col = n0 + c4;
+      const int rc = min(row, p.M - 1), cc = min(col, p.N - 4);
+      float4 v = *reinterpret_cast<const float4*>(&sC[r * LDC + c4]);
+      const float2 mr = sRow[r];
+      const long so = (long)(rc / p.w_rows) * p.N + cc;
+      const float4 cs = *reinterpret_cast<const float4*>(&p.ln_cs[so]);
+      const float4 bb = *reinterpret_cast<const float4*>(&p.bias[so]);
+      v.x = mr.y * (v.x - mr.x * cs.x) + bb.x; v.y = mr.y * (v.y - mr.x * cs.y) + bb.y;
+      v.z = mr.y * (v.z - mr.x * cs.z) + bb.z; v.w = mr.y * (v.w - mr.x * cs.w) + bb.w;
+      const int g0 = col & 31;
+      const float NEG = -3.0e38f;
+      if (g0 + 0 >= p.sm_valid) v.x = NEG;
+      if (g0 + 1 >= p.sm_valid) v.y = NEG;
+      if (g0 + 2 >= p.sm_valid) v.z = NEG;
+      if (g0 + 3 >= p.sm_valid) v.w = NEG;
+      float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+      mx = fmaxf(mx, __shfl_xor(mx, 1));
+      mx = fmaxf(mx, __shfl_xor(mx, 2));
+      mx = fmaxf(mx, __shfl_xor(mx, 4));
+      v.x = g0 + 0 < p.sm_valid ? __expf(v.x - mx) : 0.f;
+      v.y = g0 + 1 < p.sm_valid ? __expf(v.y - mx) : 0.f;
+      v.z = g0 + 2 < p.sm_valid ? __expf(v.z - mx) : 0.f;
+      v.w = g0 + 3 < p.sm_valid ? __expf(v.w - mx) : 0.f;
+      float sm = (v.x + v.y) + (v.z + v.w);
+      sm += __shfl_xor(sm, 1);
+      sm += __shfl_xor(sm, 2);
+      sm += __shfl_xor(sm, 4);
+      const float inv = 1.0f / sm;
+      if (row < p.M && col < p.N)
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (long)row * p.ldc + col) =
+            make_uint2(pack_bf2(v.x * inv, v.y * inv), pack_bf2(v.z * inv, v.w * inv));
     }
     return;
   } else if constexpr (EPI == EPI_GEGLU) {
@@ -406,7 +447,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   constexpr int LNPT = 5;
   constexpr size_t RING_B = (size_t)(BM + BN) * BK * 2 * NST, STAGE_B = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8;
   constexpr size_t SCR_OFF = RING_B > STAGE_B ? RING_B : STAGE_B;
-  const bool ln_on = MODE == 0 && (EPI == EPI_LNC || EPI == EPI_GEGLU) && p.ln_stats != nullptr;
+  const bool ln_on = MODE == 0 && (EPI == EPI_LNC || EPI == EPI_GEGLU || EPI == EPI_XS) && p.ln_stats != nullptr;
   float2 lnv[LNPT];
   if (ln_on) {
     const int cnt = min(BM, p.M - m0) * p.ln_slots;
@@ -425,7 +466,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     batch = 0;
   }
   const bf16_t* Ab = p.A + (long)batch * p.a_bs;
-  const bf16_t* Wb = p.W + (long)batch * p.w_bs;
+  const bf16_t* Wb = p.W + (long)batch * p.w_bs + (p.w_rows > 0 ? (long)(m0 / p.w_rows) * p.w_bs : 0l);
 
   // ---- per-thread staging coordinates: chunk c (8 bf16 = 16 B) of rows (tid>>3) + 32*i.
   // Operands are fetched with raw buffer loads: an out-of-range byte offset (OOB) makes the hardware return
@@ -966,7 +1007,7 @@ hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
   constexpr size_t stage = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8;          // epilogue tile + (mean, rstd) row table
   const size_t base = ring > stage ? ring : stage;
   // LayerNorm-folded GEMMs park the producer's row partials behind the ring: BM * ln_slots float2
-  const size_t lds = base + ((MODE == 0 && (EPI == EPI_LNC || EPI == EPI_GEGLU) && p.ln_stats) ? (size_t)BM * p.ln_slots * 8 : 0);
+  const size_t lds = base + ((MODE == 0 && (EPI == EPI_LNC || EPI == EPI_GEGLU || EPI == EPI_XS) && p.ln_stats) ? (size_t)BM * p.ln_slots * 8 : 0);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {

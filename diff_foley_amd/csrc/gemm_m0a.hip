@@ -11,6 +11,7 @@ hipError_t launch_gemm_m0a(int tile_cfg, int epi, const GemmParams& p, int zdim,
       case EPI_PROD: return launch_cfg<BM, BN, WGM, WGN, NST, 0, EPI_PROD>(p, zdim, stream); \
       case EPI_LNC: return launch_cfg<BM, BN, WGM, WGN, NST, 0, EPI_LNC>(p, zdim, stream); \
       case EPI_ANY: return launch_cfg<BM, BN, WGM, WGN, NST, 0, EPI_ANY>(p, zdim, stream); \
+      case EPI_XS: return launch_cfg<BM, BN, WGM, WGN, NST, 0, EPI_XS>(p, zdim, stream); \
       default: return hipErrorInvalidValue;                              \
     }
   switch (tile_cfg) {

@@ -76,6 +76,12 @@ hipError_t launch_pack_ln_linear(const float* w, const float* bias, const float*
                                  hipStream_t s);
 // conv3x3 OIHW + 1x1 skip weight [O][I2] -> operand rows [O][9*I + I2] (taps (ky,kx,ci), then the skip channels)
 hipError_t launch_pack_conv_skip(const float* w, const float* ws, uint16_t* out, int O, int I, int I2, hipStream_t s);
+// ---- cross-attention with the context folded into per-sample weights (see engine.hip context_px)
+hipError_t launch_xattn_expand(const uint16_t* kv, uint16_t* Kexp, uint16_t* Vexp, int NB, int Tc, int Tcp, int C, int H,
+                               hipStream_t s);
+hipError_t launch_pack_lnq_t(const float* Wq, const float* gamma, uint16_t* out, int C, float scale, hipStream_t s);
+hipError_t launch_xattn_rowstats(const uint16_t* G, const uint16_t* Kexp, const float* bq, float scale, int C, long rows, float* cs,
+                                 float* bb, hipStream_t s);
 // [Wp.W2 | Wp] operand [C][F + C] and bias Wp.b2 + bp: FeedForward's second Linear (W2 [C][F], b2) merged with proj_out (Wp, bp)
 hipError_t launch_pack_ffproj(const float* Wp, const float* bp, const float* W2, const float* b2, uint16_t* wout, float* bout,
                               int C, int F, hipStream_t s);
