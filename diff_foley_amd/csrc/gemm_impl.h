@@ -187,6 +187,29 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
   constexpr int LDC = BN + 4;
   const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   float2* sRow = reinterpret_cast<float2*>(sC + BM * LDC);   // (mean, rstd) of tile row r (LayerNorm-folded GEMMs)
+  // A thread keeps the SAME 4 columns in every step of the store loops below (NT is a multiple of the float4 chunks per
+  // row), so the per-column epilogue vectors -- bias, LayerNorm column sums -- are requested once, here, and arrive while
+  // the accumulators are parked in LDS instead of stalling every loop step on an L2 round trip.
+  float4 hb0 = make_float4(0.f, 0.f, 0.f, 0.f), hb1 = hb0, hc0 = hb0, hc1 = hb0;
+  if constexpr (EPI == EPI_GEGLU) {
+    static_assert(NT % (BN / 8) == 0, "invariant column per thread");
+    const int oc = (tid % (BN / 8)) * 4, xc = (oc >> 5) * 64 + (oc & 31);
+    const int gx = min(n0 + xc, p.N - 36);
+    if (p.ln_stats) {
+      hc0 = *reinterpret_cast<const float4*>(&p.ln_cs[gx]);
+      hc1 = *reinterpret_cast<const float4*>(&p.ln_cs[gx + 32]);
+    }
+    if (p.bias) {
+      hb0 = *reinterpret_cast<const float4*>(&p.bias[gx]);
+      hb1 = *reinterpret_cast<const float4*>(&p.bias[gx + 32]);
+    }
+  } else if constexpr (EPI != EPI_SPLITK && EPI != EPI_XS) {
+    static_assert(NT % (BN / 4) == 0, "invariant column per thread");
+    const int cch = min(n0 + (tid % (BN / 4)) * 4, p.N - 4);
+    if (p.bias) hb0 = *reinterpret_cast<const float4*>(&p.bias[cch]);
+    if constexpr (EPI == EPI_LNC)
+      if (p.ln_stats) hc0 = *reinterpret_cast<const float4*>(&p.ln_cs[cch]);
+  }
   __builtin_amdgcn_s_barrier();            // every wave is done reading the operand ring
   if ((EPI == EPI_LNC || EPI == EPI_GEGLU || EPI == EPI_XS) && p.ln_stats && tid < BM) sRow[tid] = ln_mr;
 #pragma unroll
@@ -258,19 +281,16 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       const int r = e / CPR, oc = (e - r * CPR) * 4;           // output column within the tile
       const int xc = (oc >> 5) * 64 + (oc & 31);               // packed x column within the tile; gate at +32
       const int row = rowmap(r), ocol = (n0 >> 1) + oc;
-      const int gx = min(n0 + xc, p.N - 36);
       float4 x = *reinterpret_cast<const float4*>(&sC[r * LDC + xc]);
       float4 g = *reinterpret_cast<const float4*>(&sC[r * LDC + xc + 32]);
       if (p.ln_stats) {       // LayerNorm folded in: rstd * (acc - mean * colsum(gamma W))
         const float2 mr = sRow[r];
-        const float4 cx = *reinterpret_cast<const float4*>(&p.ln_cs[gx]);
-        const float4 cg = *reinterpret_cast<const float4*>(&p.ln_cs[gx + 32]);
+        const float4 cx = hc0, cg = hc1;
         x.x = mr.y * (x.x - mr.x * cx.x); x.y = mr.y * (x.y - mr.x * cx.y); x.z = mr.y * (x.z - mr.x * cx.z); x.w = mr.y * (x.w - mr.x * cx.w);
         g.x = mr.y * (g.x - mr.x * cg.x); g.y = mr.y * (g.y - mr.x * cg.y); g.z = mr.y * (g.z - mr.x * cg.z); g.w = mr.y * (g.w - mr.x * cg.w);
       }
       if (has_bias) {
-        const float4 bx = *reinterpret_cast<const float4*>(&p.bias[gx]);
-        const float4 bg = *reinterpret_cast<const float4*>(&p.bias[gx + 32]);
+        const float4 bx = hb0, bg = hb1;
         x.x = x.x * p.alpha + bx.x; x.y = x.y * p.alpha + bx.y; x.z = x.z * p.alpha + bx.z; x.w = x.w * p.alpha + bx.w;
         g.x = g.x * p.alpha + bg.x; g.y = g.y * p.alpha + bg.y; g.z = g.z * p.alpha + bg.z; g.w = g.w * p.alpha + bg.w;
       }
@@ -342,12 +362,12 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
     if ((FL) & 16) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }                              \
     if ((FL) & 2) {                                                                                                 \
       const float2 mr = sRow[r];                                                                                    \
-      const float4 cs = *reinterpret_cast<const float4*>(&p.ln_cs[cc]);                                            \
+      const float4 cs = hc0;                                                                                        \
       v.x = mr.y * (v.x - mr.x * cs.x); v.y = mr.y * (v.y - mr.x * cs.y);                                           \
       v.z = mr.y * (v.z - mr.x * cs.z); v.w = mr.y * (v.w - mr.x * cs.w);                                           \
     }                                                                                                               \
     if (has_bias) {                                                                                                 \
-      const float4 b = *reinterpret_cast<const float4*>(&p.bias[cc]);                                               \
+      const float4 b = hb0;                                                                                         \
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
     }                                                                                                               \
     if (has_rb) {                                                                                                   \
