@@ -174,6 +174,37 @@ __device__ __forceinline__ void epilogue_band(const GemmParams& p, int z, int ba
   }
 }
 
+// A thread keeps the SAME 4 columns in every step of the block epilogue's store loops (NT is a multiple of the float4 chunks
+// per row), so the per-column epilogue vectors -- bias, LayerNorm column sums -- are requested ONCE, before the main loop,
+// and are in registers long before the epilogue needs them (inside the loops each was an exposed L2 round trip per step).
+struct EpiVec { float4 hb0, hb1, hc0, hc1; };
+template <int BN, int NT, int EPI>
+__device__ __forceinline__ EpiVec epi_prefetch(const GemmParams& p, int n0, int tid) {
+  EpiVec ev;
+  ev.hb0 = ev.hb1 = ev.hc0 = ev.hc1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.store_nchw || (p.N & 3)) return ev;      // scalar epilogue (epilogue_band) reads its own
+  if constexpr (EPI == EPI_GEGLU) {
+    static_assert(NT % (BN / 8) == 0, "invariant column per thread");
+    const int oc = (tid % (BN / 8)) * 4, xc = (oc >> 5) * 64 + (oc & 31);
+    const int gx = min(n0 + xc, p.N - 36);
+    if (p.ln_stats) {
+      ev.hc0 = *reinterpret_cast<const float4*>(&p.ln_cs[gx]);
+      ev.hc1 = *reinterpret_cast<const float4*>(&p.ln_cs[gx + 32]);
+    }
+    if (p.bias) {
+      ev.hb0 = *reinterpret_cast<const float4*>(&p.bias[gx]);
+      ev.hb1 = *reinterpret_cast<const float4*>(&p.bias[gx + 32]);
+    }
+  } else if constexpr (EPI != EPI_SPLITK && EPI != EPI_XS) {
+    static_assert(NT % (BN / 4) == 0, "invariant column per thread");
+    const int cch = min(n0 + (tid % (BN / 4)) * 4, p.N - 4);
+    if (p.bias) ev.hb0 = *reinterpret_cast<const float4*>(&p.bias[cch]);
+    if constexpr (EPI == EPI_LNC)
+      if (p.ln_stats) ev.hc0 = *reinterpret_cast<const float4*>(&p.ln_cs[cch]);
+  }
+  return ev;
+}
+
 // Block-level epilogue through LDS: the accumulators of the whole BM x BN tile are parked in LDS as fp32 (row
 // stride BN+4 floats keeps the 16-B reads conflict-free), then every thread re-reads 4 consecutive columns of one
 // row, applies alpha / bias / per-sample bias / residual / GEGLU on float4s and issues ONE 16-byte (fp32) or 8-byte
@@ -183,33 +214,11 @@ __device__ __forceinline__ void epilogue_band(const GemmParams& p, int z, int ba
 template <int BM, int BN, int NT, int TM, int TN, int EPI, class RowMap>
 __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int batch, float* sC,
                                                f32x16 (&acc)[TM][TN], int wrow0, int wcol0, int n0, int tid,
-                                               RowMap rowmap, float2 ln_mr = make_float2(0.f, 1.f)) {
+                                               RowMap rowmap, const EpiVec& ev, float2 ln_mr = make_float2(0.f, 1.f)) {
   constexpr int LDC = BN + 4;
   const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   float2* sRow = reinterpret_cast<float2*>(sC + BM * LDC);   // (mean, rstd) of tile row r (LayerNorm-folded GEMMs)
-  // A thread keeps the SAME 4 columns in every step of the store loops below (NT is a multiple of the float4 chunks per
-  // row), so the per-column epilogue vectors -- bias, LayerNorm column sums -- are requested once, here, and arrive while
-  // the accumulators are parked in LDS instead of stalling every loop step on an L2 round trip.
-  float4 hb0 = make_float4(0.f, 0.f, 0.f, 0.f), hb1 = hb0, hc0 = hb0, hc1 = hb0;
-  if constexpr (EPI == EPI_GEGLU) {
-    static_assert(NT % (BN / 8) == 0, "invariant column per thread");
-    const int oc = (tid % (BN / 8)) * 4, xc = (oc >> 5) * 64 + (oc & 31);
-    const int gx = min(n0 + xc, p.N - 36);
-    if (p.ln_stats) {
-      hc0 = *reinterpret_cast<const float4*>(&p.ln_cs[gx]);
-      hc1 = *reinterpret_cast<const float4*>(&p.ln_cs[gx + 32]);
-    }
-    if (p.bias) {
-      hb0 = *reinterpret_cast<const float4*>(&p.bias[gx]);
-      hb1 = *reinterpret_cast<const float4*>(&p.bias[gx + 32]);
-    }
-  } else if constexpr (EPI != EPI_SPLITK && EPI != EPI_XS) {
-    static_assert(NT % (BN / 4) == 0, "invariant column per thread");
-    const int cch = min(n0 + (tid % (BN / 4)) * 4, p.N - 4);
-    if (p.bias) hb0 = *reinterpret_cast<const float4*>(&p.bias[cch]);
-    if constexpr (EPI == EPI_LNC)
-      if (p.ln_stats) hc0 = *reinterpret_cast<const float4*>(&p.ln_cs[cch]);
-  }
+  const float4 hb0 = ev.hb0, hb1 = ev.hb1, hc0 = ev.hc0, hc1 = ev.hc1;
   __builtin_amdgcn_s_barrier();            // every wave is done reading the operand ring
   if ((EPI == EPI_LNC || EPI == EPI_GEGLU || EPI == EPI_XS) && p.ln_stats && tid < BM) sRow[tid] = ln_mr;
 #pragma unroll
@@ -673,6 +682,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     ++it;                                                                                       \
   }
 
+  const EpiVec ev = epi_prefetch<BN, NT, EPI>(p, n0, tid);
   // ---- prologue: fill NST-1 ring slots
   DF_DMA(0, 0);
   if (NST > 2) DF_DMA(1, 1);
@@ -729,13 +739,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   }
   if constexpr (EPI != EPI_ANY) {     // the host routes only vectorisable, row-major problems to the specialised kernels
     epilogue_block<BM, BN, NT, TM, TN, EPI>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid,
-                                             [&](int r) { return m0 + r; }, ln_mr);
+                                             [&](int r) { return m0 + r; }, ev, ln_mr);
   } else {
     const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
                         (p.ld_rowbias & 3) == 0 && (p.res_bs & 3) == 0 && (p.c_bs & 3) == 0 && (p.ld_aux & 3) == 0;
     if (vec_ok) {
       epilogue_block<BM, BN, NT, TM, TN, EPI>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0,
-                                               tid, [&](int r) { return m0 + r; }, ln_mr);
+                                               tid, [&](int r) { return m0 + r; }, ev, ln_mr);
       return;
     }
 #pragma unroll
@@ -931,6 +941,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
                                                (live && w_off[i] != OOB) ? w_off[i] + kb : OOB, 0, 0, 0); \
   }
 
+  const EpiVec ev = epi_prefetch<BN, NT, EPI>(p, n0, tid);
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -1001,12 +1012,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   __syncthreads();
   auto rowmap = [&](int rr) { return srow[rr]; };
   if constexpr (EPI != EPI_ANY) {
-    epilogue_block<BM, BN, NT, TM, TN, EPI>(p, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap);
+    epilogue_block<BM, BN, NT, TM, TN, EPI>(p, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap, ev);
   } else {
     const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
                         (p.ld_rowbias & 3) == 0 && (p.ld_aux & 3) == 0;
     if (vec_ok) {
-      epilogue_block<BM, BN, NT, TM, TN, EPI>(p, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap);
+      epilogue_block<BM, BN, NT, TM, TN, EPI>(p, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap, ev);
       return;
     }
 #pragma unroll
