@@ -937,7 +937,7 @@ struct Builder {
     int HT = 0;                   // H * 32
   };
   static bool px_ok(int C, int heads, int Tc, int tokens) {
-    static const bool off = getenv("DF_NO_XPRE") && atoi(getenv("DF_NO_XPRE"));
+    const bool off = getenv("DF_NO_XPRE") && atoi(getenv("DF_NO_XPRE"));     // read per plan build: tests A/B both forms
     return !off && Tc >= 1 && Tc <= 32 && C % 64 == 0 && C % heads == 0 && (C / heads) % 8 == 0 && (heads * 32) % 64 == 0 &&
            tokens % 64 == 0;
   }

@@ -352,6 +352,27 @@ def test_full_autotuned_plans_vs_golden(full):
         full.engine.finalize()
 
 
+@pytest.mark.parametrize("Tc", [32, 17, 1])
+def test_full_cross_attention_forms_agree(full, monkeypatch, Tc):
+    """Cross-attention against operands precomputed from the context (engine.hip context_px: score GEMM with softmax
+    epilogue + output GEMM) vs the q-projection -> attention kernel -> out-projection form (DF_NO_XPRE=1), also for context
+    lengths below the 32-column head group (masked softmax).  attention_openai.py:152-194."""
+    x, c = rnd((2, 4, 16, 64), 300 + Tc), rnd((2, Tc, 768), 301 + Tc)
+    t = torch.tensor([700, 13]).cuda()
+    full.engine.finalize()
+    y_pre = full.apply_model(x.cuda(), t, c.cuda()).cpu()
+    monkeypatch.setenv("DF_NO_XPRE", "1")
+    full.engine.finalize()
+    try:
+        y_ref = full.apply_model(x.cuda(), t, c.cuda().clone()).cpu()
+    finally:
+        monkeypatch.delenv("DF_NO_XPRE")
+        full.engine.finalize()
+    err = rel_l2(y_pre, y_ref)
+    print(f"Tc={Tc}: precomputed-context vs attention-kernel form rel-L2 {err:.3e}")
+    assert torch.isfinite(y_pre).all() and err < 2e-2      # two bf16 roundings of the same math, each ~1e-2 from fp32
+
+
 def test_tiny_autotuned_plans_match_untuned(P):
     """The on-device autotuner (isolated ranking + in-situ refinement, engine.hip autotune_plan) only changes tile /
     split-K choices: an autotuned engine must reproduce the golden vectors for every plan type."""
