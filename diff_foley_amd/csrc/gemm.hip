@@ -131,7 +131,7 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
       const int threads = (tile == TILE_128x256 || tile == TILE_256x128) ? 512 : 256;
       const size_t ring = (size_t)(bm_ + bn_) * 128 * nst[tile], stage = (size_t)bm_ * (bn_ + 4) * 4 + (size_t)bm_ * 8;
       if (bm_ * p.ln_slots > 5 * threads) return false;
-      if (std::max(ring, stage) + (size_t)bm_ * p.ln_slots * 8 > 160 * 1024) return false;
+      if ((size_t)bm_ * p.ln_slots * 8 > ring || std::max(ring, stage) > 160 * 1024) return false;
     }
     if (p.stats && batch > 1) return false;
     if (p.w_rows > 0 && (batch > 1 || p.taps != 1 || p.w_rows % bm_ != 0 || p.M % p.w_rows != 0)) return false;

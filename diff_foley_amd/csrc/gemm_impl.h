@@ -471,11 +471,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
 
   // LayerNorm folded into this GEMM: the producer's per-row (sum, sumsq) partials of this tile's rows are one
   // contiguous run of BM * ln_slots float2; every thread requests its share FIRST (<= LNPT 8-byte loads, in flight
-  // under the operand prologue), parks it in LDS behind the ring, and thread r < BM folds row r's slots to
-  // (mean, rstd) after the main loop.  Nothing on the critical path waits for these loads.
+  // under the operand prologue), keeps it in registers through the main loop, and after the loop the shares are exchanged
+  // through the (dead) ring so that thread r < BM folds row r's slots to (mean, rstd).  Nothing on the critical path waits
+  // for these loads.
   constexpr int LNPT = 5;
-  constexpr size_t RING_B = (size_t)(BM + BN) * BK * 2 * NST, STAGE_B = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8;
-  constexpr size_t SCR_OFF = RING_B > STAGE_B ? RING_B : STAGE_B;
   const bool ln_on = MODE == 0 && (EPI == EPI_LNC || EPI == EPI_GEGLU || EPI == EPI_XS) && p.ln_stats != nullptr;
   float2 lnv[LNPT];
   if (ln_on) {
@@ -689,13 +688,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   if (NST > 3) DF_DMA(2, 2);
   if (NST > 4) DF_DMA(3, 3);
 
-  if (ln_on) {
-    float2* sLn = reinterpret_cast<float2*>(smem + SCR_OFF);
-#pragma unroll
-    for (int i = 0; i < LNPT; ++i)
-      if (tid + i * NT < BM * p.ln_slots) sLn[tid + i * NT] = lnv[i];
-  }
-
   int it = 0;
   while (it < nt) {
     DF_ITER(0);
@@ -717,8 +709,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   wait_vmcnt<0>();                     // dead-slot requests of the last iterations must land before LDS is released
 
   float2 ln_mr = make_float2(0.f, 1.f);
-  if (ln_on && tid < BM) {             // the slots were parked before the first K-step barrier: visible to every thread
-    const float2* sLn = reinterpret_cast<const float2*>(smem + SCR_OFF) + tid * p.ln_slots;
+  if (ln_on) {
+    // the partials rode in registers through the main loop (no LDS beside the ring: every tile shape stays available to
+    // the LayerNorm-folded GEMMs of the 1280-channel level); now the ring is dead and they are exchanged through it
+    __builtin_amdgcn_s_barrier();      // every wave is done reading the ring
+    float2* sLn = reinterpret_cast<float2*>(smem);
+#pragma unroll
+    for (int i = 0; i < LNPT; ++i)
+      if (tid + i * NT < BM * p.ln_slots) sLn[tid + i * NT] = lnv[i];
+    __syncthreads();
+  }
+  if (ln_on && tid < BM) {
+    const float2* sLn = reinterpret_cast<const float2*>(smem) + tid * p.ln_slots;
     float s1 = 0.f, s2 = 0.f;
     for (int i = 0; i < p.ln_slots; ++i) {
       s1 += sLn[i].x;
@@ -1038,7 +1040,8 @@ hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
   constexpr size_t stage = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8;          // epilogue tile + (mean, rstd) row table
   const size_t base = ring > stage ? ring : stage;
   // LayerNorm-folded GEMMs park the producer's row partials behind the ring: BM * ln_slots float2
-  const size_t lds = base + ((MODE == 0 && (EPI == EPI_LNC || EPI == EPI_GEGLU || EPI == EPI_XS) && p.ln_stats) ? (size_t)BM * p.ln_slots * 8 : 0);
+  const size_t lds = base;           // LayerNorm row partials are exchanged through the dead ring after the main loop
+  if ((size_t)BM * p.ln_slots * 8 > ring) return hipErrorInvalidValue;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
