@@ -212,10 +212,13 @@ class LatentDiffusion:
         c = self._cond_tensor(cond)
         # the hoisted K/V projections are reused only for the very same bytes: storage, shape AND torch's version
         # counter (an in-place c.copy_() / c.zero_() bumps it), otherwise they are recomputed like the reference does
-        key = (c.data_ptr(), tuple(c.shape), c._version, c.device)
-        if self._ctx_owner != key:
+        # The cached tensor is held by a STRONG reference: its storage cannot be handed to another tensor while it is the
+        # cache key (the caching allocator gives a freed block to the next tensor of the same size -- a data_ptr()-only key
+        # would then skip set_context for a different conditioning).
+        key = (tuple(c.shape), c._version)
+        if self._ctx_owner is None or self._ctx_owner[0] is not c or self._ctx_owner[1] != key:
             eng.set_context(c)
-            self._ctx_owner = key
+            self._ctx_owner = (c, key)
         return eng.unet_forward(x_noisy, t)
 
     @torch.no_grad()

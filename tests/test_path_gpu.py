@@ -352,6 +352,27 @@ def test_full_autotuned_plans_vs_golden(full):
         full.engine.finalize()
 
 
+def test_apply_model_context_cache_is_not_fooled_by_address_reuse(full):
+    """apply_model reuses the hoisted context work only for the very same tensor object and version.  A NEW conditioning
+    tensor that the caching allocator places at the address of a freed one must be picked up (round 2: a data_ptr()-keyed
+    cache silently kept the old context)."""
+    x, t = rnd((2, 4, 16, 64), 400).cuda(), torch.tensor([500, 37]).cuda()
+    c1 = rnd((2, 32, 768), 401).cuda()
+    y1 = full.apply_model(x, t, c1).cpu()
+    addr = c1.data_ptr()
+    del c1
+    c2 = rnd((2, 32, 768), 402).cuda()           # same size: the allocator hands back the block just freed
+    reused = c2.data_ptr() == addr
+    y2 = full.apply_model(x, t, c2).cpu()
+    c2b = c2.clone()
+    y2_ref = full.apply_model(x, t, c2b).cpu()   # a different object: always re-set
+    print(f"address reused: {reused}; |y2 - y1| rel {rel_l2(y2, y1):.3e}, |y2 - y2_ref| rel {rel_l2(y2, y2_ref):.3e}")
+    assert rel_l2(y2, y2_ref) < 1e-6 and rel_l2(y2, y1) > 1e-2
+    c2.mul_(0.5)                                 # in-place edit bumps the version counter: must be picked up as well
+    y3 = full.apply_model(x, t, c2).cpu()
+    assert rel_l2(y3, y2) > 1e-3
+
+
 @pytest.mark.parametrize("Tc", [32, 17, 1])
 def test_full_cross_attention_forms_agree(full, monkeypatch, Tc):
     """Cross-attention against operands precomputed from the context (engine.hip context_px: score GEMM with softmax
