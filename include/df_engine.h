@@ -103,8 +103,10 @@ int df_cavp_encode(df_ctx* ctx, const float* video_dev, float* out_dev, int B, i
                    void* stream);
 
 /* ---- UNetModel.forward (openai_unetmodel.py:710-742) through LatentDiffusion.apply_model (ddpm.py:925-1026).
- * The cross-attention context is step-invariant, so it is set once per sample() call: K/V projections of
- * all 16 SpatialTransformers are computed here, not per step.  context [N][T][context_dim] fp32. */
+ * The cross-attention context is step-invariant, so it is set once per sample() call: everything of the 16
+ * SpatialTransformers' cross-attention that depends on the context only is computed here, not per step -- the K/V
+ * projections and, for T <= 32, their products with the (LayerNorm-folded) query and output projections, so that a step
+ * runs cross-attention as two GEMMs against per-sample operands.  context [N][T][context_dim] fp32. */
 int df_unet_set_context(df_ctx* ctx, const float* context_dev, int N, int T, void* stream);
 /* x [N][C][H][W] fp32, t [N] fp32 (integer or fractional timesteps), eps_out [N][C][H][W] fp32. */
 int df_unet_forward(df_ctx* ctx, const float* x_dev, const float* t_dev, float* eps_out_dev, int N, int H, int W,
