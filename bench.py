@@ -107,13 +107,17 @@ def golden_mel_mae(model, dev):
     ref = g["ddim25_mel_21"]
     mae = float(np.abs(mel - ref).mean())
     span = float(ref.max() - ref.min())
-    # same bound as tests/test_path_gpu.py::test_full_ddim25_mel_mae: MAE below 1e-3 of the mel range of this
-    # random-weight model (training mels live in [0, 1]); a regression in any kernel of the path shows up here
-    ok = mae / span < 1e-3
-    if not ok:
+    # parity_ok is the north-star bound as BASELINE.json words it: MAE < 1e-3 in mel units (absolute).  The fp16 operand
+    # build meets it; the bf16 build (2^-9 per operand) does not and says so.  The range-normalised figure (MAE below 1e-3
+    # of the mel range of this random-weight model; training mels live in [0, 1]) is the regression tripwire both builds
+    # must pass (tests/test_path_gpu.py::test_full_ddim25_mel_mae).
+    ok_abs = mae < 1e-3
+    ok_rng = mae / span < 1e-3
+    if not ok_rng:
         print(f"bench.py: PARITY REGRESSION -- mel MAE {mae:.3e} over a range of {span:.2f} exceeds 1e-3 of the range",
               file=sys.stderr, flush=True)
-    return dict(mel_mae=mae, mel_range=span, mel_std=float(ref.std()), parity_ok=bool(ok),
+    return dict(mel_mae=mae, mel_range=span, mel_std=float(ref.std()), parity_ok=bool(ok_abs),
+                parity_ok_range_normalised=bool(ok_rng),
                 z_rel_l2=float(np.linalg.norm(z.cpu().numpy() - g["ddim25_z_21"]) / np.linalg.norm(g["ddim25_z_21"])))
 
 
@@ -194,7 +198,22 @@ def run_mode(precision, sd_dev, a, dev, rank, world, lo, hi, barrier, dump_ops="
             sub = {"st_ms": st_ms, "rc_ms": rc_ms, "st_launches": sum(1 for r in rows if r["tag"].startswith(("st.", "attn.")) or r["tag"] == "layernorm")}
         if not dump_ops:
             os.remove(dump)
-    return dict(model=model, dt=dt, prof=prof, sub=sub, stats=eng.plan_stats(), t_setup=t_setup, dist=dist_info)
+    # ---- the same workload through the reference-shaped entry point (LatentDiffusion.sample_log_diff_sampler: Python DDIM
+    # loop, set_context once per call, intermediates bookkeeping): 4 calls x 25 steps, reported beside the headline
+    loop = None
+    if rank == 0:
+        x0 = synth.synthetic_xT(hi - lo, first_index=lo).to(dev)
+        model.sample_log_diff_sampler(c, hi - lo, "DDIM", 25, unconditional_guidance_scale=4.5, unconditional_conditioning=uc, x_T=x0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ncall = 4
+        for _ in range(ncall):
+            model.sample_log_diff_sampler(c, hi - lo, "DDIM", 25, unconditional_guidance_scale=4.5, unconditional_conditioning=uc, x_T=x0)
+        torch.cuda.synchronize()
+        dl = time.perf_counter() - t1
+        loop = {"steps": 25 * ncall, "steps_per_s": round(25 * ncall / dl, 3), "ms_per_step": round(dl / (25 * ncall) * 1e3, 4),
+                "what": "LatentDiffusion.sample_log_diff_sampler('DDIM', 25 steps, CFG 4.5) x 4 calls incl. set_context per call"}
+    return dict(model=model, dt=dt, prof=prof, sub=sub, stats=eng.plan_stats(), t_setup=t_setup, dist=dist_info, loop=loop)
 
 
 def vae_roofline(model, dev, B):
@@ -228,8 +247,10 @@ def main():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the second operand type and the in-bench golden check")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE decode roofline block (profiling runs of the step only)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
-                    help="MFMA operand type of the headline value (bf16 = BASELINE configs[1]; fp16 = libdfengine_f16.so)")
+    ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16"],
+                    help="MFMA operand type of the headline value.  fp16 (libdfengine_f16.so) is the default: same MFMA rate and "
+                         "the operand type that meets the north-star bound (mel MAE < 1e-3 absolute); bf16 = the literal "
+                         "wording of BASELINE configs[1], reported beside it in `modes` (mel MAE 4e-3)")
     ap.add_argument("--dump-ops", default="", help="write a per-op CSV of the instrumented pass")
     a = ap.parse_args()
 
@@ -274,7 +295,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": name[a.precision],
             "data": "synthetic (procedural weights of the full 859.5M-param UNet, unit-norm CAVP-like features, seeded x_T)",
             "config": {"workload": "BASELINE.json configs[1]: single MI355X, batch=4 (UNet batch 8), 25-step DDIM, "
-                                   + ("bf16" if a.precision == "bf16" else "fp16") + " UNet, 32 CAVP context frames, latent 4x16x64, guidance 4.5",
+                                   + ("bf16" if a.precision == "bf16" else "fp16 (16-bit MFMA operands at the bf16 rate; the "
+                                      "operand type that meets mel MAE < 1e-3 -- the bf16 build is timed in `modes`)")
+                                   + " UNet, 32 CAVP context frames, latent 4x16x64, guidance 4.5",
                        "batch_per_gpu": B, "global_batch": G, "parallelism": f"batch-shard x{world}, no step-loop collectives",
                        "weight_distribution": main_run["dist"],
                        "engine_setup_s": round(main_run["t_setup"], 3)},
@@ -298,6 +321,7 @@ def main():
                                      "gb_per_s": round((1.0235 + 0.0403 * N) / (sub["rc_ms"] * norm) * 1e3, 1),
                                      "frac_of_hbm_peak": round((1.0235 + 0.0403 * N) / (sub["rc_ms"] * norm) * 1e3 / 8000.0, 4),
                                      "tflops": round(81.62 * N / (sub["rc_ms"] * norm), 1)}},
+            "sampler_loop": main_run["loop"],
             "kernel_ms_per_step": {k: round(v, 4) for k, v in fam_ms.items()},
             "kernel_ms_per_step_instrumented": {k: round(v["ms"] / a.steps, 4) for k, v in prof.items()},
             "kernel_launches_per_step": {k: int(v["launches"] // a.steps) for k, v in prof.items()},

@@ -89,9 +89,13 @@ struct Plan {
   double gemm_flops = 0, weight_bytes = 0;
   size_t ext_hint = 0;           // largest external (caller-owned) buffer the plan touches, when above 32 MB (autotune dummies)
   size_t n_ctx = 0;              // UNet plans: ops [0, n_ctx) depend on the context only (run by df_unet_set_context)
+  std::string name;              // cache key (debug labels)
+  void* chk_list = nullptr;      // debug checksums: device array of (pointer, 32-bit words) of every workspace block
+  int chk_n = 0;
   ~Plan() {
     for (auto& b : owned) (void)hipFree(b.p);
     if (partial) (void)hipFree(partial);
+    if (chk_list) (void)hipFree(chk_list);
   }
   void* alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
@@ -155,12 +159,19 @@ struct df_ctx {
   std::vector<const void*> prof_op;
   size_t prof_used = 0;
   hipStream_t pack_stream = nullptr;
+  // debug: after every op, a 64-bit checksum of ALL workspace bytes of the plan (df_debug_checksums): two runs of the same
+  // inputs must give the same sequence; the first index that differs names the op whose launch was not reproducible
+  bool chk_on = false;
+  unsigned long long* chk_dev = nullptr;
+  size_t chk_used = 0, chk_cap = 0;
+  std::vector<std::string> chk_label;
 
   ~df_ctx() {
     plans.clear();
     for (auto& kv : raw) (void)hipFree(kv.second.d);
     for (void* p : packed_blocks) (void)hipFree(p);
     for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
+    if (chk_dev) (void)hipFree(chk_dev);
   }
 
   const RawT& rt(const std::string& name) const {
@@ -2058,6 +2069,42 @@ int op_family(const Op& o) {
   return 4;
 }
 
+struct ChkBuf { const uint32_t* p; unsigned long long words; };
+// Order-independent (integer) checksum of a list of buffers: grid (x, buffer), one 64-bit atomic add per wavefront.
+__global__ __launch_bounds__(256) void checksum_kernel(const ChkBuf* list, unsigned long long* slot) {
+  const ChkBuf b = list[blockIdx.y];
+  unsigned long long acc = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < b.words; i += (unsigned long long)gridDim.x * 256)
+    acc += (unsigned long long)b.p[i] * (unsigned long long)((i & 1023u) + 1u);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(slot, acc);
+}
+
+void checksum_after_op(df_ctx* c, Plan* pl, size_t op_index, hipStream_t s) {
+  if (!pl->chk_list) {
+    std::vector<ChkBuf> v;
+    for (auto& b : pl->owned) v.push_back({(const uint32_t*)b.p, (unsigned long long)(b.bytes / 4)});
+    if (pl->partial) v.push_back({(const uint32_t*)pl->partial, (unsigned long long)(pl->partial_bytes / 4)});
+    pl->chk_n = (int)v.size();
+    if (!v.empty()) {
+      HIPCHK(hipMalloc(&pl->chk_list, v.size() * sizeof(ChkBuf)));
+      HIPCHK(hipMemcpy(pl->chk_list, v.data(), v.size() * sizeof(ChkBuf), hipMemcpyHostToDevice));
+    }
+  }
+  if (c->chk_used >= c->chk_cap || pl->chk_n == 0) return;
+  hipLaunchKernelGGL(checksum_kernel, dim3(64, pl->chk_n), dim3(256), 0, s, (const ChkBuf*)pl->chk_list, c->chk_dev + c->chk_used);
+  char lab[160];
+  snprintf(lab, sizeof lab, "%s#%zu:%s", pl->name.c_str(), op_index, pl->ops[op_index].tag);
+  if (pl->ops[op_index].is_gemm) {
+    const Op& o = pl->ops[op_index];
+    const size_t n = strlen(lab);
+    snprintf(lab + n, sizeof lab - n, " %dx%dx%d taps%d tile%d sk%d", o.gp.M, o.gp.N, o.gp.K, o.gp.taps, o.tile, o.gp.splitk);
+  }
+  c->chk_label.push_back(lab);
+  ++c->chk_used;
+}
+
 void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const RunArgs& a) {
   for (size_t i = begin; i < end; ++i) {
     Op& o = pl->ops[i];
@@ -2093,6 +2140,7 @@ void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const
       c->prof_op.push_back(&o);
       c->prof_used += 2;
     }
+    if (c->chk_on) checksum_after_op(c, pl, i, s);
   }
 }
 
@@ -2349,6 +2397,7 @@ Plan* get_plan(df_ctx* c, const std::string& key, const std::function<void(Plan*
     HIPCHK(hipStreamSynchronize(c->pack_stream));
   }
   Plan* r = p.get();
+  r->name = key;
   c->plans[key] = std::move(p);
   return r;
 }
@@ -2793,6 +2842,40 @@ int df_plan_count(df_ctx* c, int64_t* n_plans, int64_t* workspace_bytes) {
       b += (int64_t)kv.second->partial_bytes;
     }
     *workspace_bytes = b;
+  });
+}
+
+int df_debug_checksums(df_ctx* c, int enable, int64_t capacity) {
+  return guard([&] {
+    HIPCHK(hipDeviceSynchronize());
+    c->chk_on = enable != 0;
+    c->chk_used = 0;
+    c->chk_label.clear();
+    if (enable) {
+      const size_t cap = capacity > 0 ? (size_t)capacity : (size_t)1 << 16;
+      if (cap > c->chk_cap) {
+        if (c->chk_dev) (void)hipFree(c->chk_dev);
+        HIPCHK(hipMalloc((void**)&c->chk_dev, cap * 8));
+        c->chk_cap = cap;
+      }
+      HIPCHK(hipMemset(c->chk_dev, 0, c->chk_cap * 8));
+    }
+  });
+}
+
+int df_debug_checksums_read(df_ctx* c, uint64_t* out, int64_t cap, int64_t* n) {
+  return guard([&] {
+    HIPCHK(hipDeviceSynchronize());
+    *n = (int64_t)c->chk_used;
+    const size_t k = std::min((size_t)std::max<int64_t>(cap, 0), c->chk_used);
+    if (k) HIPCHK(hipMemcpy(out, c->chk_dev, k * 8, hipMemcpyDeviceToHost));
+  });
+}
+
+int df_debug_checksum_label(df_ctx* c, int64_t index, char* buf, int64_t len) {
+  return guard([&] {
+    if (index < 0 || (size_t)index >= c->chk_label.size() || len <= 0) fail("checksum label %lld out of range", (long long)index);
+    snprintf(buf, (size_t)len, "%s", c->chk_label[(size_t)index].c_str());
   });
 }
 

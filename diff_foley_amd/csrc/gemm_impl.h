@@ -875,7 +875,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   // ---- staging coordinates.  Thread (r0 = tid>>3, slot = tid&7) fills LDS slot `slot` of rows r0 + RPP*i with the
   // source chunk slot ^ ((row>>1)&7)   (RPP is a multiple of 16, so the swizzle term is the same for every pass).
   const int r0 = tid >> 3;
-  const int c8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;
+  const int c8 = ((tid & 7) ^ ((r0 >> 1) & 7)) * 8;      // weight rows: consecutive rows, swizzle by row pair
+  // Halo rows are read by the MFMA fragments in runs of TW pixels of consecutive image rows, so a swizzle by the LINEAR halo
+  // row ((hr >> 1) & 7) puts two of the 16 lanes of a ds_read_b128 group on one 16-B slot (2-way conflicts on ~40 % of the
+  // LDS cycles, SQ_LDS_BANK_CONFLICT).  The halo slot is swizzled by the pixel's x-pair plus SC * (image row counter):
+  // conflict-free for TW = 16 (SC = 0) and TW = 8 (SC = 4) at every tap shift.
+  const int SC = (TW == 16) ? 0 : 4;
   constexpr int MAXAP = 12;
   unsigned a_off[MAXAP];
 #pragma unroll
@@ -886,11 +891,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
       const int pi = hr / HWp, rem = hr - pi * HWp;
       const int hy = rem / (TW + 2), hx = rem - hy * (TW + 2);
       const int g = mt * PB + pi;                // global patch id
+      const int ca = ((tid & 7) ^ (((hx >> 1) + SC * (pi * (TH + 2) + hy)) & 7)) * 8;
       if (g < npatch) {
         const int n = g / (npy * npx), gr = g - n * (npy * npx);
         const int y = (gr / npx) * TH + hy - 1, x = (gr % npx) * TW + hx - 1;
         if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd)
-          off = (unsigned)((((long)(n * p.H + y) * p.Wd + x) * p.lda + c8) * 2);
+          off = (unsigned)((((long)(n * p.H + y) * p.Wd + x) * p.lda + ca) * 2);
       }
     }
     a_off[i] = off;
@@ -903,13 +909,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   }
 
   // ---- MFMA row -> halo row of tap (0,0) and output pixel index
-  int hb[TM];
+  int hb[TM], hbx[TM], hbq[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int r = wm * WTM + i * 32 + l31;
     const int pi = r / PPX, rem = r - pi * PPX;
     const int y = rem / TW, x = rem - y * TW;
     hb[i] = pi * HWp + y * (TW + 2) + x;
+    hbx[i] = x;
+    hbq[i] = SC * (pi * (TH + 2) + y);
   }
   int fb[TN], sb[TN];
 #pragma unroll
@@ -973,7 +981,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                            \
       const int hr = hb[i] + dy_ * (TW + 2) + dx_;                                              \
       ha_[i] = hr * BK;                                                                         \
-      sa_[i] = (hr >> 1) & 7;                                                                   \
+      sa_[i] = (((hbx[i] + dx_) >> 1) + hbq[i] + SC * dy_) & 7;                                 \
     }                                                                                           \
     _Pragma("unroll") for (int s = 0; s < BK / 16; ++s) {                                       \
       bf16x8 af[TM], bfr[TN];                                                                   \

@@ -85,6 +85,9 @@ _SIGS = {
     "df_profile_begin": [C.c_void_p],
     "df_profile_end": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "df_profile_dump": [C.c_void_p, C.c_char_p],
+    "df_debug_checksums": [C.c_void_p, C.c_int, C.c_int64],
+    "df_debug_checksums_read": [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(C.c_int64)],
+    "df_debug_checksum_label": [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64],
     "df_test_gemm_epi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                          C.c_int, C.c_int, C.c_int, C.c_void_p],
     "df_test_gemm_dual": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -118,8 +121,8 @@ def lib(precision=None):
                                "(there is no CPU/torch fallback for the sampling path)")
         L = C.CDLL(path)
         for name, args in _SIGS.items():
-            if os.environ.get("DF_LIB_OVERRIDE") and name.startswith("df_test_") and not hasattr(L, name):
-                continue                      # A/B against an older build that predates a unit-test entry point
+            if os.environ.get("DF_LIB_OVERRIDE") and name.startswith(("df_test_", "df_debug_")) and not hasattr(L, name):
+                continue                      # A/B against an older build that predates a unit-test / debug entry point
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = C.c_int
@@ -370,6 +373,22 @@ class Engine:
 
     def profile_dump(self, path):
         _chk(self.L.df_profile_dump(self._h, path.encode()), self.L)
+
+    def debug_checksums(self, enable, capacity=1 << 16):
+        """Debug: checksum every plan workspace after every op (see include/df_engine.h)."""
+        _chk(self.L.df_debug_checksums(self._h, int(bool(enable)), int(capacity)), self.L)
+
+    def debug_checksums_read(self):
+        n = C.c_int64()
+        _chk(self.L.df_debug_checksums_read(self._h, None, 0, C.byref(n)), self.L)
+        out = (C.c_uint64 * max(n.value, 1))()
+        _chk(self.L.df_debug_checksums_read(self._h, out, n.value, C.byref(n)), self.L)
+        return list(out[:n.value])
+
+    def debug_checksum_label(self, i):
+        buf = C.create_string_buffer(200)
+        _chk(self.L.df_debug_checksum_label(self._h, int(i), buf, 200), self.L)
+        return buf.value.decode()
 
     def plan_count(self):
         n, b = C.c_int64(), C.c_int64()

@@ -195,6 +195,12 @@ int df_profile_begin(df_ctx* ctx);
 int df_profile_end(df_ctx* ctx, double* ms_by_family, int64_t* count_by_family);
 /* CSV (tag,M,N,K,taps,stride,ups,batch,tile,splitk,ms) of every op of the region last closed by df_profile_end. */
 int df_profile_dump(df_ctx* ctx, const char* path);
+/* Debug: while enabled, every op of every plan is followed by a 64-bit (order-independent, integer) checksum over ALL
+ * workspace bytes of its plan; the sequence of checksums of two runs on identical inputs must be identical, and the first
+ * index that differs names the launch that was not reproducible (tools/chk_probe.py).  capacity = checksum slots. */
+int df_debug_checksums(df_ctx* ctx, int enable, int64_t capacity);
+int df_debug_checksums_read(df_ctx* ctx, uint64_t* out, int64_t cap, int64_t* n);
+int df_debug_checksum_label(df_ctx* ctx, int64_t index, char* buf, int64_t len);
 /* Run ONE op family in isolation for unit tests (see tests/test_kernels_gpu.py). */
 int df_test_gemm_epi(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, const float* res_dev, void* C_dev,
                      int M, int N, int K, int act /*0 none, 1 SiLU, 2 ReLU*/, int out_operand, int tile, int splitk,
