@@ -213,6 +213,11 @@ def run_mode(precision, sd_dev, a, dev, rank, world, lo, hi, barrier, dump_ops="
         dl = time.perf_counter() - t1
         loop = {"steps": 25 * ncall, "steps_per_s": round(25 * ncall / dl, 3), "ms_per_step": round(dl / (25 * ncall) * 1e3, 4),
                 "what": "LatentDiffusion.sample_log_diff_sampler('DDIM', 25 steps, CFG 4.5) x 4 calls incl. set_context per call"}
+    if world > 1:       # every rank's pack / broadcast / import seconds in the one JSON line (first real SCALE run shows them)
+        infos = [None] * world
+        torch.distributed.all_gather_object(infos, dict(rank=rank, **{k: (round(v, 4) if isinstance(v, float) else v)
+                                                                   for k, v in (dist_info or {}).items()}))
+        dist_info = {"per_rank": infos}
     return dict(model=model, dt=dt, prof=prof, sub=sub, stats=eng.plan_stats(), t_setup=t_setup, dist=dist_info, loop=loop)
 
 

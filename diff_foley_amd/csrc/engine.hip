@@ -172,6 +172,7 @@ struct df_ctx {
     for (void* p : packed_blocks) (void)hipFree(p);
     for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
     if (chk_dev) (void)hipFree(chk_dev);
+    if (ctx_copy) (void)hipFree(ctx_copy);
   }
 
   const RawT& rt(const std::string& name) const {
@@ -2561,6 +2562,7 @@ int df_finalize(df_ctx* c) {
       c->packed_blocks.clear();
       c->block_bytes.clear();
       c->packed.clear();
+      if (c->ctx_copy) (void)hipFree(c->ctx_copy);
       c->ctx_copy = nullptr;
       c->ctx_copy_bytes = 0;
       c->ctx_N = c->ctx_T = 0;
@@ -2622,8 +2624,12 @@ int df_unet_set_context(df_ctx* c, const float* context, int N, int T, void* str
     }
     // keep a device copy so plans created later can still be primed
     const size_t bytes = (size_t)N * T * c->ucfg.context_dim * 4;
-    if (bytes > c->ctx_copy_bytes) {
-      c->ctx_copy = (float*)c->pmalloc(bytes);
+    if (bytes > c->ctx_copy_bytes) {     // grow-only scratch, NOT a packed operand: freed here, never exported
+      if (c->ctx_copy) {
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        (void)hipFree(c->ctx_copy);
+      }
+      HIPCHK(hipMalloc((void**)&c->ctx_copy, (bytes + 255) & ~(size_t)255));
       c->ctx_copy_bytes = bytes;
     }
     HIPCHK(hipMemcpyAsync(c->ctx_copy, context, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -2659,15 +2665,21 @@ int df_unet_forward_cfg(df_ctx* c, const float* x, const float* t, float* out, i
   return guard([&] { unet_run(c, x, t, out, 2 * B, H, W, true, scale, (hipStream_t)stream); });
 }
 
+// One GEMM operand is addressed with 32-bit buffer offsets (< 2 GiB): the decoder's widest activation is 8H x 8W pixels x
+// 2*ch channels per sample, so large batches run as slices of at most this many samples (shared by df_vae_decode / df_prepack).
+static int vae_chunk(df_ctx* c, int H, int W) {
+  const size_t per_sample = (size_t)(H << (c->vcfg.n_mult - 1)) * (W << (c->vcfg.n_mult - 1)) * (size_t)c->vcfg.ch * 2 * 2;
+  const int chunk = (int)std::max<size_t>(1, (((size_t)1 << 31) - 1) / std::max<size_t>(per_sample, 1));
+  return std::min(chunk, 16);
+}
+
 int df_vae_decode(df_ctx* c, const float* z, float* out, int B, int H, int W, void* stream) {
   return guard([&] {
     if (!c->has_vae) fail("vae not configured");
     // One GEMM operand is addressed with 32-bit buffer offsets (< 2 GiB): the decoder's widest activation is
     // 8 x H x 8 x W pixels x 2*ch channels per sample, so large batches run as slices of at most `chunk` samples through
     // the plan of that size (same kernels, same results; no host round trip between slices).
-    const size_t per_sample = (size_t)(H << (c->vcfg.n_mult - 1)) * (W << (c->vcfg.n_mult - 1)) * (size_t)c->vcfg.ch * 2 * 2;
-    int chunk = (int)std::max<size_t>(1, (((size_t)1 << 31) - 1) / std::max<size_t>(per_sample, 1));
-    chunk = std::min(chunk, 16);
+    const int chunk = vae_chunk(c, H, W);
     const int zc = c->vcfg.z_channels, up = 1 << (c->vcfg.n_mult - 1);
     for (int b0 = 0; b0 < B; b0 += chunk) {
       const int nb = std::min(chunk, B - b0);
@@ -2716,7 +2728,11 @@ int df_prepack(df_ctx* c, int B, int H, int W, int T) {
   return guard([&] {
     HIPCHK(hipSetDevice(c->device));
     if (c->has_unet) (void)unet_plan(c, 2 * B, H, W, T, true);
-    if (c->has_vae) (void)get_plan(c, keyf("vae_%d_%d_%d", B, H, W), [&](Plan* pl) { build_vae(c, pl, B, H, W); });
+    if (c->has_vae) {     // the plans df_vae_decode will actually run: slices of at most vae_chunk() samples + the remainder
+      const int chunk = vae_chunk(c, H, W);
+      for (int nb : {std::min(B, chunk), B % chunk})
+        if (nb > 0) (void)get_plan(c, keyf("vae_%d_%d_%d", nb, H, W), [&](Plan* pl) { build_vae(c, pl, nb, H, W); });
+    }
     if (c->has_cond) (void)get_plan(c, keyf("cond_%d_%d", B, T), [&](Plan* pl) { build_cond(c, pl, B, T); });
     HIPCHK(hipStreamSynchronize(c->pack_stream));
   });
@@ -2842,6 +2858,40 @@ int df_plan_count(df_ctx* c, int64_t* n_plans, int64_t* workspace_bytes) {
       b += (int64_t)kv.second->partial_bytes;
     }
     *workspace_bytes = b;
+  });
+}
+
+// The autotuner's choices ("key tile splitk gm" per line) as text: rank 0 tunes, the text travels with the packed blob and
+// every other rank configures its plans from it -- identical tiles / split-K (= identical fp32 summation order, bit-equal
+// results across ranks) and ONE tuning pass per job instead of one per rank.
+int df_tune_cache_export(char* buf, int64_t cap, int64_t* n) {
+  return guard([&] {
+    std::string t;
+    for (auto& kv : tune_cache()) {
+      char line[224];
+      snprintf(line, sizeof line, "%s %d %d %d\n", kv.first.c_str(), kv.second.tile, kv.second.sk, kv.second.gm);
+      t += line;
+    }
+    *n = (int64_t)t.size();
+    if (buf && cap > 0) memcpy(buf, t.data(), std::min((size_t)cap, t.size()));
+  });
+}
+
+int df_tune_cache_import(const char* text, int64_t n) {
+  return guard([&] {
+    std::string t(text, text + std::max<int64_t>(n, 0));
+    size_t pos = 0;
+    while (pos < t.size()) {
+      size_t e = t.find('\n', pos);
+      if (e == std::string::npos) e = t.size();
+      char key[160];
+      TuneChoice ch;
+      if (sscanf(t.substr(pos, e - pos).c_str(), "%159s %d %d %d", key, &ch.tile, &ch.sk, &ch.gm) == 4) {
+        if (ch.tile < 0 || ch.tile >= TILE_ALL || ch.sk < 1 || ch.sk > 64) fail("tune cache line out of range: %s", key);
+        tune_cache()[key] = ch;
+      }
+      pos = e + 1;
+    }
   });
 }
 

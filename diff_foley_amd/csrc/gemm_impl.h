@@ -664,20 +664,34 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
         ACC[i][j] = DF_MFMA_32x32x16(SRCA[i], SRCB[j], ACC[i][j]); \
   }
   // One K tile out of ring slot ST; refills the slot of the previous tile ((ST + NST - 1) % NST).
+  // The K-step boundary (counted vmcnt wait + s_barrier for tile it+1) sits BEFORE the last MFMA group of tile `it`, behind an
+  // explicit s_waitcnt lgkmcnt(0): a ring slot may only be handed back to the DMA engine once every wave's ds_reads of it have
+  // COMPLETED, not merely issued.  An LDS-DMA write is not ordered behind another wave's queued ds_read, and s_barrier does
+  // not wait for LDS reads in flight; without the lgkmcnt wait the compiler sank the tail MFMAs (and the waits of their
+  // operand reads) below the barrier, and a refill landing before a delayed read gave run-to-run differences when a second
+  // process shared the CUs (tools/chk_probe.py: first diverging op always a halo conv; DESIGN.md section 4 "Determinism").
+  // The last fragment reads are issued one MFMA group before the wait, so it normally costs nothing.
+#define DF_RING_SYNC(VM)                                                                          \
+  {                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* my reads of the slot about to be refilled are done */ \
+    wait_vmcnt<(VM)>();              /* next tile landed: <= NST-2 younger tiles of this wave in flight */ \
+    __builtin_amdgcn_s_barrier();    /* all parts of it visible; everyone is done with the current slot */  \
+  }
 #define DF_ITER(ST)                                                                               \
   {                                                                                             \
-    wait_vmcnt<(NST - 2) * LPT>();   /* tile `it` landed: <= NST-2 younger tiles of this wave in flight */ \
-    __builtin_amdgcn_s_barrier();    /* all parts of tile `it` visible; everyone is done with tile it-1 */  \
-    bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];                                                      \
+    bf16x8 a0[TM], b0[TN], a1[TM], b1[TN], a2[TM], b2[TN];                                      \
     DF_FRAG(a0, b0, 0, ST);                                                                     \
     DF_DMA(it + NST - 1, ((ST) + NST - 1) % NST);                                               \
     DF_FRAG(a1, b1, 1, ST);                                                                     \
+    DF_FRAG(a2, b2, 2, ST);                                                                     \
     DF_MMA(a0, b0, acc);                                                                        \
-    DF_FRAG(a0, b0, 2, ST);                                                                     \
+    DF_FRAG(a0, b0, 3, ST);                                                                     \
+    __builtin_amdgcn_sched_barrier(0);   /* the last reads are ISSUED here: two MFMA groups of cover before the wait */ \
     DF_MMA(a1, b1, acc);                                                                        \
-    DF_FRAG(a1, b1, 3, ST);                                                                     \
+    DF_MMA(a2, b2, acc);                                                                        \
+    __builtin_amdgcn_sched_barrier(0);   /* ... and those MFMA groups stay in front of it */           \
+    DF_RING_SYNC((NST - 2) * LPT);                                                              \
     DF_MMA(a0, b0, acc);                                                                        \
-    DF_MMA(a1, b1, acc);                                                                        \
     ++it;                                                                                       \
   }
 
@@ -689,6 +703,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   if (NST > 4) DF_DMA(3, 3);
 
   int it = 0;
+  DF_RING_SYNC((NST - 2) * LPT);       // tile 0 landed and visible
   while (it < nt) {
     DF_ITER(0);
     if (it >= nt) break;
@@ -965,12 +980,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
 #pragma unroll
   for (int t = 0; t < NSTW - 1; ++t) DF_HALO_W(t, t);
 
-  // One tap.  VM = loads of this wave allowed to be still in flight when W(c,t) must have landed.
-#define DF_TAP(T)                                                                        \
+  // Wait for the operands of tap T (W(c,T); at T = 0 also the halo of slice c) and hand the ring slot / halo buffer read by
+  // the previous tap back to the DMA engine.  VM = loads of this wave allowed to be still in flight.  The lgkmcnt(0) makes
+  // sure this wave's ds_reads of the slot to be refilled have COMPLETED (see DF_RING_SYNC of the generic kernel).
+#define DF_HALO_SYNC(T)                                                                           \
   {                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          \
     if ((T) >= 1 && (T) <= NSTW - 1) wait_vmcnt_dyn((NSTW - 2) * WPASS + APASS);               \
     else wait_vmcnt<(NSTW - 2) * WPASS>();                                                      \
     __builtin_amdgcn_s_barrier();                                                               \
+  }
+#define DF_HALO_READ(DA, DB, S)                                                                   \
+  {                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+      DA[i] = *reinterpret_cast<const bf16x8*>(a + ha_[i] + (((2 * (S) + lh) ^ sa_[i]) << 3));  \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
+      DB[j] = *reinterpret_cast<const bf16x8*>(b + fb[j] + (((2 * (S) + lh) ^ sb[j]) << 3));    \
+  }
+#define DF_HALO_MMA(SA, SB)                                                                       \
+  {                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
+        acc[i][j] = DF_MFMA_32x32x16(SA[i], SB[j], acc[i][j]);                                  \
+  }
+  // One tap: the boundary to the NEXT tap sits before the last MFMA group (its fragment reads were issued one group earlier).
+#define DF_TAP(T)                                                                        \
+  {                                                                                             \
     const int it_ = cs * 9 + (T);                                                               \
     const bf16_t* a = sA + (cs & 1) * HRP * BK;                                                 \
     const bf16_t* b = sW + (it_ % NSTW) * WROWS * BK;                                           \
@@ -983,18 +1018,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
       ha_[i] = hr * BK;                                                                         \
       sa_[i] = (((hbx[i] + dx_) >> 1) + hbq[i] + SC * dy_) & 7;                                 \
     }                                                                                           \
-    _Pragma("unroll") for (int s = 0; s < BK / 16; ++s) {                                       \
-      bf16x8 af[TM], bfr[TN];                                                                   \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
-        af[i] = *reinterpret_cast<const bf16x8*>(a + ha_[i] + (((2 * s + lh) ^ sa_[i]) << 3));  \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
-        bfr[j] = *reinterpret_cast<const bf16x8*>(b + fb[j] + (((2 * s + lh) ^ sb[j]) << 3));   \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                            \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                          \
-          acc[i][j] = DF_MFMA_32x32x16(af[i], bfr[j], acc[i][j]); \
-    }                                                                                           \
+    bf16x8 af0[TM], bf0[TN], af1[TM], bf1[TN], af2[TM], bf2[TN];                                \
+    DF_HALO_READ(af0, bf0, 0);                                                                  \
+    DF_HALO_READ(af1, bf1, 1);                                                                  \
+    DF_HALO_READ(af2, bf2, 2);                                                                  \
+    DF_HALO_MMA(af0, bf0);                                                                      \
+    DF_HALO_READ(af0, bf0, 3);                                                                  \
+    __builtin_amdgcn_sched_barrier(0);   /* the last reads are ISSUED here: two MFMA groups of cover before the wait */ \
+    DF_HALO_MMA(af1, bf1);                                                                      \
+    DF_HALO_MMA(af2, bf2);                                                                      \
+    __builtin_amdgcn_sched_barrier(0);   /* ... and those MFMA groups stay in front of it */           \
+    DF_HALO_SYNC(((T) + 1) % 9);                                                                \
+    DF_HALO_MMA(af0, bf0);                                                                      \
   }
 
+  DF_HALO_SYNC(0);
   for (int cs = 0; cs < nc; ++cs) {
     DF_TAP(0)
     DF_TAP(1)

@@ -85,6 +85,8 @@ _SIGS = {
     "df_profile_begin": [C.c_void_p],
     "df_profile_end": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "df_profile_dump": [C.c_void_p, C.c_char_p],
+    "df_tune_cache_export": [C.c_char_p, C.c_int64, C.POINTER(C.c_int64)],
+    "df_tune_cache_import": [C.c_char_p, C.c_int64],
     "df_debug_checksums": [C.c_void_p, C.c_int, C.c_int64],
     "df_debug_checksums_read": [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(C.c_int64)],
     "df_debug_checksum_label": [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64],
@@ -121,7 +123,7 @@ def lib(precision=None):
                                "(there is no CPU/torch fallback for the sampling path)")
         L = C.CDLL(path)
         for name, args in _SIGS.items():
-            if os.environ.get("DF_LIB_OVERRIDE") and name.startswith(("df_test_", "df_debug_")) and not hasattr(L, name):
+            if os.environ.get("DF_LIB_OVERRIDE") and name.startswith(("df_test_", "df_debug_", "df_tune_cache_")) and not hasattr(L, name):
                 continue                      # A/B against an older build that predates a unit-test / debug entry point
             fn = getattr(L, name)
             fn.argtypes = args
@@ -261,6 +263,17 @@ class Engine:
 
     def autotune(self, enable=True):
         _chk(self.L.df_autotune(self._h, int(enable)), self.L)
+
+    def tune_cache_export(self):
+        """The autotuner's choices of this process as bytes (text lines 'key tile splitk gm')."""
+        n = C.c_int64()
+        _chk(self.L.df_tune_cache_export(None, 0, C.byref(n)), self.L)
+        buf = C.create_string_buffer(max(n.value, 1))
+        _chk(self.L.df_tune_cache_export(buf, n.value, C.byref(n)), self.L)
+        return buf.raw[:n.value]
+
+    def tune_cache_import(self, text):
+        _chk(self.L.df_tune_cache_import(bytes(text), len(text)), self.L)
 
     # ---- packed-operand blob (multi-GPU weight distribution: pack once on the root rank, broadcast, import elsewhere)
     def export_packed(self, B, H, W, T):

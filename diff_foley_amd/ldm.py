@@ -215,8 +215,12 @@ class LatentDiffusion:
         # The cached tensor is held by a STRONG reference: its storage cannot be handed to another tensor while it is the
         # cache key (the caching allocator gives a freed block to the next tensor of the same size -- a data_ptr()-only key
         # would then skip set_context for a different conditioning).
-        key = (tuple(c.shape), c._version)
-        if self._ctx_owner is None or self._ctx_owner[0] is not c or self._ctx_owner[1] != key:
+        try:
+            ver = c._version
+        except RuntimeError:          # tensors made under torch.inference_mode() carry no version counter:
+            ver = None                # an in-place edit cannot be seen, so the projections are recomputed every call
+        key = (tuple(c.shape), ver)
+        if ver is None or self._ctx_owner is None or self._ctx_owner[0] is not c or self._ctx_owner[1] != key:
             eng.set_context(c)
             self._ctx_owner = (c, key)
         return eng.unet_forward(x_noisy, t)

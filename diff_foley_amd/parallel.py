@@ -2,7 +2,7 @@
 
 Every latent sample is independent for its whole trajectory, so the global batch is split
 contiguously over ranks and the step loop contains no collective.  The only exchange is at init: rank 0 packs the
-checkpoint ONCE into the engine's MFMA operand layouts and broadcasts that blob (``broadcast_packed_model``: 1.8 GB of
+checkpoint ONCE into the engine's MFMA operand layouts and broadcasts that blob (``broadcast_packed_model``: 2.09 GB of
 operand-type weights + the small fp32 tensors, RCCL over xGMI when the backend is "nccl"); the other ranks import it --
 no fp32 master copies and no re-packing there.  ``broadcast_state_dict`` (the flat fp32 checkpoint, 3.8 GB) remains for
 tensors that are not part of a LatentDiffusion (e.g. the classifier) and for the gloo CPU tests.
@@ -98,22 +98,43 @@ def broadcast_bytes(buf, src, device):
 def broadcast_packed_model(model, batch_size, src=0, size_len=64, context_frames=32):
     """``model``: a LatentDiffusion that is on its device on every rank and holds the checkpoint on ``src`` only.
     ``src`` packs for (batch_size, 16 x size_len latent, context_frames) and exports; everyone else imports.
-    Returns seconds spent in (pack + export, broadcast, import) on this rank."""
+
+    Travels in ONE extra byte payload next to the packed blob ("sidecar"): the schedule buffers of ``src`` (a checkpoint may
+    carry its own betas / alphas_cumprod: without them the importing ranks would sample with the config's schedule) and the
+    autotuner's choices of ``src`` (when its engine tuned the exported plans): every rank then runs the SAME tiles and
+    split-K factors -- identical fp32 summation order, bit-equal results across ranks -- and only ``src`` pays a tuning pass.
+    Returns seconds spent in (pack + export, broadcast, import) on this rank and the payload sizes."""
+    import io
     import time
+    from .schedule import BUFFER_NAMES
     rank = dist.get_rank() if dist.is_initialized() else 0
     dev = model.device
     t0 = time.perf_counter()
-    manifest = blob = None
+    manifest = blob = side = None
     if rank == src:
         manifest, blob = model.export_packed(batch_size, size_len, context_frames)
+        bio = io.BytesIO()
+        np.savez(bio, tune=np.frombuffer(model.engine.tune_cache_export(), dtype=np.uint8),
+                 **{k: getattr(model, k).detach().cpu().numpy() for k in BUFFER_NAMES})
+        side = torch.frombuffer(bytearray(bio.getvalue()), dtype=torch.uint8)
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     manifest = broadcast_bytes(manifest, src, dev)
+    side = broadcast_bytes(side, src, dev)
     blob = broadcast_bytes(blob, src, dev)
     torch.cuda.synchronize(dev)
     t2 = time.perf_counter()
+    ntune = 0
     if rank != src:
+        z = np.load(io.BytesIO(side.cpu().numpy().tobytes()))
+        tune = z["tune"].tobytes()
+        ntune = tune.count(b"\n")
+        if ntune:
+            model.engine.tune_cache_import(tune)
         model.load_packed(manifest, blob)
+        for k in BUFFER_NAMES:
+            setattr(model, k, torch.from_numpy(z[k]).to(getattr(model, k).device))
     torch.cuda.synchronize(dev)
     return dict(pack_export_s=t1 - t0, bcast_s=t2 - t1, import_s=time.perf_counter() - t2,
-                blob_bytes=int(blob.numel()), manifest_bytes=int(manifest.numel()))
+                blob_bytes=int(blob.numel()), manifest_bytes=int(manifest.numel()), sidecar_bytes=int(side.numel()),
+                tune_entries_imported=ntune, backend=dist.get_backend() if dist.is_initialized() else None)

@@ -195,6 +195,12 @@ int df_profile_begin(df_ctx* ctx);
 int df_profile_end(df_ctx* ctx, double* ms_by_family, int64_t* count_by_family);
 /* CSV (tag,M,N,K,taps,stride,ups,batch,tile,splitk,ms) of every op of the region last closed by df_profile_end. */
 int df_profile_dump(df_ctx* ctx, const char* path);
+/* The autotuner's choices as text ("key tile splitk gm" per line; process-wide).  Export: *n = bytes needed, at most cap are
+ * written to buf (buf may be NULL to query the size).  Import merges the lines into this process's cache: plans built with
+ * df_autotune(1) whose GEMMs are all present are configured from it without a trial launch.  parallel.broadcast_packed_model
+ * ships rank 0's text with the packed blob: every rank runs rank 0's tiles (identical fp32 summation order). */
+int df_tune_cache_export(char* buf, int64_t cap, int64_t* n);
+int df_tune_cache_import(const char* text, int64_t n);
 /* Debug: while enabled, every op of every plan is followed by a 64-bit (order-independent, integer) checksum over ALL
  * workspace bytes of its plan; the sequence of checksums of two runs on identical inputs must be identical, and the first
  * index that differs names the launch that was not reproducible (tools/chk_probe.py).  capacity = checksum slots. */
