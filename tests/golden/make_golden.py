@@ -358,6 +358,31 @@ def configs():
     save("g8_full_configs.npz", **out)
 
 
+def full_extra(seed=0):
+    """G5 extension (round 3): reference DDIM-25 trajectories for seeds 23 and 24, so that a full 25-step B=4 run of BASELINE
+    configs[1] can be compared ROW BY ROW with four B=1 reference runs (seeds 21..24; samples are independent, so row i of
+    the batch must reproduce the B=1 run of seed 21+i).  Written to its own file: g5_full_samplers.npz stays untouched."""
+    t0 = time.time()
+    spec = synth.state_dict_spec()
+    sd = synth.make_state_dict(spec, seed)
+    cfg = ref_import.load_ldm_config()
+    model, ns = ref_import.build_reference_ldm(cfg, sd)
+    check_spec(model, spec)
+    out = {}
+    with torch.no_grad():
+        for s in (23, 24):
+            xT = synth.synthetic_xT(1, seed=s)
+            feats = synth.synthetic_cavp(1, 32, 512, seed=1234 + s - 21)
+            c = model.get_learned_conditioning(feats)
+            uc = torch.zeros_like(c)
+            z, _ = model.sample_log_diff_sampler(c, 1, "DDIM", 25, unconditional_guidance_scale=4.5,
+                                                 unconditional_conditioning=uc, x_T=xT.clone())
+            out[f"ddim25_z_{s}"] = z
+            out[f"ddim25_mel_{s}"] = model.decode_first_stage(z)[:, 0]
+            print("ddim", s, time.time() - t0)
+    save("g5_full_samplers_extra.npz", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiny", action="store_true")
@@ -365,6 +390,7 @@ if __name__ == "__main__":
     ap.add_argument("--cavp", action="store_true", help="CAVP video encoder vectors (reference topology, mmcv stand-in)")
     ap.add_argument("--video", action="store_true", help="G9: frame pre-processing vectors (Pillow's own resize outputs)")
     ap.add_argument("--configs", action="store_true", help="G8: BASELINE configs[2] / configs[4] at full size (~8 min)")
+    ap.add_argument("--full-extra", action="store_true", help="G5 extension: DDIM-25 reference runs for seeds 23 / 24 (~4 min)")
     a = ap.parse_args()
     torch.set_num_threads(8)
     if a.tiny:
@@ -377,3 +403,5 @@ if __name__ == "__main__":
         video_frames()
     if a.configs:
         configs()
+    if a.full_extra:
+        full_extra()

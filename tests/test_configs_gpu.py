@@ -44,8 +44,10 @@ def test_config2_batch8_dpm50_double_guidance_vs_reference(P):
     mae = float((mel[:1] - ref).abs().mean())
     print(f"configs[2] B=8 DPM-Solver++-50 + classifier (bf16): z rel-L2 {err:.3e}, mel MAE {mae:.3e} "
           f"(mel range {float(ref.max() - ref.min()):.2f}, std {float(ref.std()):.3f})")
-    assert err < 5e-2                                           # 50 steps x (UNet + classifier gradient), bf16 operands
-    assert mae < 1.5e-2 * float(ref.std()) + 1e-3
+    # measured (round 3, MI355X): z rel-L2 4.95e-3, mel MAE 3.95e-3 -- bounds are 2x the measurement (bf16: 2^-9 per operand,
+    # 50 steps x (UNet + classifier gradient)); the fp16 variant below carries the north-star bound
+    assert err < 1e-2
+    assert mae < 8e-3
     # the 8 samples are independent trajectories: no two rows coincide, and row 0 does not depend on the batch size
     assert min(float((z[i] - z[j]).abs().max()) for i in range(B) for j in range(i)) > 1e-2
     z1, _ = m.sample_log_with_classifier_diff_sampler(
@@ -53,6 +55,53 @@ def test_config2_batch8_dpm50_double_guidance_vs_reference(P):
         unconditional_guidance_scale=4.5, unconditional_conditioning=torch.zeros_like(c[:1]), classifier=cls,
         classifier_guide_scale=50.0, x_T=xT[:1])
     assert rel_l2(z1.cpu(), z[:1].cpu()) < 2e-2                 # other plan (tiles / summation order), same sample
+
+
+def test_config2_batch8_dpm50_double_guidance_fp16_vs_reference(P):
+    """configs[2] with fp16 operands (the operand type that meets the north-star bound): row 0 of the B=8 run vs the reference."""
+    from diff_foley_amd import synth
+    g = gold("g8_full_configs.npz")
+    m = P.LatentDiffusion(precision="fp16", **P.stage2_config())
+    m.load_state_dict(full_state_dict())
+    m.cuda()
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_FULL)), precision="fp16")
+    cls.load_state_dict(full_classifier_sd())
+    B = 8
+    feats33 = synth.synthetic_cavp(B, 33, 512, seed=4321).cuda()
+    c = m.get_learned_conditioning(feats33[:, :32])
+    xT = synth.synthetic_xT(B, seed=21).cuda()
+    z, _ = m.sample_log_with_classifier_diff_sampler(
+        c, origin_cond=feats33, batch_size=B, sampler_name="DPM_Solver", ddim_steps=50, unconditional_guidance_scale=4.5,
+        unconditional_conditioning=torch.zeros_like(c), classifier=cls, classifier_guide_scale=50.0, x_T=xT)
+    mel = m.decode_first_stage(z)[:, 0].cpu()
+    err = rel_l2(z[:1].cpu(), g["c2_dpm50_cg_z0"])
+    mae = float((mel[:1] - g["c2_dpm50_cg_mel0"]).abs().mean())
+    print(f"configs[2] B=8 DPM-Solver++-50 + classifier (fp16): z rel-L2 {err:.3e}, mel MAE {mae:.3e}")
+    assert err < 2e-3
+    assert mae < 1e-3                                            # north-star bound, absolute mel units
+
+
+def test_config1_batch4_ddim25_rows_vs_four_b1_reference_runs(P):
+    """configs[1] end to end: ONE 25-step DDIM run at B=4 (fp16 operands, the bench headline), every row compared with the
+    reference's own B=1 run of that sample (seeds 21..24: g5_full_samplers.npz + g5_full_samplers_extra.npz)."""
+    from diff_foley_amd import synth
+    g = {**dict(gold("g5_full_samplers.npz")), **dict(gold("g5_full_samplers_extra.npz"))}
+    m = P.LatentDiffusion(precision="fp16", **P.stage2_config())
+    m.load_state_dict(full_state_dict())
+    m.cuda()
+    seeds = (21, 22, 23, 24)
+    xT = torch.cat([synth.synthetic_xT(1, seed=s) for s in seeds]).cuda()
+    feats = torch.cat([synth.synthetic_cavp(1, 32, 512, seed=1234 + s - 21) for s in seeds]).cuda()
+    c = m.get_learned_conditioning(feats)
+    z, _ = m.sample_log_diff_sampler(c, 4, "DDIM", 25, unconditional_guidance_scale=4.5,
+                                     unconditional_conditioning=torch.zeros_like(c), x_T=xT)
+    mel = m.decode_first_stage(z)[:, 0].cpu()
+    for i, s in enumerate(seeds):
+        zerr = rel_l2(z[i:i + 1].cpu(), g[f"ddim25_z_{s}"])
+        mae = float((mel[i:i + 1] - g[f"ddim25_mel_{s}"]).abs().mean())
+        print(f"configs[1] B=4 row {i} (seed {s}): z rel-L2 {zerr:.3e}, mel MAE {mae:.3e}")
+        assert zerr < 2e-3
+        assert mae < 1e-3                                        # north-star bound, absolute mel units
 
 
 def test_config4_chain_cavp32_ddim25_8_candidates_fp16_vs_reference(P):
@@ -81,5 +130,5 @@ def test_config4_chain_cavp32_ddim25_8_candidates_fp16_vs_reference(P):
         zerr = rel_l2(z[k:k + 1].cpu(), g[f"c4_ddim25_z{k}"])
         mae = float((mel[k:k + 1] - g[f"c4_ddim25_mel{k}"]).abs().mean())
         print(f"  candidate {k}: z rel-L2 {zerr:.3e}, mel MAE {mae:.3e}")
-        assert zerr < 1e-2
+        assert zerr < 2e-3                                        # measured 8.4e-4 / 8.2e-4
         assert mae < 1e-3                                         # north-star bound, absolute mel units, fp16 operands

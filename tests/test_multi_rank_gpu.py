@@ -34,7 +34,8 @@ def _sample(model, lo, hi, synth):
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), DF_DIST_SHARE_GPU0="1")
+                      LOCAL_RANK=str(rank), DF_DIST_SHARE_GPU0="1",
+                      DF_RAW_DATA_MAX="5120")      # tiny model: weight matrices travel shape-only, like the full model's
     import diff_foley_amd as P
     from diff_foley_amd import parallel, synth
     try:
@@ -73,11 +74,12 @@ def _worker(rank, world, port, q):
                    f"pack+export {info['pack_export_s'] * 1e3:.0f} ms, bcast {info['bcast_s'] * 1e3:.0f} ms; gathered mels == "
                    f"sequential shards on one rank: {same} (max|d| own shard rerun {d0:.1e}, other rank's shard {d1:.1e}); vs the global batch in one plan rel-L2 {err:.2e}")
         else:
-            # the importing rank never saw an fp32 checkpoint: a latent whose plan needs a packing that was not exported
-            # (16x16: maps below 64 tokens take the K / V^T cross-attention form) must fail LOUDLY, naming the missing tensor
+            # the importing rank never saw an fp32 checkpoint: a plan that needs a packing which was not exported (a 40-frame
+            # context takes the K / V^T cross-attention form: separate to_k / to_v / LayerNorm-folded to_q operands) must fail
+            # LOUDLY, naming the situation -- not sample from uninitialised operands
             try:
-                m.engine.set_context(torch.zeros(2, 32, 128).cuda())
-                m.engine.unet_forward(torch.zeros(2, 4, 16, 16).cuda(), torch.zeros(2).cuda())
+                m.engine.set_context(torch.zeros(2, 40, 128).cuda())
+                m.engine.unet_forward(torch.zeros(2, 4, 16, 64).cuda(), torch.zeros(2).cuda())
                 ok, msg = False, "an un-exported packing was built on the importing rank without an fp32 checkpoint"
             except RuntimeError as ex:
                 ok = "imported shape-only" in str(ex)
