@@ -1,5 +1,4 @@
 // Normalisation, small linears, packing and sampler-update kernels (gfx950).  All HBM/L2-bound.
-#include <algorithm>
 #include "common.h"
 #include "kernels.h"
 
@@ -665,53 +664,6 @@ hipError_t launch_groupnorm_slabs(const float* x, int ld, int N, int HW, int C, 
     hipLaunchKernelGGL(groupnorm_kernel, dim3(32, N), dim3(1024), 0, s, x, ld, HW, C, cpg, gamma, beta, eps, silu, out,
                        ldo, raw_out);
 #undef DF_GN_REG
-  return hipGetLastError();
-}
-
-// GroupNorm(32) [+ SiLU] with the statistics already accumulated by the producer(s) of x (GemmParams::gn: fixed-point sum /
-// sum of squares per (sample, group)): one fully coalesced pass, 4 channels per thread (they span at most two groups).
-__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, int ld, long rows, int HW, int C, int cpg,
-                                                              const unsigned long long* __restrict__ acc,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float eps, int silu, bf16_t* __restrict__ out, int ldo,
-                                                              bf16_t* __restrict__ raw) {
-  const int n4 = C >> 2;
-  const long total = rows * n4;
-  const double inv_cnt = 1.0 / ((double)HW * (double)cpg);
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const long row = e / n4;
-    const int c = (int)(e - row * n4) * 4;
-    const int smp = (int)(row / HW);
-    const float4 v = *reinterpret_cast<const float4*>(x + row * ld + c);
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
-    const int g0 = c / cpg, g1 = (c + 3) / cpg;
-    float m[2], r[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const unsigned long long* a = acc + ((long)smp * 32 + (k ? g1 : g0)) * 2;
-      const double s1 = (double)(long long)a[0] * (1.0 / 16777216.0), s2 = (double)(long long)a[1] * (1.0 / 65536.0);
-      const double mean = s1 * inv_cnt, var = fmax(s2 * inv_cnt - mean * mean, 0.0);
-      m[k] = (float)mean;
-      r[k] = rsqrtf((float)var + eps);
-    }
-    const int b1 = (c + 1) / cpg != g0, b2 = (c + 2) / cpg != g0, b3 = g1 != g0;
-    float y0 = (v.x - m[0]) * r[0] * ga.x + be.x;
-    float y1 = (v.y - m[b1]) * r[b1] * ga.y + be.y;
-    float y2 = (v.z - m[b2]) * r[b2] * ga.z + be.z;
-    float y3 = (v.w - m[b3]) * r[b3] * ga.w + be.w;
-    if (silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
-    *reinterpret_cast<uint2*>(out + row * ldo + c) = make_uint2(pack_bf2(y0, y1), pack_bf2(y2, y3));
-    if (raw) *reinterpret_cast<uint2*>(raw + row * ldo + c) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-  }
-}
-
-hipError_t launch_groupnorm_apply(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,
-                                  int silu, uint16_t* out, int ldo, uint16_t* raw_out, const unsigned long long* acc, hipStream_t s) {
-  if (C % 64 != 0 || (ld & 3) != 0 || (ldo & 3) != 0) return hipErrorInvalidValue;
-  const long rows = (long)N * HW, total = rows * (C >> 2);
-  int blocks = (int)std::min<long>((total + 255) / 256, 8192);
-  hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(blocks), dim3(256), 0, s, x, ld, rows, HW, C, C / 32, acc, gamma, beta, eps, silu,
-                     out, ldo, raw_out);
   return hipGetLastError();
 }
 

@@ -461,64 +461,6 @@ struct Builder {
     return (T*)pl->alloc(n * sizeof(T));
   }
 
-  // ---- GroupNorm statistics from the producers (GemmParams::gn).  Every GEMM that writes an fp32 row-major tensor is
-  // remembered by its output pointer; a GroupNorm over x looks its producer(s) up (two for a decoder concat buffer: the
-  // up-path block and the encoder block that wrote the skip columns), gives them an accumulator slot and becomes ONE
-  // coalesced elementwise pass (groupnorm_apply_kernel) instead of the (group, sample) reduction kernel.  Whether a producer
-  // can deliver (tile inside one sample / non-deferred split-K) is decided at run time from the tuned tile: otherwise the
-  // standalone kernel runs.  UNet denoiser plans only (gn_fuse).
-  bool gn_fuse = false;
-  unsigned long long* gnacc = nullptr;
-  int gn_slots = 0, gn_cap = 0, gn_nb = 0;
-  struct Prod { float* ptr; int cols, ld, rows; size_t op; };
-  std::vector<Prod> prods;
-  void gn_enable(int NB) {
-    static const bool off = getenv("DF_NO_GNSTATS") && atoi(getenv("DF_NO_GNSTATS"));
-    if (off) return;
-    gn_fuse = true;
-    gn_nb = NB;
-    gn_cap = 160;
-    const size_t bytes = (size_t)gn_cap * NB * 64 * sizeof(unsigned long long);
-    gnacc = (unsigned long long*)pl->alloc(bytes);
-    unsigned long long* a = gnacc;
-    other("gn.zero", [=](hipStream_t s, const RunArgs&) { return hipMemsetAsync(a, 0, bytes, s); });
-  }
-  struct GnUse { unsigned long long* acc = nullptr; std::vector<size_t> prod_ops; };
-  GnUse gn_attach(const F32& x, int NB) {
-    GnUse u;
-    if (!gn_fuse || NB != gn_nb || gn_slots >= gn_cap || x.C % 64 != 0 || x.rows % NB != 0) return u;
-    std::vector<const Prod*> found;
-    int covered = 0;
-    for (auto& pr : prods)
-      if (pr.ld == x.ld && pr.rows == x.rows && pr.ptr >= x.p && pr.ptr + pr.cols <= x.p + x.C) {
-        found.push_back(&pr);
-        covered += pr.cols;
-      }
-    if (found.empty() || covered != x.C) return u;                        // not (only) GEMM outputs: standalone kernel
-    for (auto* pr : found)
-      if (pl->ops[pr->op].gp.gn_n >= 2) return u;
-    u.acc = gnacc + (size_t)(gn_slots++) * NB * 64;
-    for (auto* pr : found) {
-      GemmParams& g = pl->ops[pr->op].gp;
-      g.gn[g.gn_n].acc = u.acc;
-      g.gn[g.gn_n].cpg = x.C / 32;
-      g.gn[g.gn_n].col_off = (int)(pr->ptr - x.p);
-      ++g.gn_n;
-      g.gn_hw = x.rows / NB;
-      u.prod_ops.push_back(pr->op);
-    }
-    return u;
-  }
-  // run time: did every producer of this GroupNorm's input deliver its statistics with the tile it was tuned to?
-  static bool gn_delivered(const Plan* plp, const GnUse& u) {
-    if (!u.acc) return false;
-    for (size_t i : u.prod_ops) {
-      const Op& o = plp->ops[i];
-      if (!gemm_gn_stats_ok(o.gp, o.tile, o.batch, o.gp.splitk, o.defer && o.gp.splitk > 1)) return false;
-    }
-    return true;
-  }
-
   void other(const char* tag, std::function<hipError_t(hipStream_t, const RunArgs&)> fn) {
     Op o;
     o.fn = std::move(fn);
@@ -554,12 +496,6 @@ struct Builder {
     pl->gemm_flops += 2.0 * gp.M * (double)gp.N * gp.K * batch;
     pl->weight_bytes += 2.0 * (double)gp.N * gp.K * (gp.w_bs ? batch : 1);
     pl->ops.push_back(std::move(o));
-    if (gn_fuse && gp.C) {       // latest writer of this output pointer (buffers are recycled inside a plan)
-      for (size_t k = 0; k < prods.size();)
-        if (prods[k].ptr == (float*)gp.C) prods.erase(prods.begin() + k); else ++k;
-      if (batch == 1 && !gp.out_bf16 && !gp.store_nchw && !gp.geglu && !gp.vt)
-        prods.push_back({(float*)gp.C, gp.N, gp.ldc, gp.M, pl->ops.size() - 1});
-    }
     return pl->ops.back();
   }
 
@@ -608,10 +544,7 @@ struct Builder {
       pl->release(scr);
       return o;
     }
-    const GnUse gu = gn_attach(x, NB);
-    Plan* plp = pl;
     other("groupnorm", [=](hipStream_t s, const RunArgs&) {
-      if (gn_delivered(plp, gu)) return launch_groupnorm_apply(xp, ld, NB, HW, C, g, b, eps, silu, o, C, r, gu.acc, s);
       return launch_groupnorm(xp, ld, NB, HW, C, g, b, eps, silu, o, C, r, s);
     });
     return o;
@@ -669,13 +602,11 @@ struct Builder {
       const int HW = H * Wd;
       const size_t sb = groupnorm_scratch_bytes(NB, HW, cout);
       float* scr = sb ? (float*)pl->alloc(sb) : nullptr;
-      const GnUse gu = sb ? GnUse{} : gn_attach(F32{h1, M, cout, cout}, NB);
       other("groupnorm", [=](hipStream_t s, const RunArgs&) {
         const Op& co = plp->ops[ci];
         if (co.defer && co.gp.splitk > 1)
           return launch_groupnorm_slabs(co.gp.partial, cout, NB, HW, cout, gm, bt, eps, 1, a2, cout, nullptr, co.gp.splitk,
                                         (long)M * cout, cb, rb, emb_ld, s);
-        if (gn_delivered(plp, gu)) return launch_groupnorm_apply(h1, cout, NB, HW, cout, gm, bt, eps, 1, a2, cout, nullptr, gu.acc, s);
         if (scr) return launch_groupnorm_chunked(h1, cout, NB, HW, cout, gm, bt, eps, 1, a2, cout, nullptr, scr, s);
         return launch_groupnorm(h1, cout, NB, HW, cout, gm, bt, eps, 1, a2, cout, nullptr, s);
       });
@@ -1232,7 +1163,6 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
   }
   const size_t ctx_ops_end = pl->ops.size();
   pl->n_ctx = ctx_ops_end;
-  if (which == 0) b.gn_enable(N);      // GroupNorm statistics from the producing GEMMs (first op of every forward zeroes them)
   if (!ctx_inline) {
     // move the context ops into a separate plan entry "…#ctx" is handled by the caller: it splits [begin,end)
   }
@@ -2195,7 +2125,6 @@ void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const
       GemmParams g = o.gp;
       if (o.c_ext) g.C = a.out;
       if (o.defer && g.splitk > 1) g.defer_reduce = 1;
-      if (g.gn_n > 0 && !gemm_gn_stats_ok(g, o.tile, o.batch, g.splitk, g.defer_reduce != 0)) g.gn_n = 0;   // consumer falls back
       e = launch_gemm(g, o.tile, o.batch, s);
     } else {
       e = o.fn(s, a);
@@ -2228,7 +2157,7 @@ static std::string tune_key(const Op& o) {
   const GemmParams& g = o.gp;
   char key[160];
   const int epi = (g.silu ? 128 : 0) | (g.ln_stats ? 1 : 0) | (g.stats ? 2 : 0) | (g.vt ? 4 : 0) | (g.aux ? 8 : 0) | (g.res ? 16 : 0) | (g.Cin2 ? 32 : 0) |
-                  (o.defer ? 64 : 0) | (g.gn_n ? 256 : 0);
+                  (o.defer ? 64 : 0);
   snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d_%d_e%d", g.M, g.N, g.K, g.taps, g.stride, g.ups, o.batch, g.geglu, epi);
   return key;
 }
@@ -2308,10 +2237,7 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
         if (!gemm_tile_valid(g, t, o.batch, sk)) { if (sk > 1) break; else continue; }
         const size_t need = (size_t)sk * g.M * g.N * 4;
         if (sk > 1 && need > pl->partial_bytes) break;
-        // a producer of GroupNorm statistics is only tuned over the forms that deliver them (or leave the slabs to the norm)
-        if (g.gn_n > 0 && !(gemm_gn_stats_ok(g, t, o.batch, sk, false) || (o.defer && sk > 1)) && g.gn_hw >= 64) continue;
         GemmParams q = g;
-        if (q.gn_n > 0 && !gemm_gn_stats_ok(q, t, o.batch, sk, o.defer && sk > 1)) q.gn_n = 0;
         q.splitk = sk;
         q.partial = pl->partial;
         // res may alias C: results are garbage during tuning but are recomputed by the next real run
@@ -3114,40 +3040,6 @@ int df_test_gemm_epi(const uint16_t* A, const uint16_t* W, const float* bias, co
 }
 
 // C = [A | A2] W^T with the K columns split over two operand tensors (the merged FF2 + proj_out GEMM of the SpatialTransformer).
-// GroupNorm with producer statistics, end to end: y[:, 0:N1] = A1 W1^T + b (+ res), optionally y[:, N1:N1+N2] = A2 W2^T (a decoder
-// concat buffer with two producers), each GEMM run as (tile, split-K) with the GemmParams::gn accumulators of ONE GroupNorm
-// over all N1 + N2 columns; then groupnorm_apply_kernel.  conv != 0: GEMM 1 is a 3x3 conv over [NB][H][Wd][K1 / 9] (halo tiles).
-// acc_dev: [NB][32][2] uint64 scratch (zeroed here).  Returns an error when a (tile, split-K) cannot deliver the statistics.
-int df_test_gn_chain(const uint16_t* A1, const uint16_t* W1, const float* b1, const float* res, int N1, int K1, int tile1, int sk1,
-                     const uint16_t* A2, const uint16_t* W2, int N2, int K2, int tile2, int sk2, int NB, int H, int Wd, int conv,
-                     const float* gamma, const float* beta, float eps, int silu, float* y, uint16_t* out,
-                     unsigned long long* acc_dev, void* stream) {
-  return guard([&] {
-    hipStream_t s = (hipStream_t)stream;
-    const int HW = H * Wd, M = NB * HW, C = N1 + N2;
-    HIPCHK(hipMemsetAsync(acc_dev, 0, (size_t)NB * 64 * sizeof(unsigned long long), s));
-    for (int which = 0; which < (N2 > 0 ? 2 : 1); ++which) {
-      const int N = which ? N2 : N1, K = which ? K2 : K1, tile = which ? tile2 : tile1, sk = which ? sk2 : sk1;
-      GemmParams g = (conv && !which) ? Builder::gp_conv3(A1, NB, H, Wd, K / 9, W1, N, 1, 0)
-                                      : Builder::gp_linear(which ? A2 : A1, M, K, which ? W2 : W1, N);
-      Builder::out_f32(g, y + (which ? N1 : 0), C);
-      if (!which) {
-        g.bias = b1;
-        if (res) { g.res = res; g.ldr = N1; }
-      }
-      g.gn_n = 1;
-      g.gn[0].acc = acc_dev; g.gn[0].cpg = C / 32; g.gn[0].col_off = which ? N1 : 0;
-      g.gn_hw = HW;
-      g.splitk = sk;
-      if (sk > 1) g.partial = test_partial((size_t)sk * M * N * 4);
-      if (!gemm_tile_valid(g, tile, 1, sk)) fail("tile %d / split-K %d refused this problem", tile, sk);
-      if (!gemm_gn_stats_ok(g, tile, 1, sk, false)) fail("tile %d / split-K %d cannot deliver GroupNorm statistics here", tile, sk);
-      HIPCHK(launch_gemm(g, tile, 1, s));
-    }
-    HIPCHK(launch_groupnorm_apply(y, C, NB, HW, C, gamma, beta, eps, silu, out, C, nullptr, acc_dev, s));
-  });
-}
-
 int df_test_gemm_dual(const uint16_t* A, const uint16_t* A2, const uint16_t* W, float* C, int M, int N, int K1, int K2, int tile,
                       int splitk, void* stream) {
   return guard([&] {

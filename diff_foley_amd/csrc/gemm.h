@@ -57,14 +57,6 @@ struct GemmParams {
   // columns >= vt_col0 are stored TRANSPOSED per sample into vt[(row/vt_T)*(N-vt_col0) + col-vt_col0][ldvt] at
   // position row%vt_T (attention V^T straight out of the fused QKV projection); vt_col0 % BN == 0 for every tile used
   uint16_t* vt; int vt_col0; int vt_T; int ldvt;
-  // GroupNorm statistics of the STORED fp32 value, for the GroupNorm(s) that read this tensor next (up to two: the plain
-  // tensor and the decoder's concat buffer it is a column range of): per (sample, group) fixed-point accumulators
-  // acc[(sample * 32 + group) * 2 + {0: sum * 2^24, 1: sum of squares * 2^16}], added with 64-bit INTEGER atomics
-  // (associative: the totals do not depend on the order the blocks arrive in; zeroed once per forward by the plan).
-  // group = (column + col_off) / cpg.  In-epilogue form: all rows of a tile belong to one sample (gn_hw % BM == 0, checked on
-  // the host); split-K form: the reduce kernel accumulates.  The consumer is groupnorm_apply_kernel (elementwise.hip).
-  struct GnAcc { unsigned long long* acc; int cpg; int col_off; };
-  GnAcc gn[2]; int gn_n; int gn_hw;
   int store_nchw; int hw_out;        // write C as [batch][N][hw_out] instead of [rows][ldc]
   int gm;      // tile walk: each XCD's contiguous tile range runs M-fastest inside row groups of `gm` M-tiles (0 = all rows:
                // plain M-fastest; 1 = N-fastest).  Decides which operand panels an XCD's L2 can share; autotuned in situ.
@@ -99,14 +91,6 @@ static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
   *bm = d[cfg][0];
   *bn = d[cfg][1];
 }
-
-// Fixed-point scales of the GroupNorm accumulators (GemmParams::gn).
-#define DF_GN_S1_SCALE 16777216.0   /* 2^24 */
-#define DF_GN_S2_SCALE 65536.0      /* 2^16 */
-
-// Can this GEMM, run as (tile, splitk), deliver the GroupNorm statistics GemmParams::gn asks for?  (No: the consumer falls
-// back to the standalone GroupNorm kernel and the producer runs without them.)
-bool gemm_gn_stats_ok(const GemmParams& p, int tile, int batch, int splitk, bool deferred_reduce);
 
 // Can (tile, batch, splitk) run this problem?  (halo tiles: 3x3 stride-1 convs whose patch geometry fits LDS)
 bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk);

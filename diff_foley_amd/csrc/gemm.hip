@@ -115,85 +115,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
   }
 }
 
-// Split-K reduce of a GroupNorm input: same epilogue as splitk_reduce_vec_kernel plus the per-(sample, group) statistics of the
-// stored value.  One block = R consecutive rows (of ONE sample) x all N columns; thread (column chunk, row lane) keeps its 4
-// columns over its rows, the row lanes are summed through LDS, groups are complete inside the block -> integer atomics.
-template <int SK>
-__global__ __launch_bounds__(1024) void splitk_reduce_gn_kernel(GemmParams p, int R, int RL) {
-  extern __shared__ float2 sgn[];                    // [RL][N]
-  const int n4 = p.N >> 2;
-  const int cl = threadIdx.x % n4, rl = threadIdx.x / n4;
-  const long slab = (long)p.M * p.N;
-  const bool has_bias = p.bias != nullptr, has_rb = p.rowbias != nullptr, has_res = p.res != nullptr;
-  const int r0 = blockIdx.x * R, col = cl * 4;
-  float4 gs1 = make_float4(0.f, 0.f, 0.f, 0.f), gs2 = gs1;
-  if (rl < RL) {
-    float4 bia = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (has_bias) bia = *reinterpret_cast<const float4*>(&p.bias[col]);
-    for (int r = r0 + rl; r < r0 + R && r < p.M; r += RL) {
-      const float* src = p.partial + (long)r * p.N + col;
-      float4 t[SK];
-#pragma unroll
-      for (int s = 0; s < SK; ++s) t[s] = *reinterpret_cast<const float4*>(src + s * slab);
-      float4 v = t[0];
-#pragma unroll
-      for (int s = 1; s < SK; ++s) { v.x += t[s].x; v.y += t[s].y; v.z += t[s].z; v.w += t[s].w; }
-      v.x = v.x * p.alpha + bia.x; v.y = v.y * p.alpha + bia.y; v.z = v.z * p.alpha + bia.z; v.w = v.w * p.alpha + bia.w;
-      if (has_rb) {
-        const int ri = (p.rowbias_mode == 1) ? (r / p.rows_per_sample) : (r % p.rows_per_sample);
-        const float4 b = *reinterpret_cast<const float4*>(&p.rowbias[(long)ri * p.ld_rowbias + col]);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-      }
-      if (has_res) {
-        const float4 b = *reinterpret_cast<const float4*>(&p.res[(long)r * p.ldr + col]);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-      }
-      if (p.silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-      if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      gs1.x += v.x; gs1.y += v.y; gs1.z += v.z; gs1.w += v.w;
-      gs2.x += v.x * v.x; gs2.y += v.y * v.y; gs2.z += v.z * v.z; gs2.w += v.w * v.w;
-      const long idx = (long)r * p.ldc + col;
-      if (p.out_bf16)
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-      else
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;
-      if (p.aux) *reinterpret_cast<uint2*>(p.aux + (long)r * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-    }
-    sgn[rl * p.N + col + 0] = make_float2(gs1.x, gs2.x);
-    sgn[rl * p.N + col + 1] = make_float2(gs1.y, gs2.y);
-    sgn[rl * p.N + col + 2] = make_float2(gs1.z, gs2.z);
-    sgn[rl * p.N + col + 3] = make_float2(gs1.w, gs2.w);
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < p.N; c += blockDim.x) {      // row lanes in fixed order
-    float2 tot = sgn[c];
-    for (int k = 1; k < RL; ++k) { tot.x += sgn[k * p.N + c].x; tot.y += sgn[k * p.N + c].y; }
-    sgn[c] = tot;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < p.N; c += blockDim.x) gn_flush_groups(p, sgn, p.N, 0, r0 / p.gn_hw, c);
-}
-
 }  // namespace
-
-static bool reduce_vec_ok(const GemmParams& p) {
-  return !p.geglu && !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.ld_rowbias & 3) == 0 &&
-         (p.ld_aux & 3) == 0;
-}
-
-bool gemm_gn_stats_ok(const GemmParams& p, int tile, int batch, int splitk, bool deferred_reduce) {
-  if (p.gn_n <= 0 || p.gn_n > 2 || p.gn_hw <= 0 || batch > 1 || p.M % p.gn_hw != 0) return false;
-  if (p.ln_stats || p.stats || p.vt || p.geglu || p.sm_w > 0 || p.store_nchw || p.out_bf16) return false;
-  if (splitk > 1) {     // the reduce kernel accumulates: R rows of one sample per block, (N / 4) x RL <= 1024 threads
-    return !deferred_reduce && reduce_vec_ok(p) && (p.N >> 2) <= 1024 &&
-           (splitk == 2 || splitk == 4 || splitk == 8 || splitk == 16 || splitk == 32);
-  }
-  const bool vec = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.ld_rowbias & 3) == 0 && (p.res_bs & 3) == 0 &&
-                   (p.c_bs & 3) == 0 && (p.ld_aux & 3) == 0;
-  int bm, bn;
-  gemm_tile_dims(tile, &bm, &bn);
-  return vec && p.gn_hw % bm == 0;      // all rows of a tile in one sample
-}
 
 bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int nk = p.K / 64;
@@ -256,8 +178,7 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
   else if (p.ln_stats || p.vt) epi = EPI_LNC;
   else if (p.stats) epi = EPI_PROD;
   else if (!vec || p.relu || p.aux || p.alpha != 1.f) epi = EPI_ANY;
-  else epi = p.gn_n > 0 ? EPI_GNS : EPI_LEAN;
-  if (p.gn_n > 0 && !gemm_gn_stats_ok(p, tile_cfg, batch, p.splitk, p.defer_reduce != 0)) return hipErrorInvalidValue;
+  else epi = EPI_LEAN;
   if ((epi == EPI_GEGLU || epi == EPI_LNC || epi == EPI_PROD) && (p.taps != 1 || p.alpha != 1.f || p.relu || p.silu || !vec))
     return hipErrorInvalidValue;
   if (epi == EPI_LNC && (!p.ln_stats || p.aux)) return hipErrorInvalidValue;
@@ -273,21 +194,7 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
   if (p.splitk > 1 && !p.defer_reduce) {
     const bool vec = !p.geglu && !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
                      (p.ld_rowbias & 3) == 0 && (p.ld_aux & 3) == 0;
-    if (vec && p.gn_n > 0) {
-      // GroupNorm input: reduce + statistics.  R rows per block (a power of two dividing the rows of a sample), at least
-      // ~128 blocks; RL row lanes so that a block has (N / 4) * RL <= 1024 threads.
-      const int n4 = p.N >> 2;
-      int R = 16;
-      while (R > 1 && (p.gn_hw % R != 0 || p.M / R < 128)) R >>= 1;
-      int RL = std::min(R, 1024 / n4);
-      const size_t lds = (size_t)RL * p.N * sizeof(float2);
-#define DF_REDG(SK) case SK: hipLaunchKernelGGL(splitk_reduce_gn_kernel<SK>, dim3((p.M + R - 1) / R), dim3(n4 * RL), lds, stream, p, R, RL); break;
-      switch (p.splitk) {
-        DF_REDG(2) DF_REDG(4) DF_REDG(8) DF_REDG(16) DF_REDG(32)
-        default: return hipErrorInvalidValue;
-      }
-#undef DF_REDG
-    } else if (vec) {
+    if (vec) {
       const long total = (long)p.M * (p.N >> 2);
       int blocks = (int)((total + 255) / 256);
       if (blocks > 4096) blocks = 4096;

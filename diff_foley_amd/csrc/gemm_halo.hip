@@ -6,7 +6,6 @@ hipError_t launch_gemm_halo(int tile_cfg, int epi, const GemmParams& p, int zdim
   case T:                                                                            \
     switch (epi) {                                                                   \
       case EPI_LEAN: return launch_halo<BM, BN, WGM, WGN, NSTW, EPI_LEAN>(p, zdim, stream);     \
-      case EPI_GNS: return launch_halo<BM, BN, WGM, WGN, NSTW, EPI_GNS>(p, zdim, stream);       \
       case EPI_SPLITK: return launch_halo<BM, BN, WGM, WGN, NSTW, EPI_SPLITK>(p, zdim, stream); \
       case EPI_ANY: return launch_halo<BM, BN, WGM, WGN, NSTW, EPI_ANY>(p, zdim, stream);       \
       default: return hipErrorInvalidValue;                                          \

@@ -29,27 +29,7 @@ constexpr int BK = 64;
 //   PROD   LEAN + per-row partial statistics + operand-type copy (producers of a LayerNorm-folded consumer)
 //   LNC    LayerNorm-folded consumer, optionally with the transposed V^T column range (fused QKV)
 //   ANY    everything else: alpha, ReLU, aux copy, NCHW store, unaligned shapes (scalar fallback)
-//   GNS    LEAN + per-(sample, group) GroupNorm statistics of the stored value (producers of a GroupNorm input)
-enum { EPI_LEAN = 0, EPI_SPLITK = 1, EPI_GEGLU = 2, EPI_PROD = 3, EPI_LNC = 4, EPI_ANY = 5, EPI_XS = 6, EPI_GNS = 7 };
-
-// Column totals [cols][(sum, sumsq)] in LDS -> fixed-point integer atomics on the (sample, group) accumulators of every
-// GroupNorm that reads this tensor.  The first column of each group inside the tile sums the group's columns (<= cpg values).
-__device__ __forceinline__ void gn_flush_groups(const GemmParams& p, const float2* sCol, int ncols, int col0, int sample, int t) {
-  if (t >= ncols || col0 + t >= p.N) return;
-#pragma unroll 1
-  for (int k = 0; k < p.gn_n; ++k) {
-    const int cpg = p.gn[k].cpg, cg = col0 + t + p.gn[k].col_off, g = cg / cpg;
-    if (t != 0 && (cg - 1) / cpg == g) continue;                 // not the first column of its group in this tile
-    float s1 = 0.f, s2 = 0.f;
-    for (int j = t; j < ncols && col0 + j < p.N && (col0 + j + p.gn[k].col_off) / cpg == g; ++j) {
-      s1 += sCol[j].x;
-      s2 += sCol[j].y;
-    }
-    unsigned long long* a = p.gn[k].acc + ((long)sample * 32 + g) * 2;
-    atomicAdd(a, (unsigned long long)__double2ll_rn((double)s1 * DF_GN_S1_SCALE));
-    atomicAdd(a + 1, (unsigned long long)__double2ll_rn((double)s2 * DF_GN_S2_SCALE));
-  }
-}
+enum { EPI_LEAN = 0, EPI_SPLITK = 1, EPI_GEGLU = 2, EPI_PROD = 3, EPI_LNC = 4, EPI_ANY = 5, EPI_XS = 6 };
 
 // Spatial patch (th x tw output pixels) owned by one block of a halo kernel with BM rows.
 bool halo_patch(int H, int W, int BM, int* th, int* tw) {
@@ -416,10 +396,6 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);                   \
     }                                                                                                               \
     const bool ok = row < p.M && col < p.N;                                                                         \
-    if (((FL) & 8) && ok) {                                                                                         \
-      gs1.x += v.x; gs1.y += v.y; gs1.z += v.z; gs1.w += v.w;                                                       \
-      gs2.x += v.x * v.x; gs2.y += v.y * v.y; gs2.z += v.z * v.z; gs2.w += v.w * v.w;                               \
-    }                                                                                                               \
     if ((FL) & 4) {                                                                                                 \
       const float s1 = row16_sum(ok ? (v.x + v.y) + (v.z + v.w) : 0.f);                                             \
       const float s2 = row16_sum(ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f);                     \
@@ -435,45 +411,13 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
         *reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
     }                                                                                                               \
   }
-  float4 gs1 = make_float4(0.f, 0.f, 0.f, 0.f), gs2 = gs1;     // GroupNorm statistics: this thread's 4 columns over its rows
   if constexpr (EPI == EPI_PROD) DF_EPI_LOOP(5)
   else if constexpr (EPI == EPI_LNC) DF_EPI_LOOP(2)
-  else if constexpr (EPI == EPI_GNS) DF_EPI_LOOP(8)
   else if constexpr (EPI == EPI_ANY) {
-    if (p.gn_n > 0) {
-      if (p.relu || p.aux) DF_EPI_LOOP(25)
-      else DF_EPI_LOOP(24)
-    } else if (p.relu || p.aux) DF_EPI_LOOP(17)
+    if (p.relu || p.aux) DF_EPI_LOOP(17)
     else DF_EPI_LOOP(16)
   } else DF_EPI_LOOP(0)
 #undef DF_EPI_LOOP
-  if constexpr (EPI == EPI_GNS || EPI == EPI_ANY) {
-    if (EPI == EPI_GNS || p.gn_n > 0) {
-      // thread (column chunk c4, thread-row tr) -> column totals of the tile -> group totals -> integer atomics
-      constexpr int RS = NT / CPR;
-      static_assert(BN <= NT && RS * BN * 8 <= BM * LDC * 4, "statistics scratch fits the epilogue tile");
-      __syncthreads();                                 // every thread is done reading the parked tile
-      float2* sPart = reinterpret_cast<float2*>(sC);   // [RS][BN]
-      const int c4s = (tid % CPR) * 4, tr = tid / CPR;
-      sPart[tr * BN + c4s + 0] = make_float2(gs1.x, gs2.x);
-      sPart[tr * BN + c4s + 1] = make_float2(gs1.y, gs2.y);
-      sPart[tr * BN + c4s + 2] = make_float2(gs1.z, gs2.z);
-      sPart[tr * BN + c4s + 3] = make_float2(gs1.w, gs2.w);
-      __syncthreads();
-      float2 tot = make_float2(0.f, 0.f);
-      if (tid < BN) {
-#pragma unroll 4
-        for (int k = 0; k < RS; ++k) {
-          tot.x += sPart[k * BN + tid].x;
-          tot.y += sPart[k * BN + tid].y;
-        }
-      }
-      __syncthreads();
-      if (tid < BN) sPart[tid] = tot;
-      __syncthreads();
-      gn_flush_groups(p, sPart, BN, n0, rowmap(0) / p.gn_hw, tid);
-    }
-  }
   }
 }
 

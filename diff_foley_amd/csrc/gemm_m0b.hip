@@ -6,7 +6,6 @@ hipError_t launch_gemm_m0b(int tile_cfg, int epi, const GemmParams& p, int zdim,
   case T:                                                                \
     switch (epi) {                                                       \
       case EPI_LEAN: return launch_cfg<BM, BN, WGM, WGN, NST, 0, EPI_LEAN>(p, zdim, stream); \
-      case EPI_GNS: return launch_cfg<BM, BN, WGM, WGN, NST, 0, EPI_GNS>(p, zdim, stream); \
       case EPI_SPLITK: return launch_cfg<BM, BN, WGM, WGN, NST, 0, EPI_SPLITK>(p, zdim, stream); \
       case EPI_GEGLU: return launch_cfg<BM, BN, WGM, WGN, NST, 0, EPI_GEGLU>(p, zdim, stream); \
       case EPI_PROD: return launch_cfg<BM, BN, WGM, WGN, NST, 0, EPI_PROD>(p, zdim, stream); \

@@ -15,11 +15,6 @@ hipError_t launch_groupnorm_slabs(const float* x, int ld, int N, int HW, int C, 
                                   long slab_stride, const float* bias, const float* rowbias, int ld_rowbias, hipStream_t s);
 bool groupnorm_accepts_slabs(int HW, int C);
 
-// GroupNorm with statistics that the producer GEMM(s) of x already accumulated (GemmParams::gn; acc = [N][32][2] fixed-point
-// sum / sum of squares): one coalesced elementwise pass instead of the (group, sample) reduction kernel.
-hipError_t launch_groupnorm_apply(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,
-                                  int silu, uint16_t* out, int ldo, uint16_t* raw_out, const unsigned long long* acc, hipStream_t s);
-
 // Large slabs (VAE decoder, C in {128, 256, 512}, more than 16384 float2 per group): pixel-chunked three-launch form with
 // fully coalesced rows; `scratch` holds groupnorm_scratch_bytes(N, HW, C) bytes (0 = shape not handled: use launch_groupnorm).
 size_t groupnorm_scratch_bytes(int N, int HW, int C);

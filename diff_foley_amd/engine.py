@@ -92,9 +92,6 @@ _SIGS = {
     "df_debug_checksum_label": [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64],
     "df_test_gemm_epi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                          C.c_int, C.c_int, C.c_int, C.c_void_p],
-    "df_test_gn_chain": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
-                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "df_test_gemm_dual": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                           C.c_void_p],
     "df_test_gemm": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],

@@ -211,12 +211,6 @@ int df_debug_checksum_label(df_ctx* ctx, int64_t index, char* buf, int64_t len);
 int df_test_gemm_epi(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, const float* res_dev, void* C_dev,
                      int M, int N, int K, int act /*0 none, 1 SiLU, 2 ReLU*/, int out_operand, int tile, int splitk,
                      void* stream);
-/* GroupNorm fed by producer statistics (GemmParams::gn): one or two GEMMs (3x3 conv when conv != 0) write column ranges of
- * y [NB*H*Wd][N1+N2] fp32 and accumulate per-(sample, group) fixed-point sums; groupnorm_apply_kernel normalises -> out. */
-int df_test_gn_chain(const uint16_t* A1_dev, const uint16_t* W1_dev, const float* b1_dev, const float* res_dev, int N1, int K1,
-                     int tile1, int sk1, const uint16_t* A2_dev, const uint16_t* W2_dev, int N2, int K2, int tile2, int sk2, int NB,
-                     int H, int Wd, int conv, const float* gamma_dev, const float* beta_dev, float eps, int silu, float* y_dev,
-                     uint16_t* out_dev, unsigned long long* acc_dev, void* stream);
 int df_test_gemm_dual(const uint16_t* A_dev, const uint16_t* A2_dev, const uint16_t* W_dev, float* C_dev, int M, int N, int K1,
                       int K2, int tile, int splitk, void* stream);
 int df_test_gemm(const uint16_t* A_dev, const uint16_t* W_dev, float* C_dev, int M, int N, int K, int tile, int splitk,

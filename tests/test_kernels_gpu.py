@@ -354,77 +354,3 @@ def test_time_embed_first_layer_fused():
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max() < 2e-4       # cos/sin of arguments up to ~1e3 rad: fp32 argument reduction
 
-
-# ---- GroupNorm fed by producer statistics (GemmParams::gn -> groupnorm_apply_kernel) -------------------------------------
-_TILE_BM = {0: 128, 1: 128, 2: 64, 3: 64, 4: 32, 5: 128, 6: 256, 7: 128, 8: 128, 9: 256, 10: 128, 11: 128, 12: 64, 13: 64, 14: 32}
-
-
-def _gn_chain(NB, H, W, K1, N1, tile1, sk1, conv=False, N2=0, K2=0, tile2=3, sk2=1, res=False, silu=True, mean_shift=0.0):
-    E = _eng()
-    M = NB * H * W
-    Cin = K1 // 9 if conv else K1
-    a1 = bf(rnd((M, Cin), 1))
-    w1 = bf(rnd((N1, K1), 2) * (K1 ** -0.5))
-    b1 = (rnd((N1,), 3) + mean_shift).cuda()
-    r = rnd((M, N1), 4).cuda() if res else None
-    C_ = N1 + N2
-    gamma, beta = (1 + 0.2 * rnd((C_,), 5)).cuda(), (0.1 * rnd((C_,), 6)).cuda()
-    y = torch.empty(M, C_, device="cuda")
-    out = torch.empty(M, C_, device="cuda", dtype=odt())
-    acc = torch.zeros(NB * 64, dtype=torch.int64, device="cuda")
-    a1d, w1d = a1.cuda(), w1.cuda()
-    a2d = w2d = None
-    if N2:
-        a2, w2 = bf(rnd((M, K2), 7)), bf(rnd((N2, K2), 8) * (K2 ** -0.5))
-        a2d, w2d = a2.cuda(), w2.cuda()
-    rc = E.lib(PREC).df_test_gn_chain(ptr(a1d), ptr(w1d), ptr(b1), ptr(r) if res else None, N1, K1, tile1, sk1,
-                                       ptr(a2d) if N2 else None, ptr(w2d) if N2 else None, N2, K2, tile2, sk2, NB, H, W, int(conv),
-                                       ptr(gamma), ptr(beta), 1e-5, int(silu), ptr(y), ptr(out), ptr(acc), stream())
-    assert rc == 0, E.lib(PREC).df_last_error()
-    torch.cuda.synchronize()
-    # reference: GroupNorm(32) of the tensor the GEMMs actually stored (fp32), torch on the GPU result's own y
-    yy = y.float().cpu().reshape(NB, H * W, C_).permute(0, 2, 1)                 # [NB][C][HW]
-    ref = F.group_norm(yy, 32, gamma.cpu(), beta.cpu(), 1e-5)
-    if silu:
-        ref = F.silu(ref)
-    ref = ref.permute(0, 2, 1).reshape(M, C_)
-    # and y itself against the fp32 matmul / conv of the rounded operands
-    if conv:
-        x = a1.float().reshape(NB, H, W, Cin).permute(0, 3, 1, 2)
-        wt = w1.float().reshape(N1, 3, 3, Cin).permute(0, 3, 1, 2)
-        y1 = F.conv2d(x, wt, b1.cpu(), padding=1).permute(0, 2, 3, 1).reshape(M, N1)
-    else:
-        y1 = a1.float() @ w1.float().t() + b1.cpu()
-    if res:
-        y1 = y1 + r.cpu()
-    assert rel_l2(y[:, :N1].cpu(), y1) < 2e-3
-    if N2:
-        assert rel_l2(y[:, N1:].cpu(), a2.float() @ w2.float().t()) < 2e-3
-    return rel_l2(out.float().cpu(), ref)
-
-
-@pytest.mark.parametrize("tile,sk", [(3, 1), (13, 1), (0, 1), (2, 1), (4, 1), (8, 1), (9, 1), (3, 2), (12, 4), (8, 8), (2, 16)])
-@pytest.mark.parametrize("NB,H,W,C", [(2, 16, 16, 320), (4, 8, 8, 640), (2, 4, 4, 1280)])
-def test_groupnorm_from_producer_statistics_linear(tile, sk, NB, H, W, C):
-    """1x1 / Linear producers: in-epilogue statistics (tile inside one sample) and the split-K reduce form; channel counts
-    whose groups (10 / 20 / 40 columns) do not line up with the 4-column chunks or the tile edges."""
-    K = 256 if sk <= 4 else 128 * sk
-    if sk == 1 and (H * W) % _TILE_BM[tile] != 0:
-        pytest.skip("tile spans several samples: the engine falls back to the standalone kernel")
-    err = _gn_chain(NB, H, W, K, C, tile, sk, res=(tile % 2 == 0), mean_shift=3.0)
-    assert err < (4e-3 if PREC == "bf16" else 6e-4)          # output rounding of the operand type (2^-9 / 2^-12) only
-
-
-@pytest.mark.parametrize("tile,sk", [(5, 1), (6, 1), (7, 1), (6, 2), (3, 1), (8, 2)])
-def test_groupnorm_from_producer_statistics_conv(tile, sk):
-    NB, H, W, Cin, Cout = 2, 16, 32, 128, 320
-    err = _gn_chain(NB, H, W, 9 * Cin, Cout, tile, sk, conv=True)
-    assert err < (4e-3 if PREC == "bf16" else 6e-4)
-
-
-@pytest.mark.parametrize("N1,N2", [(640, 320), (1280, 640), (320, 320)])
-def test_groupnorm_from_producer_statistics_concat(N1, N2):
-    """Decoder concat buffer: two producers write column ranges of one tensor; the groups of the concat (30 / 60 / 20 columns)
-    straddle the boundary between them when N1 is not a multiple of the group width."""
-    err = _gn_chain(2, 16, 16, 256, N1, 3, 1, N2=N2, K2=192, tile2=12, sk2=2, res=True)
-    assert err < (4e-3 if PREC == "bf16" else 6e-4)
