@@ -771,6 +771,35 @@ hipError_t launch_cast_bf16_2d(const float* x, int ld, uint16_t* out, long rows,
   return hipGetLastError();
 }
 
+// nearest-x2 upsample + conv3x3 == four 2x2-tap convs on the input-resolution map (output phase (a, b) = (Y & 1, X & 1)): the
+// taps of the 3x3 kernel that land on the same input pixel are summed in fp32 and rounded ONCE:
+//   W'[a][b][o][dy][dx][c] = sum_{ky in S_a(dy)} sum_{kx in S_b(dx)} w[o][c][ky][kx],  S_0 = ({0}, {1, 2}),  S_1 = ({0, 1}, {2});
+// tap (dy, dx) reads input pixel (y - 1 + a + dy, x - 1 + b + dx).  out: [4][O][4][Ipad] operand type.
+__global__ void pack_conv_ups4_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int O, int I, int Ipad) {
+  const long total = (long)16 * O * Ipad;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(e % Ipad);
+    long r = e / Ipad;
+    const int tap = (int)(r & 3);
+    r >>= 2;
+    const int o = (int)(r % O), ph = (int)(r / O);
+    const int a = ph >> 1, b = ph & 1, dy = tap >> 1, dx = tap & 1;
+    const int ky0 = a == 0 ? (dy == 0 ? 0 : 1) : (dy == 0 ? 0 : 2), ky1 = a == 0 ? (dy == 0 ? 0 : 2) : (dy == 0 ? 1 : 2);
+    const int kx0 = b == 0 ? (dx == 0 ? 0 : 1) : (dx == 0 ? 0 : 2), kx1 = b == 0 ? (dx == 0 ? 0 : 2) : (dx == 0 ? 1 : 2);
+    float acc = 0.f;
+    if (ci < I)
+      for (int ky = ky0; ky <= ky1; ++ky)
+        for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((long)o * I + ci) * 3 + ky) * 3 + kx];
+    out[e] = f2bf(acc);
+  }
+}
+
+hipError_t launch_pack_conv_ups4(const float* w, uint16_t* out, int O, int I, int Ipad, hipStream_t s) {
+  const long n = (long)16 * O * Ipad;
+  hipLaunchKernelGGL(pack_conv_ups4_kernel, dim3(grid_for(n)), dim3(256), 0, s, w, out, O, I, Ipad);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_conv_weight(const float* w, uint16_t* out, int O, int I, int KH, int KW, int Ipad,
                                    hipStream_t s) {
   const long n = (long)O * KH * KW * Ipad;

@@ -250,6 +250,19 @@ struct df_ctx {
     packed[key] = o;
     return o;
   }
+  // 3x3 conv weight that follows a nearest-x2 Upsample: per-phase 2x2-tap weights [4][O][4][Ipad] (gemm_m3.hip)
+  const bf16_t* w_conv3_ups4(const std::string& name, int ipad) {
+    const std::string key = name + "#c3ups4";
+    auto it = packed.find(key);
+    if (it != packed.end()) return (const bf16_t*)it->second;
+    const RawT& t = rt(name);
+    if (t.shape.size() != 4 || t.shape[2] != 3 || t.shape[3] != 3) fail("'%s' is not a 3x3 conv weight", name.c_str());
+    const int O = (int)t.shape[0], I = (int)t.shape[1];
+    bf16_t* o = (bf16_t*)pmalloc((size_t)16 * O * ipad * 2);
+    HIPCHK(launch_pack_conv_ups4(f32(name), o, O, I, ipad, pack_stream));
+    packed[key] = o;
+    return o;
+  }
   // conv2 + folded 1x1 skip connection: operand [O][9*I + I2] and the summed bias
   void w_conv3_skip(const std::string& conv, const std::string& skip, const bf16_t** w, const float** b) {
     const std::string kw = conv + ".weight#c3skip", kb = conv + ".bias#c3skip";
@@ -488,12 +501,12 @@ struct Builder {
     }
     gp.splitk = sk;
     if (sk > 1) {
-      const size_t need = (size_t)sk * gp.M * gp.N * 4;
+      const size_t need = (size_t)sk * gp.M * gp.N * 4 * (gp.taps == 4 ? 4 : 1);
       if (need > pl->partial_bytes) pl->partial_bytes = need;
     }
     gp.dbg = getenv("DF_GEMM_DBG") ? atoi(getenv("DF_GEMM_DBG")) : 0;   // tools only (timing experiments)
     o.gp = gp;
-    pl->gemm_flops += 2.0 * gp.M * (double)gp.N * gp.K * batch;
+    pl->gemm_flops += 2.0 * gp.M * (double)gp.N * gp.K * batch * (gp.taps == 4 ? 4 : 1);
     pl->weight_bytes += 2.0 * (double)gp.N * gp.K * (gp.w_bs ? batch : 1);
     pl->ops.push_back(std::move(o));
     return pl->ops.back();
@@ -521,6 +534,19 @@ struct Builder {
     g.M = NB * g.OH * g.OW; g.N = Cout; g.K = 9 * Cin;
     g.taps = 9; g.Cin = Cin; g.alpha = 1.f;
     g.a_bytes = op_bytes((size_t)NB * H * Wd * Cin * 2); g.w_bytes = op_bytes((size_t)Cout * 9 * Cin * 2);
+    return g;
+  }
+  // nearest-x2 upsample + conv3x3 as four 2x2-tap convs (one per output phase) over the INPUT-resolution map: rows = input
+  // pixels, K = 4 Cin, one weight matrix per phase (w_bs), output rows = the x2 map (the kernel scatters by phase)
+  static GemmParams gp_conv3_ups4(const bf16_t* A, int NB, int H, int Wd, int Cin, const bf16_t* W4, int Cout) {
+    GemmParams g{};
+    g.A = A; g.lda = Cin; g.W = W4;
+    g.H = H; g.Wd = Wd; g.stride = 1; g.ups = 0;
+    g.OH = H; g.OW = Wd;                       // row grid of the GEMM (the output map is 2H x 2W)
+    g.M = NB * H * Wd; g.N = Cout; g.K = 4 * Cin;
+    g.taps = 4; g.Cin = Cin; g.alpha = 1.f;
+    g.w_bs = (long)Cout * 4 * Cin;
+    g.a_bytes = op_bytes((size_t)NB * H * Wd * Cin * 2); g.w_bytes = op_bytes((size_t)Cout * 4 * Cin * 2);
     return g;
   }
   static void out_f32(GemmParams& g, float* C, int ldc) { g.C = C; g.ldc = ldc; g.out_bf16 = 0; }
@@ -1312,7 +1338,12 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
       } else {  // UP: nearest x2 then conv3x3 (openai_unetmodel.py:100-119)
         dst = mk(h.rows * 4, d.cout);
         bf16_t* hb = in_aux ? in_aux : b.cast2d(h);
-        GemmParams g = Builder::gp_conv3(hb, N, hh, ww, d.cin, c->w_conv3(pre + d.prefix + ".conv.weight", d.cin), d.cout, 1, 1);
+        // Upsample (openai_unetmodel.py:100-119): four 2x2-tap convs on the input-resolution map instead of a 3x3 conv on
+        // the x2 map (2.25x fewer multiply-adds, gemm_m3.hip); DF_NO_UPS4=1 keeps the 3x3 form (A/B, parity tests)
+        static const bool no_ups4 = getenv("DF_NO_UPS4") && atoi(getenv("DF_NO_UPS4"));
+        GemmParams g = (!no_ups4 && d.cin % 64 == 0)
+                           ? Builder::gp_conv3_ups4(hb, N, hh, ww, d.cin, c->w_conv3_ups4(pre + d.prefix + ".conv.weight", d.cin), d.cout)
+                           : Builder::gp_conv3(hb, N, hh, ww, d.cin, c->w_conv3(pre + d.prefix + ".conv.weight", d.cin), d.cout, 1, 1);
         Builder::out_f32(g, dst.p, dst.ld);
         g.bias = c->f32(pre + d.prefix + ".conv.bias");
         b.gemm(g, 1, "up");
@@ -1867,7 +1898,9 @@ void build_vae(df_ctx* c, Plan* pl, int B, int H, int W) {
       bf16_t* hb = b.cast2d(h);
       F32 o{b.buf<float>((size_t)h.rows * 4 * co), h.rows * 4, co, co};
       const std::string p = pre + "decoder.up." + std::to_string(lvl) + ".upsample.conv";
-      GemmParams g = Builder::gp_conv3(hb, B, hh, ww, co, c->w_conv3(p + ".weight", co), co, 1, 1);
+      static const bool no_ups4 = getenv("DF_NO_UPS4") && atoi(getenv("DF_NO_UPS4"));
+      GemmParams g = (!no_ups4 && co % 64 == 0) ? Builder::gp_conv3_ups4(hb, B, hh, ww, co, c->w_conv3_ups4(p + ".weight", co), co)
+                                                : Builder::gp_conv3(hb, B, hh, ww, co, c->w_conv3(p + ".weight", co), co, 1, 1);
       Builder::out_f32(g, o.p, co);
       g.bias = c->f32(p + ".bias");
       b.gemm(g, 1, "vae.up");
@@ -2201,7 +2234,7 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
       for (auto& o : pl->ops) {
         if (!o.is_gemm || o.c_ext) continue;
         const TuneChoice& ch = tc[tune_key(o)];
-        const size_t need = (size_t)ch.sk * o.gp.M * o.gp.N * 4;
+        const size_t need = (size_t)ch.sk * o.gp.M * o.gp.N * 4 * (o.gp.taps == 4 ? 4 : 1);
         if (!gemm_tile_valid(o.gp, ch.tile, o.batch, ch.sk) || (ch.sk > 1 && need > pl->partial_bytes)) continue;
         o.tile = ch.tile;
         o.gp.splitk = ch.sk;
@@ -2235,7 +2268,7 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
     for (int t = 0; t < TILE_ALL && t < tile_cap; ++t) {
       for (int sk = 1; sk <= 32; sk *= 2) {
         if (!gemm_tile_valid(g, t, o.batch, sk)) { if (sk > 1) break; else continue; }
-        const size_t need = (size_t)sk * g.M * g.N * 4;
+        const size_t need = (size_t)sk * g.M * g.N * 4 * (g.taps == 4 ? 4 : 1);
         if (sk > 1 && need > pl->partial_bytes) break;
         GemmParams q = g;
         q.splitk = sk;
@@ -2388,7 +2421,7 @@ Plan* get_plan(df_ctx* c, const std::string& key, const std::function<void(Plan*
     // tuning may try larger split-K factors than the cost model picked: give the scratch some head-room
     size_t want = 0;
     for (auto& o : p->ops)
-      if (o.is_gemm && o.batch == 1) want = std::max(want, (size_t)32 * o.gp.M * o.gp.N * 4);
+      if (o.is_gemm && o.batch == 1) want = std::max(want, (size_t)32 * o.gp.M * o.gp.N * 4 * (o.gp.taps == 4 ? 4 : 1));
     if (want > ((size_t)512 << 20)) want = (size_t)512 << 20;
     if (want > p->partial_bytes) p->partial_bytes = want;
   }
@@ -3160,7 +3193,9 @@ int df_test_unet_block(df_ctx* c, const char* prefix, int kind, const float* x, 
     } else {
       bf16_t* hb = b.cast2d(xin);
       const std::string wn = pre + p + (kind == 2 ? ".op" : ".conv");
-      GemmParams g = Builder::gp_conv3(hb, N, H, W, Cin, c->w_conv3(wn + ".weight", Cin), Cout, kind == 2 ? 2 : 1, kind == 3 ? 1 : 0);
+      const bool ups4 = kind == 3 && Cin % 64 == 0 && !(getenv("DF_NO_UPS4") && atoi(getenv("DF_NO_UPS4")));   // as in the plan
+      GemmParams g = ups4 ? Builder::gp_conv3_ups4(hb, N, H, W, Cin, c->w_conv3_ups4(wn + ".weight", Cin), Cout)
+                          : Builder::gp_conv3(hb, N, H, W, Cin, c->w_conv3(wn + ".weight", Cin), Cout, kind == 2 ? 2 : 1, kind == 3 ? 1 : 0);
       Builder::out_f32(g, dst.p, Cout);
       g.bias = c->f32(wn + ".bias");
       b.gemm(g, 1, kind == 2 ? "down" : "up");
@@ -3182,6 +3217,21 @@ int df_test_conv3x3(const uint16_t* A, const uint16_t* W, const float* bias, flo
     g.splitk = splitk;
     g.dbg = getenv("DF_GEMM_DBG") ? atoi(getenv("DF_GEMM_DBG")) : 0;
     if (splitk > 1) g.partial = test_partial((size_t)splitk * g.M * g.N * 4);
+    HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
+  });
+}
+
+// Upsample + conv3x3 through the phase-decomposed form (gemm_m3.hip): W_oihw fp32 [Cout][Cin][3][3] is packed here.
+int df_test_conv3x3_ups4(const uint16_t* A, const float* W_oihw, const float* bias, float* C, uint16_t* w4_scratch, int NB, int H,
+                         int Wd, int Cin, int Cout, int tile, int splitk, void* stream) {
+  return guard([&] {
+    HIPCHK(launch_pack_conv_ups4(W_oihw, w4_scratch, Cout, Cin, Cin, (hipStream_t)stream));
+    GemmParams g = Builder::gp_conv3_ups4(A, NB, H, Wd, Cin, w4_scratch, Cout);
+    Builder::out_f32(g, C, Cout);
+    g.bias = bias;
+    g.splitk = splitk;
+    if (splitk > 1) g.partial = test_partial((size_t)splitk * 4 * g.M * g.N * 4);
+    if (!gemm_tile_valid(g, tile, 1, splitk)) fail("tile %d / split-K %d refused this problem", tile, splitk);
     HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
   });
 }

@@ -20,6 +20,7 @@ hipError_t launch_gemm_m0b(int tile_cfg, int epi, const GemmParams& p, int zdim,
 hipError_t launch_gemm_m1(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 hipError_t launch_gemm_m2(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 hipError_t launch_gemm_halo(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
+hipError_t launch_gemm_m3(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 
 namespace {
 
@@ -119,6 +120,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
 
 bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int nk = p.K / 64;
+  if (p.taps == 4) {     // phase-decomposed upsample conv (MODE 3): a subset of the generic tiles, plain epilogues only
+    static const bool ok3[TILE_ALL] = {false, false, false, true, false, false, false, false, true, true, true, true, true, true, false, false, false};
+    if (tile < 0 || tile >= TILE_ALL || !ok3[tile] || batch > 1) return false;
+    if (p.geglu || p.vt || p.ln_stats || p.stats || p.w_rows > 0 || p.sm_w > 0 || p.Cin2 > 0 || p.res || p.store_nchw) return false;
+    if (splitk > 1 && (p.N & 3) != 0) return false;
+    return splitk == 1 || nk / splitk >= 2;
+  }
   if (!gemm_tile_is_halo(tile)) {
     if (tile < 0 || tile >= TILE_ALL) return false;
     if (p.geglu && ((p.N & 63) != 0 || (p.ldc & 3) != 0)) return false;   // GEGLU needs the vectorised block epilogue
@@ -185,12 +193,32 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
   if (epi == EPI_XS && (!p.ln_stats || p.taps != 1 || !vec || (p.N & 63) != 0)) return hipErrorInvalidValue;
   hipError_t e;
   // MODE 0: linear / 1x1;  1: 3x3 stride 1 (tap offsets are linear, 2 VALU per request);  2: 3x3 stride 2 / upsampled
-  const int mode = (p.taps != 9) ? 0 : ((p.stride == 1 && !p.ups) ? 1 : 2);
-  if (gemm_tile_is_halo(tile_cfg)) e = launch_gemm_halo(tile_cfg, epi, p, zdim, stream);
+  const int mode = (p.taps == 4) ? 3 : (p.taps != 9) ? 0 : ((p.stride == 1 && !p.ups) ? 1 : 2);
+  if (mode == 3) {
+    if (batch > 1 || gemm_tile_is_halo(tile_cfg) || p.OH != p.H || p.OW != p.Wd || p.K != 4 * p.Cin || p.w_bs != (long)p.N * p.K)
+      return hipErrorInvalidValue;
+    e = launch_gemm_m3(tile_cfg, epi, p, zdim, stream);
+  } else if (gemm_tile_is_halo(tile_cfg)) e = launch_gemm_halo(tile_cfg, epi, p, zdim, stream);
   else if (mode == 0) e = (tile_cfg <= TILE_256x128) ? launch_gemm_m0a(tile_cfg, epi, p, zdim, stream) : launch_gemm_m0b(tile_cfg, epi, p, zdim, stream);
   else if (mode == 1) e = launch_gemm_m1(tile_cfg, epi, p, zdim, stream);
   else e = launch_gemm_m2(tile_cfg, epi, p, zdim, stream);
   if (e != hipSuccess) return e;
+  if (p.splitk > 1 && !p.defer_reduce && mode == 3) {
+    GemmParams q = p;
+    q.M = 4 * p.M;           // the slabs hold the x2 output map
+    q.taps = 1;
+    const long total = (long)q.M * (q.N >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if ((q.N & 3) != 0 || (q.ldc & 3) != 0 || q.store_nchw) return hipErrorInvalidValue;
+#define DF_RED3(SK) case SK: hipLaunchKernelGGL(splitk_reduce_vec_kernel<SK>, dim3(blocks), dim3(256), 0, stream, q); break;
+    switch (p.splitk) {
+      DF_RED3(2) DF_RED3(4) DF_RED3(8) DF_RED3(16) DF_RED3(32)
+      default: hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, q); break;
+    }
+#undef DF_RED3
+    return hipGetLastError();
+  }
   if (p.splitk > 1 && !p.defer_reduce) {
     const bool vec = !p.geglu && !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
                      (p.ld_rowbias & 3) == 0 && (p.ld_aux & 3) == 0;

@@ -485,13 +485,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   }
 
   int z = blockIdx.z;
+  // MODE 3 (nearest-x2 upsample + conv3x3 as four 2x2-tap convs, one per output phase (a, b) = (Y & 1, X & 1)): grid z =
+  // phase + 4 * split, one weight matrix per phase
+  const int phase = (MODE == 3) ? (z & 3) : 0;
+  if (MODE == 3) z >>= 2;
   const int nk = p.K / BK;
-  int kt0 = 0, kt1 = nk, batch = z;
+  int kt0 = 0, kt1 = nk, batch = (MODE == 3) ? phase : z;
   if (p.splitk > 1) {
     const int per = (nk + p.splitk - 1) / p.splitk;
     kt0 = z * per;
     kt1 = min(nk, kt0 + per);
-    batch = 0;
+    if (MODE != 3) batch = 0;
   }
   const bf16_t* Ab = p.A + (long)batch * p.a_bs;
   const bf16_t* Wb = p.W + (long)batch * p.w_bs + (p.w_rows > 0 ? (long)(m0 / p.w_rows) * p.w_bs : 0l);
@@ -530,7 +534,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
       const int ohw = p.OH * p.OW;
       const int nb = m / ohw, rem = m - nb * ohw;
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      if (MODE == 1) {
+      if (MODE == 3) {
+        // rows = INPUT-resolution pixels (OH = H, OW = Wd here); tap (dy, dx) of phase (a, b) reads pixel (y-1+a+dy, x-1+b+dx)
+        const int pa = phase >> 1, pb = phase & 1;
+        a_off[i] = (unsigned)((((long)(nb * p.H + oy - 1 + pa) * p.Wd + ox - 1 + pb) * p.lda + c8) * 2);
+        unsigned msk = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int y = oy - 1 + pa + (t >> 1), x = ox - 1 + pb + (t & 1);
+          if (mv && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd) msk |= 1u << t;
+        }
+        a_msk[i] = msk;
+      } else if (MODE == 1) {
         a_off2[i] = mv ? (unsigned)((((long)(nb * p.H + oy) * p.Wd + ox) * p.lda2 + c8) * 2) : OOB;
         a_off[i] = (unsigned)((((long)(nb * p.H + oy) * p.Wd + ox) * p.lda + c8) * 2);
         unsigned msk = 0;
@@ -585,6 +600,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
                                                    (live && a_off2[i] != OOB) ? a_off2[i] + kb : OOB, 0, 0, 0); \
       }                                                                                         \
+    } else if (MODE == 3) {                                                                     \
+      const unsigned delta = (unsigned)((((d_tap >> 1) * p.Wd + (d_tap & 1)) * p.lda + d_cc) * 2); \
+      const unsigned bit = live ? (1u << d_tap) : 0u;                                           \
+      _Pragma("unroll") for (int i = 0; i < AP; ++i)                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dmaA + ((ST) * BM + i * RPP) * (BK * 2)), 16, \
+                                                 (a_msk[i] & bit) ? a_off[i] + delta : OOB, 0, 0, 0); \
     } else if (MODE == 1) {                                                                     \
       if (d_tap < 9) {                                                                          \
         const int ky = (d_tap * 11) >> 5, kx = d_tap - ky * 3;                                  \
@@ -752,7 +773,38 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
       for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  if constexpr (EPI != EPI_ANY) {     // the host routes only vectorisable, row-major problems to the specialised kernels
+  if constexpr (MODE == 3) {
+    // tile row (input-resolution pixel n, y, x) -> output pixel (n, 2y + a, 2x + b) of the x2 map; the epilogue sees the
+    // OUTPUT tensor: M = 4 * rows.  Row table behind the epilogue tile (launch_cfg reserves BM ints).
+    int* srow = reinterpret_cast<int*>(smem + (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8);
+    __builtin_amdgcn_s_barrier();
+    for (int rr = tid; rr < BM; rr += NT) {
+      const int m = m0 + rr, hw = p.OH * p.OW;
+      const int nb = m / hw, rem = m - nb * hw, oy = rem / p.OW, ox = rem - oy * p.OW;
+      srow[rr] = (m < p.M) ? ((nb * 2 * p.OH + 2 * oy + (phase >> 1)) * 2 * p.OW + 2 * ox + (phase & 1)) : 4 * p.M;
+    }
+    __syncthreads();
+    GemmParams pe = p;
+    pe.M = 4 * p.M;
+    auto rowmap = [&](int rr) { return srow[rr]; };
+    if constexpr (EPI != EPI_ANY) {
+      epilogue_block<BM, BN, NT, TM, TN, EPI>(pe, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap, ev);
+    } else {
+      const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.ld_rowbias & 3) == 0 &&
+                          (p.ld_aux & 3) == 0;
+      if (vec_ok) {
+        epilogue_block<BM, BN, NT, TM, TN, EPI>(pe, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap, ev);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          int rowv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rowv[r] = rowmap(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+          epilogue_band<TN>(pe, z, 0, rowv, acc[i], n0 + wn * WTN, l31);
+        }
+      }
+    }
+  } else if constexpr (EPI != EPI_ANY) {     // the host routes only vectorisable, row-major problems to the specialised kernels
     epilogue_block<BM, BN, NT, TM, TN, EPI>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid,
                                              [&](int r) { return m0 + r; }, ev, ln_mr);
   } else {
@@ -1081,7 +1133,7 @@ template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI>
 hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   constexpr size_t ring = (size_t)(BM + BN) * BK * 2 * NST;                    // operand ring
-  constexpr size_t stage = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8;          // epilogue tile + (mean, rstd) row table
+  constexpr size_t stage = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8 + (MODE == 3 ? (size_t)BM * 4 : 0);   // epilogue tile + (mean, rstd) row table (+ MODE 3 pixel table)
   const size_t base = ring > stage ? ring : stage;
   // LayerNorm-folded GEMMs park the producer's row partials behind the ring: BM * ln_slots float2
   const size_t lds = base;           // LayerNorm row partials are exchanged through the dead ring after the main loop
@@ -1095,7 +1147,7 @@ hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE, EPI>), dim3(nbm * nbn, 1, zdim), dim3(64 * WGM * WGN), lds, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE, EPI>), dim3(nbm * nbn, 1, MODE == 3 ? 4 * zdim : zdim), dim3(64 * WGM * WGN), lds, stream, p);
   return hipGetLastError();
 }
 

@@ -68,6 +68,8 @@ hipError_t launch_cast_bf16_2d(const float* x, int ld, uint16_t* out, long rows,
 
 // Weight re-pack on device: conv OIHW fp32 -> [O][kh][kw][Ipad] bf16 ; (Ipad >= I, zero filled)
 hipError_t launch_pack_conv_weight(const float* w, uint16_t* out, int O, int I, int KH, int KW, int Ipad, hipStream_t s);
+// conv3x3 OIHW fp32 -> per-phase 2x2-tap weights [4][O][4][Ipad] of the nearest-x2-upsample + conv3x3 pair (gemm_m3.hip)
+hipError_t launch_pack_conv_ups4(const float* w, uint16_t* out, int O, int I, int Ipad, hipStream_t s);
 // GEGLU weight/bias interleave: rows [x(4C) ; gate(4C)] -> blocks of (32 x-rows | 32 gate-rows)
 // LayerNorm-folded Linear weight (one call per stacked matrix): operand rows gamma*W at row_off (or GEGLU-interleaved
 // when geglu_half > 0), their column sums cs and the folded bias bb = beta.W + bias

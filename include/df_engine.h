@@ -234,6 +234,11 @@ int df_test_unet_block(df_ctx* ctx, const char* prefix, int kind, const float* x
                        const float* context_dev, float* out_dev, int N, int H, int W, int Cin, int Cout, int T, void* stream);
 int df_test_conv3x3(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, float* C_dev, int NB, int H,
                     int W, int Cin, int Cout, int stride, int ups, int tile, int splitk, void* stream);
+/* nearest-x2 upsample + conv3x3 in the phase-decomposed form (four 2x2-tap convs on the input-resolution map, per-phase
+ * weights = sums of the 3x3 taps): A [NB*H*Wd][Cin] operand type, W_oihw fp32 [Cout][Cin][3][3], w4_scratch 16*Cout*Cin
+ * operand-type elements, C fp32 [NB*2H*2Wd][Cout]. */
+int df_test_conv3x3_ups4(const uint16_t* A_dev, const float* W_oihw_dev, const float* bias_dev, float* C_dev, uint16_t* w4_scratch_dev,
+                         int NB, int H, int Wd, int Cin, int Cout, int tile, int splitk, void* stream);
 int df_test_groupnorm(const float* x_dev, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,
                       int silu, uint16_t* out_dev, void* stream);
 int df_test_layernorm(const float* x_dev, int rows, int C, const float* gamma, const float* beta, uint16_t* out_dev,

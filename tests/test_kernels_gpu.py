@@ -354,3 +354,53 @@ def test_time_embed_first_layer_fused():
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max() < 2e-4       # cos/sin of arguments up to ~1e3 rad: fp32 argument reduction
 
+
+
+# ---- nearest-x2 upsample + conv3x3 as four 2x2-tap convs on the input-resolution map (csrc/gemm_m3.hip) ---------------------
+def _ups4_weights(w):
+    """[a][b][O][dy][dx][I] from OIHW fp32: the 3x3 taps that land on one input pixel are summed (S_0 = ({0},{1,2}), S_1 = ({0,1},{2}))."""
+    S = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+    O, I = w.shape[:2]
+    out = torch.zeros(2, 2, O, 2, 2, I)
+    for a in (0, 1):
+        for b in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    out[a, b, :, dy, dx, :] = sum(w[:, :, ky, kx] for ky in S[a][dy] for kx in S[b][dx])
+    return out
+
+
+@pytest.mark.parametrize("tile,splitk", [(3, 1), (13, 1), (12, 1), (11, 1), (10, 1), (8, 1), (9, 1), (3, 2), (12, 4), (8, 2)])
+@pytest.mark.parametrize("NB,H,W,Cin,Cout", [(2, 8, 32, 128, 192), (3, 4, 16, 256, 64), (1, 2, 8, 64, 320), (2, 5, 7, 64, 64)])
+def test_upsample_conv_phase_decomposed(tile, splitk, NB, H, W, Cin, Cout):
+    """Two references: (i) exact -- the same per-phase weights (fp32 sums rounded once to the operand type) applied as 2x2
+    convs, fp32 accumulation: only the summation order differs (2e-3); (ii) the reference module's form -- nearest x2 then
+    conv3x3 with the UNROUNDED fp32 weights (openai_unetmodel.py:100-119): operand rounding of the summed weights only."""
+    E = _eng()
+    if splitk > 1 and 4 * Cin // 64 // splitk < 2:
+        pytest.skip("K too short for this split")
+    x = bf(rnd((NB, Cin, H, W), 3))
+    w = rnd((Cout, Cin, 3, 3), 4) / (3 * Cin ** 0.5)
+    b = rnd((Cout,), 5)
+    w4 = bf(_ups4_weights(w)).float()                                        # what the engine's packing must produce
+    xp = F.pad(x.float(), (1, 1, 1, 1))
+    ref = torch.empty(NB, Cout, 2 * H, 2 * W)
+    for a in (0, 1):
+        for bb in (0, 1):
+            k = w4[a, bb].permute(0, 3, 1, 2)                                # [O][I][dy][dx]
+            ref[:, :, a::2, bb::2] = F.conv2d(xp[:, :, a:a + H + 1, bb:bb + W + 1], k, b)
+    ref_module = F.conv2d(F.interpolate(x.float(), scale_factor=2, mode="nearest"), w, b, padding=1)
+    a_dev = x.permute(0, 2, 3, 1).contiguous().cuda()
+    w_dev, b_dev = w.cuda().contiguous(), b.cuda()
+    scratch = torch.empty(16 * Cout * Cin, dtype=odt(), device="cuda")
+    c = torch.full((NB * 4 * H * W, Cout), float("nan"), device="cuda")
+    rc = E.lib(PREC).df_test_conv3x3_ups4(ptr(a_dev), ptr(w_dev), ptr(b_dev), ptr(c), ptr(scratch), NB, H, W, Cin, Cout, tile,
+                                          splitk, stream())
+    assert rc == 0, E.lib(PREC).df_last_error()
+    torch.cuda.synchronize()
+    got = c.cpu().reshape(NB, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, ref) < 2e-3
+    assert rel_l2(got, ref_module) < (6e-3 if PREC == "bf16" else 8e-4)
+    packed = scratch.float().cpu().reshape(2, 2, Cout, 2, 2, Cin)
+    assert torch.equal(packed, w4)                                           # the packing kernel, bit for bit

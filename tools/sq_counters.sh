@@ -1,0 +1,18 @@
+#!/bin/bash
+# SQ counters of the whole denoise step per kernel (MFMA busy, LDS stalls, bank conflicts, occupancy), two --pmc passes of the
+# SAME bench command on a tuned configuration (counters with --kernel-trace only, as MI355X_MICROARCH.md prescribes).
+# usage (GPU box, repo root): tools/sq_counters.sh [outdir]  ->  <outdir>/sq_counters.json (copy to profiles/rN_sq_counters.json)
+ROOTD=$(pwd)
+OUT=${1:-$ROOTD/gpurun_out/sq}
+rm -rf $OUT; mkdir -p $OUT
+export DF_TUNE_CACHE=$OUT/tune_cache.txt
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-modes --no-vae"
+python bench.py $ARGS 2>/dev/null | tail -1 | cut -c1-160
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES \
+  --kernel-trace --output-format csv -d $OUT/a -o a -- python $ROOTD/bench.py $ARGS > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_VMEM \
+  --kernel-trace --output-format csv -d $OUT/b -o b -- python $ROOTD/bench.py $ARGS > /dev/null 2>&1
+cd $ROOTD
+python tools/sq_counters.py $OUT $OUT/sq_counters.json
+rm -rf $OUT/a $OUT/b
