@@ -165,26 +165,26 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
       s = DF_MFMA_32x32x16(kf, qf[c], s);
     }
     // ---- online softmax over this lane's 16 keys (+ partner half-wave)
+    // The softmax scale (x log2 e) is applied inside the exponent's FMA: the maximum is taken over the RAW scores (the scale
+    // is positive) and scaled once, p = exp2(fma(s, scale, -m)) -- 16 multiplies per tile fewer than scaling every score.
     float mx = -INFINITY;
     if (k0 + KT > Tk) {          // ragged last tile only: mask keys that do not exist
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        s[r] = (key < Tk) ? s[r] * scale_log2e : -INFINITY;
+        s[r] = (key < Tk) ? s[r] : -INFINITY;
       }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] *= scale_log2e;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;
     const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 valid key
     float ps = 0.f;
     uint32_t pk[8];
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-      const float p0 = __builtin_amdgcn_exp2f(s[r] - m_new), p1 = __builtin_amdgcn_exp2f(s[r + 1] - m_new);
+      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2e, -m_new)),
+                  p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r + 1], scale_log2e, -m_new));
       ps += p0 + p1;
       pk[r >> 1] = pack_bf2_bounded(p0, p1);      // p in [0, 1]
     }

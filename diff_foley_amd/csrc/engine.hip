@@ -595,7 +595,7 @@ struct Builder {
   // concat buffer.  Names differ between the two families, so they are passed in.
   void resblock(const F32& x, const F32& out, int NB, int H, int Wd, const std::string& n1, const std::string& c1,
                 const std::string& n2, const std::string& c2, const std::string& skip, float eps,
-                const float* emb, int emb_ld, int emb_col) {
+                const float* emb, int emb_ld, int emb_col, int dup_rows = 0) {
     const int cin = x.C, cout = out.C, M = x.rows;
     const bool has_skip = c->has(nm(skip + ".weight"));
     if (!has_skip && cin != cout) fail("resblock %s: channel change without skip conv", nm(c1).c_str());
@@ -664,6 +664,7 @@ struct Builder {
         g.w_bytes = op_bytes((size_t)cout * g.K * 2);
       } else if (has_skip) { g.res = out.p; g.ldr = out.ld; } else { g.res = x.p; g.ldr = x.ld; }
       attach_aux(g, M, cout);
+      g.dup_rows = dup_rows;       // CFG prefix: this block ran on one half of the batch, its output feeds both
       gemm(g, 1, "res.conv2");
     }
     if (fold_skip) pl->release(xraw);
@@ -772,15 +773,21 @@ struct Builder {
 
   // SpatialTransformer (attention_openai.py:250-261) with one BasicTransformerBlock (:211-215).
   // ctxK [NB*Tc][C] bf16 and ctxVt [NB][C][ldvt] bf16 are the hoisted cross-attention K / V^T.
+  // cfg_prefix: the block is the first SpatialTransformer of a classifier-free-guidance batch [x ; x] -- its GroupNorm, proj_in,
+  // Q|K|V projection, self-attention and out-projection see identical rows in both halves (no context yet), so they run on the
+  // first half only and attn1.out stores every row for both halves (GemmParams::dup_rows); from the cross-attention on, full batch.
   void spatial_transformer(const F32& x, const F32& out, int NB, int T, const std::string& p, int heads,
-                           const bf16_t* ctxK, const bf16_t* ctxVt, int Tc, int ldvtc, const PX* px = nullptr) {
+                           const bf16_t* ctxK, const bf16_t* ctxVt, int Tc, int ldvtc, const PX* px = nullptr,
+                           bool cfg_prefix = false) {
     static const bool no_fold = getenv("DF_NO_LNFOLD") && atoi(getenv("DF_NO_LNFOLD"));
     if (no_fold) return spatial_transformer_unfused(x, out, NB, T, p, heads, ctxK, ctxVt, Tc, ldvtc);
     const int C = x.C, M = x.rows, D = C / heads;
+    if (cfg_prefix && (T % 4 != 0 || NB % 2 != 0)) fail("cfg prefix needs the fused QKV form");
+    const int Mp = cfg_prefix ? M / 2 : M, NBp = cfg_prefix ? NB / 2 : NB;     // rows / samples of the deduplicated prefix
     if (!attention_supported(D)) fail("unsupported attention head dim %d", D);
     const std::string tb = p + ".transformer_blocks.0";
     const float scale = 1.0f / sqrtf((float)D);
-    bf16_t* a = groupnorm(x, NB, p + ".norm", 1e-6f, 0, nullptr);
+    bf16_t* a = groupnorm(F32{x.p, Mp, C, x.ld}, NBp, p + ".norm", 1e-6f, 0, nullptr);
     float* t0 = buf<float>((size_t)M * C);        // fp32 residual stream of the transformer block
     F32 t0v{t0, M, C, C};
     bf16_t* xb = buf<bf16_t>((size_t)M * C);      // its operand-type copy (A operand of the LayerNorm-folded GEMMs)
@@ -799,7 +806,7 @@ struct Builder {
       g.bias = bb;
     };
     {
-      GemmParams g = gp_linear(a, M, C, c->w_linear(nm(p + ".proj_in.weight")), C);
+      GemmParams g = gp_linear(a, Mp, C, c->w_linear(nm(p + ".proj_in.weight")), C);
       produces_t0(g);
       g.bias = c->f32(nm(p + ".proj_in.bias"));
       gemm(g, 1, "st.proj_in");
@@ -832,7 +839,7 @@ struct Builder {
       c->w_ln_stack(nm(tb + ".attn1.qkv"), nm(tb + ".norm1"),
                     {nm(tb + ".attn1.to_q.weight"), nm(tb + ".attn1.to_k.weight"), nm(tb + ".attn1.to_v.weight")}, {}, false,
                     &w, &cs, &bb);
-      GemmParams g = gp_linear(xb, M, C, w, 3 * C);
+      GemmParams g = gp_linear(xb, Mp, C, w, 3 * C);
       out_b16(g, qk, 2 * C);
       ln_fold(g, cs, bb);
       g.vt = vt; g.vt_col0 = 2 * C; g.vt_T = T; g.ldvt = ldvt;
@@ -840,13 +847,14 @@ struct Builder {
     }
     bf16_t* o = o_own ? o_own : a;                 // GroupNorm output is dead after proj_in
     other("attn.self", [=](hipStream_t s, const RunArgs&) {
-      return launch_attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, o, C, NB, heads, D, T, T, scale, s);
+      return launch_attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, o, C, NBp, heads, D, T, T, scale, s);
     });
     {
-      GemmParams g = gp_linear(o, M, C, c->w_linear(nm(tb + ".attn1.to_out.0.weight")), C);
+      GemmParams g = gp_linear(o, Mp, C, c->w_linear(nm(tb + ".attn1.to_out.0.weight")), C);
       produces_t0(g);
       g.bias = c->f32(nm(tb + ".attn1.to_out.0.bias"));
       g.res = t0; g.ldr = C;
+      g.dup_rows = cfg_prefix ? Mp : 0;           // t0 / xb / statistics of BOTH halves of the CFG batch from here on
       gemm(g, 1, "st.attn1.out");
     }
     // ---- cross attention
@@ -1269,9 +1277,19 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
 
   // ---- input packing: NCHW fp32 -> NHWC bf16 (channels padded to 64), CFG duplication folded in
   const int cin = u.in_channels;
-  bf16_t* xin = b.buf<bf16_t>((size_t)N * HW * 64);
+  // Classifier-free guidance runs the batch [x ; x] with the contexts [uncond ; cond]: everything in front of the first
+  // cross-attention -- conv_in, the first ResBlock, and the first SpatialTransformer up to its self-attention out-projection --
+  // is identical in both halves.  Those ops run on ONE half; the ops whose outputs the full batch needs (conv_in -> skip +
+  // ResBlock, ResBlock -> transformer residual, attn1.out -> residual stream) store every row twice (GemmParams::dup_rows).
+  static const bool no_dedup = getenv("DF_NO_CFGDEDUP") && atoi(getenv("DF_NO_CFGDEDUP"));
+  const bool dedup = cfg_mode && !which && !no_dedup && !no_lnfold && N % 2 == 0 && topo.input.size() >= 2 &&
+                     topo.input[0].size() == 1 && topo.input[0][0].kind == BlockDesc::CONV_IN && topo.input[1].size() == 2 &&
+                     topo.input[1][0].kind == BlockDesc::RES && topo.input[1][1].kind == BlockDesc::ST && (HW % 4) == 0 &&
+                     pxs.count(topo.input[1][1].prefix) > 0 && !(getenv("DF_NO_FFPROJ") && atoi(getenv("DF_NO_FFPROJ")));
+  const int Np = dedup ? N / 2 : N;              // samples the prefix ops run on
+  bf16_t* xin = b.buf<bf16_t>((size_t)Np * HW * 64);
   b.other("x.pack", [=](hipStream_t s, const RunArgs& a) {
-    return launch_pack_latent(a.x, xin, B_ext, cin, HW, 64, cfg_mode ? 2 : 1, 1.0f, nullptr, nullptr, s);
+    return launch_pack_latent(a.x, xin, B_ext, cin, HW, 64, (cfg_mode && !dedup) ? 2 : 1, 1.0f, nullptr, nullptr, s);
   });
 
   // ---- concat buffers of the decoder (skip tensors are produced straight into them)
@@ -1297,6 +1315,7 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
   };
 
   bf16_t* h_aux = nullptr;        // operand-type copy of the current h, when its producer was asked for one
+  bool in_prefix = false;         // building input_blocks[0..1] of a deduplicated CFG batch
   auto run_block = [&](const std::vector<BlockDesc>& blk, F32 h, int ds, F32 final_dst, bool tail_aux) -> F32 {
     for (size_t li = 0; li < blk.size(); ++li) {
       const BlockDesc& d = blk[li];
@@ -1314,19 +1333,25 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
       };
       if (d.kind == BlockDesc::CONV_IN) {
         dst = mk(N * HW, d.cout);
-        GemmParams g = Builder::gp_conv3(xin, N, H, W, 64, c->w_conv3(pre + d.prefix + ".weight", 64), d.cout, 1, 0);
+        GemmParams g = Builder::gp_conv3(xin, in_prefix ? Np : N, H, W, 64, c->w_conv3(pre + d.prefix + ".weight", 64), d.cout, 1, 0);
         Builder::out_f32(g, dst.p, dst.ld);
         g.bias = c->f32(pre + d.prefix + ".bias");
+        g.dup_rows = in_prefix ? Np * HW : 0;
         b.gemm(g, 1, "conv_in");
       } else if (d.kind == BlockDesc::RES) {
         dst = mk(h.rows, d.cout);
+        if (in_prefix)
+          b.resblock(F32{h.p, h.rows / 2, h.C, h.ld}, dst, Np, hh, ww, d.prefix + ".in_layers.0", d.prefix + ".in_layers.2",
+                     d.prefix + ".out_layers.0", d.prefix + ".out_layers.3", d.prefix + ".skip_connection", 1e-5f, E, etot,
+                     c->emb_off[which].at(d.prefix), h.rows / 2);
+        else
         b.resblock(h, dst, N, hh, ww, d.prefix + ".in_layers.0", d.prefix + ".in_layers.2", d.prefix + ".out_layers.0",
                    d.prefix + ".out_layers.3", d.prefix + ".skip_connection", 1e-5f, E, etot,
                    c->emb_off[which].at(d.prefix));
       } else if (d.kind == BlockDesc::ST) {
         dst = mk(h.rows, d.cout);
         b.spatial_transformer(h, dst, N, hh * ww, d.prefix, heads, kv[d.prefix].first, kv[d.prefix].second, Tc, ldvtc,
-                              pxs.count(d.prefix) ? &pxs[d.prefix] : nullptr);
+                              pxs.count(d.prefix) ? &pxs[d.prefix] : nullptr, in_prefix);
       } else if (d.kind == BlockDesc::DOWN) {
         dst = mk(h.rows / 4, d.cout);
         bf16_t* hb = in_aux ? in_aux : b.cast2d(h);
@@ -1366,7 +1391,9 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
   for (int k = 0; k < nin; ++k) {
     const int ds_run = (topo.input[k][0].kind == BlockDesc::DOWN) ? topo.in_ds[k] / 2 : topo.in_ds[k];
     const bool next_down = (k + 1 < nin) && topo.input[k + 1][0].kind == BlockDesc::DOWN;
+    in_prefix = dedup && k <= 1;
     h = run_block(topo.input[k], h, ds_run, skip_slot(k), next_down);
+    in_prefix = false;
   }
   const int ds_mid = topo.in_ds.back();
   if (which) {
@@ -2190,7 +2217,7 @@ static std::string tune_key(const Op& o) {
   const GemmParams& g = o.gp;
   char key[160];
   const int epi = (g.silu ? 128 : 0) | (g.ln_stats ? 1 : 0) | (g.stats ? 2 : 0) | (g.vt ? 4 : 0) | (g.aux ? 8 : 0) | (g.res ? 16 : 0) | (g.Cin2 ? 32 : 0) |
-                  (o.defer ? 64 : 0);
+                  (o.defer ? 64 : 0) | (g.dup_rows ? 256 : 0);
   snprintf(key, sizeof key, "%d_%d_%d_%d_%d_%d_%d_%d_e%d", g.M, g.N, g.K, g.taps, g.stride, g.ups, o.batch, g.geglu, epi);
   return key;
 }

@@ -57,6 +57,10 @@ struct GemmParams {
   // columns >= vt_col0 are stored TRANSPOSED per sample into vt[(row/vt_T)*(N-vt_col0) + col-vt_col0][ldvt] at
   // position row%vt_T (attention V^T straight out of the fused QKV projection); vt_col0 % BN == 0 for every tile used
   uint16_t* vt; int vt_col0; int vt_T; int ldvt;
+  // Classifier-free-guidance prefix: the two halves of the CFG batch are identical until the first cross-attention, so the
+  // ops in front of it run on ONE half (M rows) and the op that feeds the full batch stores every output row twice, at
+  // row and row + dup_rows (C / aux / stats alike).  0 = off.  Plain row-major epilogues only (LEAN / PROD / ANY, reduce).
+  int dup_rows;
   int store_nchw; int hw_out;        // write C as [batch][N][hw_out] instead of [rows][ldc]
   int gm;      // tile walk: each XCD's contiguous tile range runs M-fastest inside row groups of `gm` M-tiles (0 = all rows:
                // plain M-fastest; 1 = N-fastest).  Decides which operand panels an XCD's L2 can share; autotuned in situ.

@@ -105,14 +105,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
     if (p.stats) {           // N % 64 == 0: 16 consecutive threads hold one 64-column slot of one row
       const float s1 = row16_sum((v.x + v.y) + (v.z + v.w));
       const float s2 = row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
-      if ((threadIdx.x & 15) == 0) p.stats[(long)row * p.stats_slots + (col >> 6)] = make_float2(s1, s2);
+      if ((threadIdx.x & 15) == 0) {
+        p.stats[(long)row * p.stats_slots + (col >> 6)] = make_float2(s1, s2);
+        if (p.dup_rows) p.stats[(long)(row + p.dup_rows) * p.stats_slots + (col >> 6)] = make_float2(s1, s2);
+      }
     }
-    const long idx = (long)row * p.ldc + col;
-    if (p.out_bf16)
-      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
-    else
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;
-    if (p.aux) *reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    for (int rep = 0; rep < (p.dup_rows ? 2 : 1); ++rep) {      // CFG prefix: every row is stored for both halves of the batch
+      const long orow = row + (rep ? p.dup_rows : 0);
+      const long idx = orow * p.ldc + col;
+      if (p.out_bf16)
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+      else
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;
+      if (p.aux) *reinterpret_cast<uint2*>(p.aux + orow * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    }
   }
 }
 
@@ -146,6 +152,9 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
     if (p.sm_w > 0 && (p.sm_w != 32 || splitk > 1 || !p.ln_stats || !p.out_bf16 || p.w_rows <= 0 || (p.N & 31) != 0 || p.geglu ||
                        p.vt || p.res || p.rowbias || p.aux || p.alpha != 1.f || !p.bias))
       return false;
+    if (p.dup_rows > 0 && (batch > 1 || p.geglu || p.vt || p.sm_w > 0 || p.store_nchw || (p.N & 3) != 0 || (p.ldc & 3) != 0 ||
+                           (p.ldr & 3) != 0 || (p.ld_rowbias & 3) != 0 || (p.ld_aux & 3) != 0))
+      return false;
     if (p.Cin2 > 0 && (batch > 1 || (p.Cin2 & 63) != 0 || !p.A2)) return false;
     if (p.Cin2 > 0 && p.taps == 9 && (p.stride != 1 || p.ups)) return false;    // conv: the folded 1x1 skip connection
     if (p.Cin2 > 0 && p.taps != 9 && (p.taps != 1 || p.Cin2 >= p.K)) return false;   // linear: K columns [K-Cin2, K) from A2
@@ -153,6 +162,8 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
     return splitk == 1 || (batch <= 1 && nk / splitk >= 2);
   }
   if (splitk > 1 && (p.N & 3) != 0) return false;
+  if (p.dup_rows > 0 && (p.store_nchw || (p.N & 3) != 0 || (p.ldc & 3) != 0 || (p.ldr & 3) != 0 || (p.ld_rowbias & 3) != 0 || (p.ld_aux & 3) != 0))
+    return false;
   if (p.Cin2 > 0) return false;                 // the folded skip connection exists in the generic stride-1 kernel only
   if (p.taps != 9 || p.stride != 1 || p.ups != 0 || p.geglu || batch > 1) return false;
   int bm, bn, th, tw;
@@ -219,6 +230,7 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
 #undef DF_RED3
     return hipGetLastError();
   }
+  if (p.splitk > 1 && p.dup_rows > 0 && p.defer_reduce) return hipErrorInvalidValue;
   if (p.splitk > 1 && !p.defer_reduce) {
     const bool vec = !p.geglu && !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
                      (p.ld_rowbias & 3) == 0 && (p.ld_aux & 3) == 0;

@@ -399,7 +399,10 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
     if ((FL) & 4) {                                                                                                 \
       const float s1 = row16_sum(ok ? (v.x + v.y) + (v.z + v.w) : 0.f);                                             \
       const float s2 = row16_sum(ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f);                     \
-      if (ok && (tid & 15) == 0) p.stats[(long)row * p.stats_slots + (col >> 6)] = make_float2(s1, s2);             \
+      if (ok && (tid & 15) == 0) {                                                                                  \
+        p.stats[(long)row * p.stats_slots + (col >> 6)] = make_float2(s1, s2);                                      \
+        if (p.dup_rows) p.stats[(long)(row + p.dup_rows) * p.stats_slots + (col >> 6)] = make_float2(s1, s2);       \
+      }                                                                                                             \
     }                                                                                                               \
     if (ok) {                                                                                                       \
       const long idx = (long)batch * p.c_bs + (long)row * p.ldc + col;                                              \
@@ -409,6 +412,15 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;                                        \
       if (((FL) & 1) && p.aux)                                                                                      \
         *reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
+      if (p.dup_rows) {       /* CFG prefix: the other half of the batch gets the same row */                       \
+        const long idx2 = idx + (long)p.dup_rows * p.ldc;                                                           \
+        if (p.out_bf16)                                                                                             \
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx2) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
+        else                                                                                                        \
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx2) = v;                                     \
+        if (((FL) & 1) && p.aux)                                                                                    \
+          *reinterpret_cast<uint2*>(p.aux + (long)(row + p.dup_rows) * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
+      }                                                                                                             \
     }                                                                                                               \
   }
   if constexpr (EPI == EPI_PROD) DF_EPI_LOOP(5)
