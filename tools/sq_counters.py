@@ -30,6 +30,8 @@ def short(name):
 def load(d):
     files = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)
     rows = [r for f in files for r in csv.DictReader(open(f))]
+    if not rows:
+        raise SystemExit(f"no counter rows under {d} (files: {files})")
     byd = collections.defaultdict(dict)
     names = {}
     for r in rows:
@@ -80,6 +82,8 @@ def main():
             "waves_per_simd": 4 * wc / (32 * busy_a),
             "waves_per_launch": c.get("a:SQ_WAVES", 0.0) / max(cnt[k], 1),
         })
+    if not res:
+        raise SystemExit("no kernel carries SQ_BUSY_CYCLES: counters seen = %s" % sorted({k for c in agg.values() for k in c})[:20])
     res.sort(key=lambda r: -r["busy_us_per_step"])
     tot = sum(r["busy_us_per_step"] for r in res)
     fam = collections.defaultdict(lambda: [0.0, 0.0])

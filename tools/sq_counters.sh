@@ -4,15 +4,16 @@
 # usage (GPU box, repo root): tools/sq_counters.sh [outdir]  ->  <outdir>/sq_counters.json (copy to profiles/rN_sq_counters.json)
 ROOTD=$(pwd)
 OUT=${1:-$ROOTD/gpurun_out/sq}
+case $OUT in /*) ;; *) OUT=$ROOTD/$OUT ;; esac
 rm -rf $OUT; mkdir -p $OUT
 export DF_TUNE_CACHE=$OUT/tune_cache.txt
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-modes --no-vae"
 python bench.py $ARGS 2>/dev/null | tail -1 | cut -c1-160
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES \
-  --kernel-trace --output-format csv -d $OUT/a -o a -- python $ROOTD/bench.py $ARGS > /dev/null 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_VMEM \
-  --kernel-trace --output-format csv -d $OUT/b -o b -- python $ROOTD/bench.py $ARGS > /dev/null 2>&1
+  --kernel-trace --output-format csv -d $OUT/a -o a -- python $ROOTD/bench.py $ARGS > $OUT/a.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU \
+  --kernel-trace --output-format csv -d $OUT/b -o b -- python $ROOTD/bench.py $ARGS > $OUT/b.log 2>&1
 cd $ROOTD
-python tools/sq_counters.py $OUT $OUT/sq_counters.json
-rm -rf $OUT/a $OUT/b
+find $OUT -name '*counter_collection.csv' | head; tail -n 3 $OUT/a.log; tail -n 3 $OUT/b.log
+python tools/sq_counters.py $OUT $OUT/sq_counters.json && rm -rf $OUT/a $OUT/b
