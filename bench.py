@@ -80,6 +80,17 @@ def pmc_traffic():
         return None
 
 
+def sq_counters():
+    """MFMA-pipe busy fraction per kernel family from the SQ counters of this same command (tools/sq_counters.sh: two rocprofv3
+    --pmc passes; SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES)), read from the committed profile of the current round."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:
+            d = json.load(f)
+        return {k: round(v["mfma_busy"], 4) for k, v in d["families"].items() if v.get("mfma_busy") is not None}
+    except Exception:
+        return None
+
+
 def measured_peak():
     """MFMA issue peak measured on an MI355X by tools/peaks.py (profiles/peaks.json), next to the nominal one."""
     try:
@@ -316,7 +327,10 @@ def main():
                          "time_source": "HIP events around every op of the K steps on the launch stream, normalised so that the "
                                         "families sum to the un-instrumented ms_per_step (events add ~2 us per op)",
                          "traffic": pmc_traffic(), "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command; not measured in this run)",
-                         "peak_measured": measured_peak(), "peak_measured_source": "profiles/peaks.json (tools/peaks.py on an MI355X; not measured in this run)"},
+                         "peak_measured": measured_peak(), "peak_measured_source": "profiles/peaks.json (tools/peaks.py on an MI355X; not measured in this run)",
+                         "mfma_busy_pmc": sq_counters(), "mfma_busy_pmc_source": "profiles/sq_counters.json (SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES) per kernel "
+                                                                              "family over 4 denoise steps of this command; includes the matrix pipe's time on padded tiles, "
+                                                                              "so it sits above the algorithmic frac; not measured in this run)"},
             "north_star_families": None if not sub else {
                 "spatial_transformer": {"algorithmic_gflop_per_step": round(73.22 * N, 1), "ms_per_step": round(sub["st_ms"] * norm, 4),
                                         "launches_per_step": sub["st_launches"],

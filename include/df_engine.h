@@ -112,7 +112,8 @@ int df_unet_set_context(df_ctx* ctx, const float* context_dev, int N, int T, voi
 int df_unet_forward(df_ctx* ctx, const float* x_dev, const float* t_dev, float* eps_out_dev, int N, int H, int W,
                     void* stream);
 /* Classifier-free-guidance step of p_sample_ddim (ddim.py:241-245): runs the UNet on cat([x,x]) against the
- * 2B-row context set before ([uncond ; cond]) and returns e_u + scale*(e_c - e_u).  x, t, eps: B rows. */
+ * 2B-row context set before ([uncond ; cond]) and returns e_u + scale*(e_c - e_u).  x, t, eps: B rows.  The ops in front of
+ * the first cross-attention see identical rows in both halves and run on one half only (DF_NO_CFGDEDUP=1 disables). */
 int df_unet_forward_cfg(df_ctx* ctx, const float* x_dev, const float* t_dev, float* eps_out_dev, int B, int H, int W,
                         float guidance_scale, void* stream);
 

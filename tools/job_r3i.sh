@@ -1,0 +1,6 @@
+set -x
+mkdir -p gpurun_out/r3i
+bash tools/profile_round.sh > gpurun_out/r3i/profile_round.log 2>&1
+bash tools/sq_counters.sh gpurun_out/r3i/sq > gpurun_out/r3i/sq.log 2>&1
+python -m pytest tests/test_multi_rank_gpu.py -m gpu -q -s 2>&1 | grep -v "^$" | tail -6 > gpurun_out/r3i/two_rank_gpu_test.log
+DF_DIST_SHARE_GPU0=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 3 > gpurun_out/r3i/bench_2rank_shared_gpu.json 2> gpurun_out/r3i/bench_2rank.err
