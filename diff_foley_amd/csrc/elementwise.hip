@@ -987,28 +987,40 @@ __global__ __launch_bounds__(256) void out_conv_dot_kernel(const bf16_t* __restr
   float acc[PAIR ? 8 : 4];
 #pragma unroll
   for (int o = 0; o < (PAIR ? 8 : 4); ++o) acc[o] = 0.f;
-  for (int c = lane; c < nchunk; c += 64) {
+  // every lane owns up to MAXI 16-byte chunks of the 9 x C contraction; all their loads are issued before the first use
+  // (clamped address + select: no divergent branch around a load), so one memory round trip covers the whole pixel
+  constexpr int MAXI = 6;                                    // 9 C / 8 <= 384 chunks (launcher checks)
+  uint4 ua[MAXI], ub[MAXI];
+  int wofs[MAXI];
+  bool okc[MAXI];
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = lane + 64 * i;
     const int tap = c / c8n, ch = (c - tap * c8n) * 8;
     const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-    if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;         // zero padding
-    const long off = (((long)n * H + yy) * W + xx) * C + ch;
+    okc[i] = c < nchunk && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    const long off = okc[i] ? (((long)n * H + yy) * W + xx) * C + ch : 0;
+    wofs[i] = okc[i] ? tap * C + ch : 0;
+    ua[i] = *reinterpret_cast<const uint4*>(a + off);
+    if (PAIR) ub[i] = *reinterpret_cast<const uint4*>(a + off + (long)NB * HW * C);
+  }
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
     float av[PAIR ? 16 : 8];
     {
-      const uint4 u = *reinterpret_cast<const uint4*>(a + off);
-      const bf16_t* h = reinterpret_cast<const bf16_t*>(&u);
+      const bf16_t* h = reinterpret_cast<const bf16_t*>(&ua[i]);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) av[k] = bf2f(h[k]);
+      for (int k = 0; k < 8; ++k) av[k] = okc[i] ? bf2f(h[k]) : 0.f;
     }
     if (PAIR) {
-      const uint4 u = *reinterpret_cast<const uint4*>(a + off + (long)NB * HW * C);
-      const bf16_t* h = reinterpret_cast<const bf16_t*>(&u);
+      const bf16_t* h = reinterpret_cast<const bf16_t*>(&ub[i]);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) av[8 + k] = bf2f(h[k]);
+      for (int k = 0; k < 8; ++k) av[8 + k] = okc[i] ? bf2f(h[k]) : 0.f;
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-      const float4 w0 = *reinterpret_cast<const float4*>(&sw[o * K + tap * C + ch]);
-      const float4 w1 = *reinterpret_cast<const float4*>(&sw[o * K + tap * C + ch + 4]);
+      const float4 w0 = *reinterpret_cast<const float4*>(&sw[o * K + wofs[i]]);
+      const float4 w1 = *reinterpret_cast<const float4*>(&sw[o * K + wofs[i] + 4]);
       acc[o] += av[0] * w0.x + av[1] * w0.y + av[2] * w0.z + av[3] * w0.w + av[4] * w1.x + av[5] * w1.y + av[6] * w1.z + av[7] * w1.w;
       if (PAIR)
         acc[4 + o] += av[8] * w0.x + av[9] * w0.y + av[10] * w0.z + av[11] * w0.w + av[12] * w1.x + av[13] * w1.y + av[14] * w1.z +
@@ -1027,7 +1039,7 @@ __global__ __launch_bounds__(256) void out_conv_dot_kernel(const bf16_t* __restr
   }
 }
 
-bool out_conv_dot_supported(int C, int Cout) { return Cout == 4 && C % 8 == 0 && (size_t)36 * C * 4 <= 64 * 1024; }
+bool out_conv_dot_supported(int C, int Cout) { return Cout == 4 && C % 8 == 0 && 9 * C / 8 <= 384 && (size_t)36 * C * 4 <= 64 * 1024; }
 
 hipError_t launch_out_conv_dot(const uint16_t* a, const uint16_t* w, const float* bias, float* out, int NB, int H, int W, int C, int pair,
                                float scale, hipStream_t s) {

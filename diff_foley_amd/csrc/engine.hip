@@ -880,7 +880,8 @@ struct Builder {
         produces_t0(g);
         // nobody reads the fp32 residual stream after this op on the merged-FF path (FF1 and ffproj consume the operand
         // copy + row statistics, the block residual is x): the epilogue skips the fp32 store
-        if (!(getenv("DF_NO_FFPROJ") && atoi(getenv("DF_NO_FFPROJ"))) && C % 64 == 0) g.C = nullptr;
+        if (!(getenv("DF_NO_FFPROJ") && atoi(getenv("DF_NO_FFPROJ"))) && C % 64 == 0 && !(getenv("DF_XO_STORE") && atoi(getenv("DF_XO_STORE"))))
+          g.no_c_store = 1;
         g.bias = c->f32(nm(tb + ".attn2.to_out.0.bias"));
         g.res = t0; g.ldr = C;
         gemm(g, 1, "st.xo");
@@ -2217,6 +2218,11 @@ void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const
       c->prof_used += 2;
     }
     if (c->chk_on) checksum_after_op(c, pl, i, s);
+    static const bool trace = getenv("DF_TRACE_OPS") && atoi(getenv("DF_TRACE_OPS"));     // debug: name + sync every op
+    if (trace) {
+      fprintf(stderr, "[df] %s#%zu %s%s\n", pl->name.c_str(), i, o.tag, o.is_gemm ? (" tile " + std::to_string(o.tile) + " sk " + std::to_string(o.gp.splitk)).c_str() : "");
+      HIPCHK(hipStreamSynchronize(s));
+    }
   }
 }
 

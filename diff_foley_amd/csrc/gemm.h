@@ -61,6 +61,7 @@ struct GemmParams {
   // ops in front of it run on ONE half (M rows) and the op that feeds the full batch stores every output row twice, at
   // row and row + dup_rows (C / aux / stats alike).  0 = off.  Plain row-major epilogues only (LEAN / PROD / ANY, reduce).
   int dup_rows;
+  int no_c_store;   // PROD epilogue: skip the fp32 store of C (nobody reads it); operand copy + row statistics only
   int store_nchw; int hw_out;        // write C as [batch][N][hw_out] instead of [rows][ldc]
   int gm;      // tile walk: each XCD's contiguous tile range runs M-fastest inside row groups of `gm` M-tiles (0 = all rows:
                // plain M-fastest; 1 = N-fastest).  Decides which operand panels an XCD's L2 can share; autotuned in situ.

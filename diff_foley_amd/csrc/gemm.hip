@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
     for (int rep = 0; rep < (p.dup_rows ? 2 : 1); ++rep) {      // CFG prefix: every row is stored for both halves of the batch
       const long orow = row + (rep ? p.dup_rows : 0);
       const long idx = orow * p.ldc + col;
-      if (!p.C) {               // producer whose fp32 value nobody reads (operand copy + statistics only)
+      if (p.no_c_store) {       // producer whose fp32 value nobody reads (operand copy + statistics only)
       } else if (p.out_bf16)
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
       else

@@ -406,7 +406,7 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
     }                                                                                                               \
     if (ok) {                                                                                                       \
       const long idx = (long)batch * p.c_bs + (long)row * p.ldc + col;                                              \
-      if (((FL) & 4) && !p.C) {       /* producer whose fp32 value nobody reads: operand copy + statistics only */  \
+      if (((FL) & 4) && p.no_c_store) { /* producer whose fp32 value nobody reads: operand copy + statistics only */ \
       } else if (p.out_bf16)                                                                                        \
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
       else                                                                                                          \
@@ -415,7 +415,7 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
         *reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
       if (p.dup_rows) {       /* CFG prefix: the other half of the batch gets the same row */                       \
         const long idx2 = idx + (long)p.dup_rows * p.ldc;                                                           \
-        if (((FL) & 4) && !p.C) {                                                                                   \
+        if (((FL) & 4) && p.no_c_store) {                                                                            \
         } else if (p.out_bf16)                                                                                      \
           *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx2) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
         else                                                                                                        \
