@@ -964,94 +964,6 @@ hipError_t launch_pack_ln_linear(const float* w, const float* bias, const float*
   return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// UNet output conv (openai_unetmodel.py:682-686: conv3x3 320 -> 4 after GroupNorm + SiLU) as a dot-product kernel: a 4-column
-// "GEMM" wastes 15/16 of a 64-wide MFMA tile and needs split-K plus a scalar NCHW reduce; here one wavefront owns one output
-// pixel (of BOTH halves of a classifier-free-guidance batch), its 64 lanes split the 9 x C contraction in 16-byte chunks, the
-// fp32 weights sit in LDS, and the CFG combine e_u + scale (e_c - e_u) (ddim.py:241-245) happens before the one store.
-//   a    operand type [N][H][W][C] (N = 2B when pair != 0: rows [0, B) unconditional, [B, 2B) conditional)
-//   w    operand type [4][3][3][C],  bias fp32 [4],  out fp32 NCHW [B or N][4][H*W]
-template <int PAIR>
-__global__ __launch_bounds__(256) void out_conv_dot_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ out, int NB, int H,
-                                                           int W, int C, float scale) {
-  extern __shared__ float sw[];                              // [4][9 * C]
-  const int K = 9 * C, HW = H * W;
-  for (int i = threadIdx.x; i < 4 * K; i += 256) sw[i] = bf2f(w[i]);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const long pix = (long)blockIdx.x * 4 + wid;               // (sample, y, x) of the first half
-  if (pix >= (long)NB * HW) return;
-  const int n = (int)(pix / HW), rem = (int)(pix - (long)n * HW), y = rem / W, x = rem - y * W;
-  const int c8n = C >> 3, nchunk = 9 * c8n;
-  float acc[PAIR ? 8 : 4];
-#pragma unroll
-  for (int o = 0; o < (PAIR ? 8 : 4); ++o) acc[o] = 0.f;
-  // every lane owns up to MAXI 16-byte chunks of the 9 x C contraction; all their loads are issued before the first use
-  // (clamped address + select: no divergent branch around a load), so one memory round trip covers the whole pixel
-  constexpr int MAXI = 6;                                    // 9 C / 8 <= 384 chunks (launcher checks)
-  uint4 ua[MAXI], ub[MAXI];
-  int wofs[MAXI];
-  bool okc[MAXI];
-#pragma unroll
-  for (int i = 0; i < MAXI; ++i) {
-    const int c = lane + 64 * i;
-    const int tap = c / c8n, ch = (c - tap * c8n) * 8;
-    const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-    okc[i] = c < nchunk && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-    const long off = okc[i] ? (((long)n * H + yy) * W + xx) * C + ch : 0;
-    wofs[i] = okc[i] ? tap * C + ch : 0;
-    ua[i] = *reinterpret_cast<const uint4*>(a + off);
-    if (PAIR) ub[i] = *reinterpret_cast<const uint4*>(a + off + (long)NB * HW * C);
-  }
-#pragma unroll
-  for (int i = 0; i < MAXI; ++i) {
-    float av[PAIR ? 16 : 8];
-    {
-      const bf16_t* h = reinterpret_cast<const bf16_t*>(&ua[i]);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) av[k] = okc[i] ? bf2f(h[k]) : 0.f;
-    }
-    if (PAIR) {
-      const bf16_t* h = reinterpret_cast<const bf16_t*>(&ub[i]);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) av[8 + k] = okc[i] ? bf2f(h[k]) : 0.f;
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const float4 w0 = *reinterpret_cast<const float4*>(&sw[o * K + wofs[i]]);
-      const float4 w1 = *reinterpret_cast<const float4*>(&sw[o * K + wofs[i] + 4]);
-      acc[o] += av[0] * w0.x + av[1] * w0.y + av[2] * w0.z + av[3] * w0.w + av[4] * w1.x + av[5] * w1.y + av[6] * w1.z + av[7] * w1.w;
-      if (PAIR)
-        acc[4 + o] += av[8] * w0.x + av[9] * w0.y + av[10] * w0.z + av[11] * w0.w + av[12] * w1.x + av[13] * w1.y + av[14] * w1.z +
-                      av[15] * w1.w;
-    }
-  }
-#pragma unroll
-  for (int o = 0; o < (PAIR ? 8 : 4); ++o) acc[o] = wave_sum_dpp(acc[o]);
-  if (lane == 0) {
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      float v = acc[o] + bias[o];
-      if (PAIR) v += scale * (acc[4 + o] - acc[o]);
-      out[((long)n * 4 + o) * HW + rem] = v;
-    }
-  }
-}
-
-bool out_conv_dot_supported(int C, int Cout) { return Cout == 4 && C % 8 == 0 && 9 * C / 8 <= 384 && (size_t)36 * C * 4 <= 64 * 1024; }
-
-hipError_t launch_out_conv_dot(const uint16_t* a, const uint16_t* w, const float* bias, float* out, int NB, int H, int W, int C, int pair,
-                               float scale, hipStream_t s) {
-  if (!out_conv_dot_supported(C, 4)) return hipErrorInvalidValue;
-  const long pix = (long)NB * H * W;
-  const int blocks = (int)((pix + 3) / 4);
-  const size_t lds = (size_t)36 * C * 4;
-  if (pair) hipLaunchKernelGGL(out_conv_dot_kernel<1>, dim3(blocks), dim3(256), lds, s, a, w, bias, out, NB, H, W, C, scale);
-  else hipLaunchKernelGGL(out_conv_dot_kernel<0>, dim3(blocks), dim3(256), lds, s, a, w, bias, out, NB, H, W, C, scale);
-  return hipGetLastError();
-}
-
 hipError_t launch_cfg_combine(const float* e2, float* e, long n, float scale, hipStream_t s) {
   hipLaunchKernelGGL(cfg_combine_kernel, dim3(grid_for(n)), dim3(256), 0, s, e2, e, n, scale);
   return hipGetLastError();

@@ -1429,18 +1429,6 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
   }
   // ---- out: GN -> SiLU -> conv3x3 -> NCHW fp32 (openai_unetmodel.py:682-686)
   bf16_t* a = b.groupnorm(h, N, "out.0", 1e-5f, 1, nullptr);
-  static const bool no_outdot = getenv("DF_NO_OUTDOT") && atoi(getenv("DF_NO_OUTDOT"));
-  if (!no_outdot && out_conv_dot_supported(mc, u.out_channels)) {
-    // 4 output channels: a dot-product kernel (one wavefront per pixel) with the CFG combine fused, instead of a 64-wide MFMA
-    // tile + split-K + scalar NCHW reduce + cfg_combine (3 launches -> 1)
-    const bf16_t* wo = c->w_conv3(pre + "out.2.weight", mc);
-    const float* bo = c->f32(pre + "out.2.bias");
-    const int nb = cfg_mode ? N / 2 : N, pair = cfg_mode ? 1 : 0;
-    b.other("out.conv", [=](hipStream_t s, const RunArgs& ar) {
-      return launch_out_conv_dot(a, wo, bo, ar.out, nb, H, W, mc, pair, ar.scale, s);
-    });
-    return;
-  }
   GemmParams g = Builder::gp_conv3(a, N, H, W, mc, c->w_conv3(pre + "out.2.weight", mc), u.out_channels, 1, 0);
   g.bias = c->f32(pre + "out.2.bias");
   g.store_nchw = 1;
@@ -3282,11 +3270,6 @@ int df_test_conv3x3_ups4(const uint16_t* A, const float* W_oihw, const float* bi
     if (!gemm_tile_valid(g, tile, 1, splitk)) fail("tile %d / split-K %d refused this problem", tile, splitk);
     HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
   });
-}
-
-int df_test_out_conv(const uint16_t* A, const uint16_t* W, const float* bias, float* out, int NB, int H, int Wd, int C, int pair,
-                     float scale, void* stream) {
-  return guard([&] { HIPCHK(launch_out_conv_dot(A, W, bias, out, NB, H, Wd, C, pair, scale, (hipStream_t)stream)); });
 }
 
 int df_test_groupnorm(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,

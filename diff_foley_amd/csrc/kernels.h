@@ -90,12 +90,6 @@ hipError_t launch_pack_ffproj(const float* Wp, const float* bp, const float* W2,
 hipError_t launch_pack_geglu(const float* w, const float* b, uint16_t* wout, float* bout, int half_rows, int K,
                              hipStream_t s);
 
-// UNet output conv 3x3 (C -> 4 channels) as a dot-product kernel, NCHW fp32 out; pair != 0: a holds 2*NB samples ([uncond ; cond]) and
-// the classifier-free-guidance combine e_u + scale (e_c - e_u) is applied before the store (out: NB samples).
-bool out_conv_dot_supported(int C, int Cout);
-hipError_t launch_out_conv_dot(const uint16_t* a, const uint16_t* w, const float* bias, float* out, int NB, int H, int W, int C, int pair,
-                               float scale, hipStream_t s);
-
 // ---- sampler elementwise ops on fp32 latents -------------------------------------------------
 // e = e_u + scale * (e_c - e_u) for e2 = [e_u ; e_c] (each n elements)
 hipError_t launch_cfg_combine(const float* e2, float* e, long n, float scale, hipStream_t s);

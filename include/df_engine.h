@@ -235,10 +235,6 @@ int df_test_unet_block(df_ctx* ctx, const char* prefix, int kind, const float* x
                        const float* context_dev, float* out_dev, int N, int H, int W, int Cin, int Cout, int T, void* stream);
 int df_test_conv3x3(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, float* C_dev, int NB, int H,
                     int W, int Cin, int Cout, int stride, int ups, int tile, int splitk, void* stream);
-/* UNet output conv (C -> 4 channels, 3x3) as the dot-product kernel: A operand type [(pair ? 2 : 1) * NB][H][Wd][C], W operand type
- * [4][3][3][C], out fp32 NCHW [NB][4][H*Wd]; pair != 0 applies e_u + scale (e_c - e_u) between the two halves of A. */
-int df_test_out_conv(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, float* out_dev, int NB, int H, int Wd, int C,
-                     int pair, float scale, void* stream);
 /* nearest-x2 upsample + conv3x3 in the phase-decomposed form (four 2x2-tap convs on the input-resolution map, per-phase
  * weights = sums of the 3x3 taps): A [NB*H*Wd][Cin] operand type, W_oihw fp32 [Cout][Cin][3][3], w4_scratch 16*Cout*Cin
  * operand-type elements, C fp32 [NB*2H*2Wd][Cout]. */

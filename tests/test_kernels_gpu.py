@@ -405,22 +405,3 @@ def test_upsample_conv_phase_decomposed(tile, splitk, NB, H, W, Cin, Cout):
     packed = scratch.float().cpu().reshape(2, 2, Cout, 2, 2, Cin)
     assert torch.equal(packed, w4)                                           # the packing kernel, bit for bit
 
-
-@pytest.mark.parametrize("NB,H,W,C,pair", [(2, 16, 64, 320, 1), (3, 5, 7, 64, 0), (1, 8, 8, 128, 1), (4, 2, 8, 320, 0)])
-def test_out_conv_dot_kernel_with_cfg_combine(NB, H, W, C, pair):
-    """conv3x3 C -> 4 as one wavefront per pixel, fp32 accumulation, NCHW store; pair: e_u + s (e_c - e_u) fused (ddim.py:241-245)."""
-    E = _eng()
-    N = NB * (2 if pair else 1)
-    x = bf(rnd((N, C, H, W), 11))
-    w = bf(rnd((4, C, 3, 3), 12) / (3 * C ** 0.5))
-    b = rnd((4,), 13)
-    y = F.conv2d(x.float(), w.float(), b, padding=1)
-    ref = y[:NB] + 4.5 * (y[NB:] - y[:NB]) if pair else y
-    a = x.permute(0, 2, 3, 1).contiguous().cuda()
-    wp = w.permute(0, 2, 3, 1).contiguous().cuda()
-    bc = b.cuda()
-    out = torch.full((NB, 4, H * W), float("nan"), device="cuda")
-    rc = E.lib(PREC).df_test_out_conv(ptr(a), ptr(wp), ptr(bc), ptr(out), NB, H, W, C, pair, 4.5, stream())
-    assert rc == 0, E.lib(PREC).df_last_error()
-    torch.cuda.synchronize()
-    assert rel_l2(out.cpu().reshape(NB, 4, H, W), ref) < 2e-3
