@@ -2,7 +2,7 @@
 
 Every latent sample is independent for its whole trajectory, so the global batch is split
 contiguously over ranks and the step loop contains no collective.  The only exchange is at init: rank 0 packs the
-checkpoint ONCE into the engine's MFMA operand layouts and broadcasts that blob (``broadcast_packed_model``: 2.09 GB of
+checkpoint ONCE into the engine's MFMA operand layouts and broadcasts that blob (``broadcast_packed_model``: 2.15 GB of
 operand-type weights + the small fp32 tensors, RCCL over xGMI when the backend is "nccl"); the other ranks import it --
 no fp32 master copies and no re-packing there.  ``broadcast_state_dict`` (the flat fp32 checkpoint, 3.8 GB) remains for
 tensors that are not part of a LatentDiffusion (e.g. the classifier) and for the gloo CPU tests.

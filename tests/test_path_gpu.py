@@ -598,3 +598,41 @@ def test_plan_cache_is_bounded(P, monkeypatch):
     nmax = max(n for n, _ in sizes)
     assert nmax <= 32, sizes[-1]                      # the default bound (or the smaller one set above)
     assert sizes[-1][1] < 8 * (1 << 30)
+
+
+def test_debug_checksums_and_tune_cache_round_trip(P):
+    """Round-3 debug / distribution entry points: (i) the per-op workspace checksums of two identical runs are identical and
+    labelled op by op (df_debug_checksums: the tool that localised the ring race); (ii) the autotuner's choices exported as text
+    and imported again reproduce themselves (df_tune_cache_export / _import: what broadcast_packed_model ships to the ranks)."""
+    from diff_foley_amd import synth
+    m = P.LatentDiffusion(**P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
+    m.load_state_dict(synth.make_state_dict(synth.state_dict_spec(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY), 0))
+    m.cuda()
+    m.autotune(True)
+    feats = synth.synthetic_cavp(2, 32, 64, seed=1234).cuda()
+    xT = synth.synthetic_xT(2).cuda()
+
+    def run():
+        c = m.get_learned_conditioning(feats)
+        z, _ = m.sample_log_diff_sampler(c, 2, "DDIM", 3 + 1, unconditional_guidance_scale=4.5,
+                                         unconditional_conditioning=torch.zeros_like(c), x_T=xT)
+        return z
+
+    z0 = run()                                          # builds and tunes the plans
+    eng = m.engine
+    seqs = []
+    for _ in range(2):
+        eng.debug_checksums(True, 1 << 14)
+        z = run()
+        seqs.append(eng.debug_checksums_read())
+        assert torch.equal(z, z0)
+    eng.debug_checksums(False)
+    assert len(seqs[0]) > 100 and seqs[0] == seqs[1]
+    lab = eng.debug_checksum_label(len(seqs[0]) - 1)
+    assert "#" in lab and ":" in lab
+    text = eng.tune_cache_export()
+    assert text.count(b"\n") >= 10
+    eng.tune_cache_import(text)                         # idempotent
+    assert eng.tune_cache_export() == text
+    with pytest.raises(RuntimeError):
+        eng.tune_cache_import(b"bogus_key 999 1 0\n")   # tile id out of range
