@@ -626,10 +626,10 @@ def test_debug_checksums_and_tune_cache_round_trip(P):
         z = run()
         seqs.append(eng.debug_checksums_read())
         assert torch.equal(z, z0)
-    eng.debug_checksums(False)
     assert len(seqs[0]) > 100 and seqs[0] == seqs[1]
-    lab = eng.debug_checksum_label(len(seqs[0]) - 1)
+    lab = eng.debug_checksum_label(len(seqs[0]) - 1)     # labels live until the next debug_checksums() call
     assert "#" in lab and ":" in lab
+    eng.debug_checksums(False)
     text = eng.tune_cache_export()
     assert text.count(b"\n") >= 10
     eng.tune_cache_import(text)                         # idempotent
