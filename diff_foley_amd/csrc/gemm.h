@@ -80,11 +80,15 @@ enum GemmTile {
   // generic kernel, double-buffered (ring depth 2): less LDS -> 2-5 resident blocks per CU, for short-K layers
   TILE_128x128_S = 10, TILE_128x64_S = 11, TILE_64x128_S = 12, TILE_64x64_S = 13, TILE_32x128_S = 14,
   // halo kernels with an 8-deep weight ring: more weight bytes in flight per CU for the weight-streaming layers
-  TILE_HALO_128x64_D = 15, TILE_HALO_256x64_D = 16, TILE_ALL = 17
+  TILE_HALO_128x64_D = 15, TILE_HALO_256x64_D = 16,
+  // 192 output pixels (three 4x16 patches) x 64 couts, 4 wavefronts of 96x32: (8192, 320) becomes 43 x 5 = 215 blocks on 256 CUs
+  // where the 256x64 tile gives 160 (the model's channel counts are 5 * 2^k: power-of-two tiles leave 3/8 of the CUs idle)
+  TILE_HALO_192x64 = 17, TILE_ALL = 18
 };
 
 static inline bool gemm_tile_is_halo(int cfg) {
-  return (cfg >= TILE_HALO_128x64 && cfg <= TILE_HALO_128x128) || cfg == TILE_HALO_128x64_D || cfg == TILE_HALO_256x64_D;
+  return (cfg >= TILE_HALO_128x64 && cfg <= TILE_HALO_128x128) || cfg == TILE_HALO_128x64_D || cfg == TILE_HALO_256x64_D ||
+         cfg == TILE_HALO_192x64;
 }
 static inline int gemm_halo_ring(int cfg) { return (cfg == TILE_HALO_128x64_D || cfg == TILE_HALO_256x64_D) ? 8 : 4; }
 
@@ -92,7 +96,7 @@ static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
   static const int d[TILE_ALL][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
                                      {128, 64},  {256, 64}, {128, 128}, {128, 256}, {256, 128},
                                      {128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
-                                     {128, 64}, {256, 64}};
+                                     {128, 64}, {256, 64}, {192, 64}};
   *bm = d[cfg][0];
   *bn = d[cfg][1];
 }

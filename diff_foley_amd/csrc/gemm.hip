@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
 bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int nk = p.K / 64;
   if (p.taps == 4) {     // phase-decomposed upsample conv (MODE 3): a subset of the generic tiles, plain epilogues only
-    static const bool ok3[TILE_ALL] = {false, false, false, true, false, false, false, false, true, true, true, true, true, true, false, false, false};
+    static const bool ok3[TILE_ALL] = {false, false, false, true, false, false, false, false, true, true, true, true, true, true, false, false, false, false};
     if (tile < 0 || tile >= TILE_ALL || !ok3[tile] || batch > 1) return false;
     if (p.geglu || p.vt || p.ln_stats || p.stats || p.w_rows > 0 || p.sm_w > 0 || p.Cin2 > 0 || p.res || p.store_nchw) return false;
     if (splitk > 1 && (p.N & 3) != 0) return false;
@@ -142,7 +142,7 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
     if (p.vt && (splitk > 1 || batch > 1 || p.vt_col0 % bn_ != 0)) return false;   // transposed-V tiles are whole tiles
     if (p.ln_stats && (batch > 1 || (p.geglu && splitk > 1))) return false;
     if (p.ln_stats && splitk <= 1) {     // row partials: <= 5 float2 per thread, parked in LDS behind the ring
-      static const int nst[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0};
+      static const int nst[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0};
       const int threads = (tile == TILE_128x256 || tile == TILE_256x128) ? 512 : 256;
       const size_t ring = (size_t)(bm_ + bn_) * 128 * nst[tile], stage = (size_t)bm_ * (bn_ + 4) * 4 + (size_t)bm_ * 8;
       if (bm_ * p.ln_slots > 5 * threads) return false;

@@ -16,6 +16,7 @@ hipError_t launch_gemm_halo(int tile_cfg, int epi, const GemmParams& p, int zdim
     DF_H(TILE_HALO_128x128, 128, 128, 2, 2, 4)
     DF_H(TILE_HALO_128x64_D, 128, 64, 2, 2, 8)
     DF_H(TILE_HALO_256x64_D, 256, 64, 4, 2, 8)
+    DF_H(TILE_HALO_192x64, 192, 64, 2, 2, 4)
     default: return hipErrorInvalidValue;
   }
 #undef DF_H

@@ -37,6 +37,7 @@ bool halo_patch(int H, int W, int BM, int* th, int* tw) {
   if (w <= 0 || BM % w != 0) return false;
   int h = BM / w;
   if (h > H) h = H;
+  while (h > 1 && (H % h != 0 || BM % (h * w) != 0)) --h;     // tallest patch that tiles both the image and the block (192 rows: 3 x 4x16)
   if (h <= 0 || H % h != 0 || BM % (h * w) != 0) return false;
   *th = h;
   *tw = w;

@@ -45,8 +45,9 @@ def stream():
 
 
 TILES = [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13, 14]
-HALO = (5, 6, 7, 15, 16)
-_HALO_GEO = {5: (128, 64, 256, 4), 6: (256, 64, 512, 4), 7: (128, 128, 256, 4), 15: (128, 64, 256, 8), 16: (256, 64, 512, 8)}
+HALO = (5, 6, 7, 15, 16, 17)
+_HALO_GEO = {5: (128, 64, 256, 4), 6: (256, 64, 512, 4), 7: (128, 128, 256, 4), 15: (128, 64, 256, 8), 16: (256, 64, 512, 8),
+             17: (192, 64, 256, 4)}
 
 
 def _halo_fits(tile, H, W):
@@ -56,6 +57,8 @@ def _halo_fits(tile, H, W):
     if tw <= 0 or bm % tw:
         return False
     th = min(bm // tw, H)
+    while th > 1 and (H % th or bm % (th * tw)):      # tallest patch that tiles both the image and the block
+        th -= 1
     if th <= 0 or H % th or bm % (th * tw):
         return False
     rpp = threads // 8
@@ -123,7 +126,7 @@ def test_gemm_epilogue_times_splitk(tile, splitk, act, res, out_operand):
     assert rel_l2(c.float().cpu(), ref.cpu()) < (6e-3 if out_operand else 2e-3)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 3, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16])
+@pytest.mark.parametrize("tile", [0, 1, 3, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 17])
 @pytest.mark.parametrize("NB,H,W,Cin,Cout,stride,ups,splitk", [
     (2, 16, 64, 128, 96, 1, 0, 2), (8, 2, 8, 256, 64, 1, 0, 4), (3, 4, 16, 64, 192, 1, 0, 1), (1, 16, 16, 64, 64, 1, 0, 1),
     (2, 16, 64, 64, 64, 1, 0, 1), (2, 8, 32, 128, 192, 1, 0, 1), (1, 16, 64, 64, 64, 2, 0, 1),
