@@ -12,12 +12,22 @@ namespace {
 // Split-K input (GnSlabs::n > 0): x is the FIRST fp32 partial slab of the producing conv; the kernel sums the n slabs
 // (fixed order: deterministic) and adds the conv's bias and per-sample FiLM bias while loading -- the conv's reduce
 // launch and the fp32 round trip of its output disappear (the normalised operand is the only consumer of that tensor).
+// Split-K PRODUCER of x (GnSlabs::own != null, round 3): the tensor being normalised is itself the not-yet-reduced output of
+// the previous GEMM (a ResBlock's conv2 / a SpatialTransformer's merged FF2+proj_out, both followed by the next block's
+// GroupNorm).  Channels [0, c_own) of x are summed from the producer's slabs (leading dimension c_own) with its bias and
+// fp32 residual added in the reduce kernel's order -- bit-identical to the reduce launch this replaces -- and WRITTEN BACK
+// to x (later readers: the residual adds of this block); channels >= c_own (the skip half of a concat buffer) are read from x.
 struct GnSlabs {
   int n;
   long stride;                 // floats between consecutive slabs
   const float* bias;           // [C] or null
   const float* rowbias;        // [samples][ld_rowbias] or null
   int ld_rowbias;
+  const float* own;            // first slab of x's own producer, or null
+  int c_own;
+  const float* res;            // fp32 residual of the producer's epilogue, or null
+  int ldr;
+  float* hout;                 // == x (write-back of the reduced channels)
 };
 template <int PER>
 __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
@@ -32,31 +42,77 @@ __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW
   float2 v[PER];
   int px[PER], jj[PER];
   float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int i = threadIdx.x + k * blockDim.x;
-    const int ic = min(i, items - 1);
-    px[k] = ic / half;
-    jj[k] = ic - px[k] * half;
-    v[k] = *reinterpret_cast<const float2*>(xb + (long)px[k] * ld + 2 * jj[k]);
-  }
   if (sl.n > 0) {
-    for (int sidx = 1; sidx < sl.n; ++sidx) {
-#pragma unroll
-      for (int k = 0; k < PER; ++k) {
-        const float2 t = *reinterpret_cast<const float2*>(xb + sidx * sl.stride + (long)px[k] * ld + 2 * jj[k]);
-        v[k].x += t.x;
-        v[k].y += t.y;
-      }
-    }
+    // split-K input.  so[k] = element offset of item k inside ONE slab, or -1 when the item is read from x (the skip half of a
+    // concat buffer).  The slab loads are issued U slabs at a time (16 independent loads per thread in flight) and added in
+    // slab order, so the sum is bit-identical to the reduce kernel's and the latency chain is n / U long, not n.
+    const float* sbase = sl.own ? sl.own : x;
+    const int sld = sl.own ? sl.c_own : ld;
+    const int row0 = n * HW;
+    int so[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
+      const int i = threadIdx.x + k * blockDim.x;
+      const int ic = min(i, items - 1);
+      px[k] = ic / half;
+      jj[k] = ic - px[k] * half;
       const int c = g * cpg + 2 * jj[k];
-      float bx = 0.f, by = 0.f;
-      if (sl.bias) { bx = sl.bias[c]; by = sl.bias[c + 1]; }
-      if (sl.rowbias) { bx += sl.rowbias[(long)n * sl.ld_rowbias + c]; by += sl.rowbias[(long)n * sl.ld_rowbias + c + 1]; }
-      v[k].x += bx;
-      v[k].y += by;
+      so[k] = (!sl.own || c < sl.c_own) ? (row0 + px[k]) * sld + c : -1;
+      v[k] = (so[k] >= 0) ? *reinterpret_cast<const float2*>(sbase + so[k])
+                          : *reinterpret_cast<const float2*>(xb + (long)px[k] * ld + 2 * jj[k]);
+    }
+    constexpr int U = PER >= 16 ? 1 : 16 / PER;
+    for (int s0 = 1; s0 < sl.n; s0 += U) {
+      float2 t[U][PER];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float* sp = sbase + (long)min(s0 + u, sl.n - 1) * sl.stride;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) t[u][k] = *reinterpret_cast<const float2*>(sp + max(so[k], 0));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (s0 + u >= sl.n) break;
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+          if (so[k] >= 0) {
+            v[k].x += t[u][k].x;
+            v[k].y += t[u][k].y;
+          }
+      }
+    }
+    if (sl.own) {       // the producer's epilogue, in the reduce kernel's order: bias, residual; then x is written back
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        if (so[k] < 0) continue;
+        const int c = g * cpg + 2 * jj[k];
+        if (sl.bias) { v[k].x += sl.bias[c]; v[k].y += sl.bias[c + 1]; }
+        if (sl.res) {
+          const float2 r = *reinterpret_cast<const float2*>(sl.res + (long)(row0 + px[k]) * sl.ldr + c);
+          v[k].x += r.x;
+          v[k].y += r.y;
+        }
+        if (threadIdx.x + k * blockDim.x < items) *reinterpret_cast<float2*>(sl.hout + (long)(row0 + px[k]) * ld + c) = v[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int c = g * cpg + 2 * jj[k];
+        float bx = 0.f, by = 0.f;
+        if (sl.bias) { bx = sl.bias[c]; by = sl.bias[c + 1]; }
+        if (sl.rowbias) { bx += sl.rowbias[(long)n * sl.ld_rowbias + c]; by += sl.rowbias[(long)n * sl.ld_rowbias + c + 1]; }
+        v[k].x += bx;
+        v[k].y += by;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = threadIdx.x + k * blockDim.x;
+      const int ic = min(i, items - 1);
+      px[k] = ic / half;
+      jj[k] = ic - px[k] * half;
+      v[k] = *reinterpret_cast<const float2*>(xb + (long)px[k] * ld + 2 * jj[k]);
     }
   }
 #pragma unroll
@@ -642,13 +698,32 @@ hipError_t launch_groupnorm_chunked(const float* x, int ld, int N, int HW, int C
   return hipGetLastError();
 }
 
+static hipError_t launch_groupnorm_sl(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
+                                      float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, const GnSlabs& sl,
+                                      hipStream_t s);
+
 hipError_t launch_groupnorm_slabs(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
                                   float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, int nslab,
                                   long slab_stride, const float* bias, const float* rowbias, int ld_rowbias, hipStream_t s) {
+  GnSlabs sl{nslab, slab_stride, bias, rowbias, ld_rowbias, nullptr, 0, nullptr, 0, nullptr};
+  return launch_groupnorm_sl(x, ld, N, HW, C, gamma, beta, eps, silu, out, ldo, raw_out, sl, s);
+}
+
+hipError_t launch_groupnorm_own_slabs(float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,
+                                      int silu, uint16_t* out, int ldo, uint16_t* raw_out, const float* slab0, int nslab,
+                                      long slab_stride, int c_own, const float* bias, const float* res, int ldr, hipStream_t s) {
+  if (nslab < 2 || !slab0 || c_own <= 0 || c_own > C || (c_own & 1) || (ld & 1) || (ldr & 1)) return hipErrorInvalidValue;
+  GnSlabs sl{nslab, slab_stride, bias, nullptr, 0, slab0, c_own, res, ldr, x};
+  return launch_groupnorm_sl(x, ld, N, HW, C, gamma, beta, eps, silu, out, ldo, raw_out, sl, s);
+}
+
+static hipError_t launch_groupnorm_sl(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
+                                      float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, const GnSlabs& sl,
+                                      hipStream_t s) {
   if (C % 64 != 0) return hipErrorInvalidValue;
   const int cpg = C / 32;
   const long items = (long)HW * (cpg / 2);
-  GnSlabs sl{nslab, slab_stride, bias, rowbias, ld_rowbias};
+  const int nslab = sl.n;
   if (nslab > 0 && items > 16384) return hipErrorInvalidValue;     // the streaming kernel has no slab path
 #define DF_GN_REG(PER, THREADS)                                                                                     \
   hipLaunchKernelGGL(groupnorm_reg_kernel<PER>, dim3(32, N), dim3(THREADS), 0, s, x, ld, HW, C, cpg, gamma, beta, eps, \

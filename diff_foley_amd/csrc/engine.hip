@@ -115,8 +115,23 @@ struct Plan {
     owned.push_back({p, bytes});
     return p;
   }
+  // One buffer may be HELD: a release() of it is postponed until unhold() (Builder: the fp32 residual of a GEMM whose split-K
+  // reduce is handed to the next op must not be recycled for that op's own outputs).
+  const void* held = nullptr;
+  bool held_released = false;
+  void unhold() {
+    const void* h = held;
+    const bool rel = held_released;
+    held = nullptr;
+    held_released = false;
+    if (h && rel) release(const_cast<void*>(h));
+  }
   void release(void* p) {
     if (!p) return;
+    if (p == held) {
+      held_released = true;
+      return;
+    }
     for (auto& b : owned)
       if (b.p == p) {
         freelist.push_back(b);
@@ -474,7 +489,18 @@ struct Builder {
     return (T*)pl->alloc(n * sizeof(T));
   }
 
+  // The last emitted op, when it is a GEMM whose fp32 output could be left as split-K slabs for a GroupNorm that follows
+  // IMMEDIATELY (groupnorm() below claims it; any other emission forgets it).
+  struct Pend { long op = -1; const float* p = nullptr; int ld = 0, C = 0, rows = 0; };
+  Pend pend;
+
+  void forget_pend() {
+    pend = Pend{};
+    pl->unhold();
+  }
+
   void other(const char* tag, std::function<hipError_t(hipStream_t, const RunArgs&)> fn) {
+    forget_pend();
     Op o;
     o.fn = std::move(fn);
     o.tag = tag;
@@ -509,6 +535,14 @@ struct Builder {
     pl->gemm_flops += 2.0 * gp.M * (double)gp.N * gp.K * batch * (gp.taps == 4 ? 4 : 1);
     pl->weight_bytes += 2.0 * (double)gp.N * gp.K * (gp.w_bs ? batch : 1);
     pl->ops.push_back(std::move(o));
+    forget_pend();
+    if (batch == 1 && gp.C && !gp.out_bf16 && !gp.aux && !gp.dup_rows && !gp.stats && !gp.ln_stats && !gp.geglu && !gp.vt &&
+        !gp.rowbias && !gp.store_nchw && !gp.relu && !gp.silu && !gp.no_c_store && gp.alpha == 1.f && gp.taps != 4 &&
+        gp.sm_w == 0 && (gp.N & 3) == 0)
+    {
+      pend = Pend{(long)pl->ops.size() - 1, (const float*)gp.C, gp.ldc, gp.N, gp.M};
+      pl->held = gp.res;       // the claiming norm reads the residual while it writes its own (freshly allocated) outputs
+    }
     return pl->ops.back();
   }
 
@@ -562,6 +596,28 @@ struct Builder {
     const float* xp = x.p;
     const int ld = x.ld, HW = x.rows / NB, C = x.C;
     const size_t sb = groupnorm_scratch_bytes(NB, HW, C);
+    // x straight out of a GEMM that may run split-K (a ResBlock's conv2, a SpatialTransformer's merged FF2 + proj_out, a
+    // Downsample conv): this norm is its first reader, so it does the reduce -- sums the slabs, adds bias + residual, writes
+    // x back -- in the launch it needs anyway; the producer's reduce launch and one fp32 round trip of x disappear.
+    static const bool no_own = getenv("DF_NO_GNOWN") && atoi(getenv("DF_NO_GNOWN"));
+    Pend pd = pend;
+    if (const char* only = getenv("DF_GNOWN_ONLY"))      // debugging: restrict the hand-over to producers of one tag
+      if (pd.op >= 0 && !strstr(pl->ops[pd.op].tag, only)) pd = Pend{};
+    if (!no_own && !sb && pd.op >= 0 && pd.p == xp && pd.ld == ld && pd.rows == x.rows && pd.C <= C && (pd.C & 1) == 0 &&
+        (ld & 1) == 0 && groupnorm_accepts_slabs(HW, C)) {
+      Plan* plp = pl;
+      const size_t pi = (size_t)pd.op;
+      pl->ops[pi].defer = true;
+      float* xw = x.p;
+      other("groupnorm", [=](hipStream_t s, const RunArgs&) {
+        const Op& po = plp->ops[pi];
+        if (po.defer && po.gp.splitk > 1)
+          return launch_groupnorm_own_slabs(xw, ld, NB, HW, C, g, b, eps, silu, o, C, r, po.gp.partial, po.gp.splitk,
+                                            (long)po.gp.M * po.gp.N, po.gp.N, po.gp.bias, po.gp.res, po.gp.ldr, s);
+        return launch_groupnorm(xp, ld, NB, HW, C, g, b, eps, silu, o, C, r, s);
+      });
+      return o;
+    }
     if (sb) {          // large slabs (VAE decoder): pixel-chunked, fully coalesced three-launch form
       float* scr = (float*)pl->alloc(sb);
       other("groupnorm", [=](hipStream_t s, const RunArgs&) {
@@ -3282,6 +3338,15 @@ int df_test_groupnorm(const float* x, int ld, int N, int HW, int C, const float*
     } else {
       HIPCHK(launch_groupnorm(x, ld, N, HW, C, gamma, beta, eps, silu, out, C, nullptr, (hipStream_t)stream));
     }
+  });
+}
+int df_test_groupnorm_own_slabs(float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps, int silu,
+                                uint16_t* out, const float* slabs, int nslab, int c_own, const float* bias, const float* res,
+                                int ldr, void* stream) {
+  return guard([&] {
+    if (!groupnorm_accepts_slabs(HW, C)) fail("groupnorm: %d x %d slab does not fit the register kernel", HW, C);
+    HIPCHK(launch_groupnorm_own_slabs(x, ld, N, HW, C, gamma, beta, eps, silu, out, C, nullptr, slabs, nslab,
+                                      (long)N * HW * c_own, c_own, bias, res, ldr, (hipStream_t)stream));
   });
 }
 int df_test_layernorm(const float* x, int rows, int C, const float* gamma, const float* beta, uint16_t* out, void* stream) {

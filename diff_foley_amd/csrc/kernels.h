@@ -14,6 +14,12 @@ hipError_t launch_groupnorm_slabs(const float* x, int ld, int N, int HW, int C, 
                                   float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, int nslab,
                                   long slab_stride, const float* bias, const float* rowbias, int ld_rowbias, hipStream_t s);
 bool groupnorm_accepts_slabs(int HW, int C);
+// x is the NOT-YET-REDUCED output of its own split-K producer: channels [0, c_own) are summed from nslab slabs (leading
+// dimension c_own), bias and the fp32 residual `res` are added in the reduce kernel's order and the result is written back
+// to x before it is normalised; channels [c_own, C) are read from x (the skip half of a concat buffer).
+hipError_t launch_groupnorm_own_slabs(float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,
+                                      int silu, uint16_t* out, int ldo, uint16_t* raw_out, const float* slab0, int nslab,
+                                      long slab_stride, int c_own, const float* bias, const float* res, int ldr, hipStream_t s);
 
 // Large slabs (VAE decoder, C in {128, 256, 512}, more than 16384 float2 per group): pixel-chunked three-launch form with
 // fully coalesced rows; `scratch` holds groupnorm_scratch_bytes(N, HW, C) bytes (0 = shape not handled: use launch_groupnorm).

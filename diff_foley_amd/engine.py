@@ -105,6 +105,8 @@ _SIGS = {
                              C.c_int, C.c_int, C.c_void_p],
     "df_test_groupnorm": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
                           C.c_void_p, C.c_void_p],
+    "df_test_groupnorm_own_slabs": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "df_test_layernorm": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "df_test_attention": [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],

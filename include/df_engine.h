@@ -242,6 +242,12 @@ int df_test_conv3x3_ups4(const uint16_t* A_dev, const float* W_oihw_dev, const f
                          int NB, int H, int Wd, int Cin, int Cout, int tile, int splitk, void* stream);
 int df_test_groupnorm(const float* x_dev, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,
                       int silu, uint16_t* out_dev, void* stream);
+/* GroupNorm whose input is the not-yet-reduced output of its own split-K producer: channels [0, c_own) of x are summed from
+ * `nslab` fp32 slabs [N*HW][c_own] (consecutive), + bias[c_own] + res[N*HW][ldr] (either may be NULL), written back to x and
+ * normalised together with channels [c_own, C) read from x. */
+int df_test_groupnorm_own_slabs(float* x_dev, int ld, int N, int HW, int C, const float* gamma, const float* beta, float eps,
+                                int silu, uint16_t* out_dev, const float* slabs_dev, int nslab, int c_own,
+                                const float* bias_dev, const float* res_dev, int ldr, void* stream);
 int df_test_layernorm(const float* x_dev, int rows, int C, const float* gamma, const float* beta, uint16_t* out_dev,
                       void* stream);
 int df_test_attention(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt, uint16_t* O,

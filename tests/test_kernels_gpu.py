@@ -175,6 +175,39 @@ def test_groupnorm(N, HW, C, silu, eps):
     assert rel_l2(out.float().cpu().permute(0, 2, 1), ref) < 4e-3     # bf16 output rounding
 
 
+@pytest.mark.parametrize("N,HW,C,c_own,nslab,silu", [(2, 1024, 320, 320, 2, 1), (2, 16, 1280, 1280, 8, 1), (1, 256, 960, 640, 4, 1),
+                                                     (3, 64, 2560, 1280, 32, 0), (2, 1024, 640, 320, 3, 1)])
+def test_groupnorm_finishes_its_producers_split_k(N, HW, C, c_own, nslab, silu):
+    """The norm that follows a split-K GEMM does that GEMM's reduce (csrc/elementwise.hip GnSlabs::own): channels [0, c_own) of
+    x = sum of the slabs (slab order) + bias + residual, BIT-equal to the same fp32 additions done one after the other, written
+    back to x; channels [c_own, C) (the skip half of a concat buffer, 960 = 640 + 320 puts group 21 across the boundary) come
+    from x; the normalised operand matches torch's group_norm of the finished tensor."""
+    E = _eng()
+    rows = N * HW
+    slabs = rnd((nslab, rows, c_own), 61) * 0.7
+    bias, res = rnd((c_own,), 62), rnd((rows, c_own + 8), 63)
+    x0 = rnd((rows, C), 64) * 2 + 0.5
+    g, b = rnd((C,), 65), rnd((C,), 66)
+    fin = slabs[0].clone()
+    for s_ in range(1, nslab):
+        fin += slabs[s_]
+    fin = fin + bias
+    fin = fin + res[:, :c_own]
+    full = x0.clone()
+    full[:, :c_own] = fin
+    ref = F.group_norm(full.reshape(N, HW, C).permute(0, 2, 1), 32, g, b, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    xc, sc, bc, rc_, gc, btc = x0.cuda(), slabs.cuda(), bias.cuda(), res.cuda(), g.cuda(), b.cuda()
+    out = torch.empty(N, HW, C, dtype=odt(), device="cuda")
+    rc = E.lib(PREC).df_test_groupnorm_own_slabs(ptr(xc), C, N, HW, C, ptr(gc), ptr(btc), 1e-5, silu, ptr(out), ptr(sc), nslab, c_own,
+                                                 ptr(bc), ptr(rc_), c_own + 8, stream())
+    assert rc == 0, E.lib(PREC).df_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(xc.cpu(), full)
+    assert rel_l2(out.float().cpu().permute(0, 2, 1), ref) < 4e-3
+
+
 @pytest.mark.parametrize("rows,C", [(1024, 320), (77, 640), (16, 1280), (128, 64), (8192, 320), (3, 128), (5, 256),
                                     (7, 512), (513, 1280)])
 def test_layernorm(rows, C):
