@@ -2439,6 +2439,13 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
     }
   }
   apply(-1);
+  if (getenv("DF_TUNE_LOG") && atoi(getenv("DF_TUNE_LOG"))) {      // tools: the candidates of every GEMM class, both stages
+    for (auto& kv : cands) {
+      fprintf(stderr, "[df tune] %s:", kv.first.c_str());
+      for (auto& cd : kv.second) fprintf(stderr, "  t%d/sk%d iso %.1f situ %.1f", cd.tile, cd.sk, cd.iso_ms * 1e3 / 3, cd.situ_ms * 1e3);
+      fprintf(stderr, "\n");
+    }
+  }
   // stage 3: tile walk order of the chosen tile (GemmParams::gm), again timed inside the plan
   static const bool tune_walk = !(getenv("DF_TUNE_WALK") && atoi(getenv("DF_TUNE_WALK")) == 0);
   if (tune_walk) {
