@@ -99,3 +99,14 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   for (int i = 0; i < nw; ++i) t += red[i];
   return t;
 }
+// The same with the in-wave steps as DPP adds (wave_sum_dpp): 2 LDS-pipe exchanges per wavefront instead of 6.
+__device__ __forceinline__ float block_sum_dpp(float v, float* red) {
+  v = wave_sum_dpp(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}

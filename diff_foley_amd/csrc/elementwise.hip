@@ -1,4 +1,5 @@
 // Normalisation, small linears, packing and sampler-update kernels (gfx950).  All HBM/L2-bound.
+#include <algorithm>
 #include "common.h"
 #include "kernels.h"
 
@@ -29,120 +30,111 @@ struct GnSlabs {
   int ldr;
   float* hout;                 // == x (write-back of the reduced channels)
 };
+// Thread layout (round 3): thread = (row ty, channel pair tx) with blockDim.x = roundup64(half * R): a thread keeps ONE channel
+// pair for all of its PER items (rows ty + k * R), so gamma / beta / bias are loaded once, addresses are affine in k and no
+// per-item division or index array exists (the round-2 kernel indexed items linearly: 25 VALU instructions of integer division
+// per item and, at PER = 16, scratch spills -- the norm was VALU-bound, its time proportional to the element count).
 template <int PER>
 __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                     int silu, bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw, GnSlabs sl) {
+                                     int silu, bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw, GnSlabs sl, int R) {
   __shared__ float red[16];
   // block b runs on XCD b%8: put the 4 neighbouring groups that share 128-B lines of every pixel row on one XCD
   const int g = (blockIdx.x & 7) * 4 + (blockIdx.x >> 3), n = blockIdx.y;
-  const float* xb = x + (long)n * HW * ld + g * cpg;
   const int half = cpg >> 1;
-  const int items = HW * half;
+  const int ty = threadIdx.x / half, tx = threadIdx.x - ty * half;
+  const bool act = ty < R;                       // the last wavefront may carry idle threads
+  const int c = g * cpg + 2 * tx;
+  const long row0 = (long)n * HW;
   float2 v[PER];
-  int px[PER], jj[PER];
-  float s = 0.f;
-  if (sl.n > 0) {
-    // split-K input.  so[k] = element offset of item k inside ONE slab, or -1 when the item is read from x (the skip half of a
-    // concat buffer).  The slab loads are issued U slabs at a time (16 independent loads per thread in flight) and added in
-    // slab order, so the sum is bit-identical to the reduce kernel's and the latency chain is n / U long, not n.
-    const float* sbase = sl.own ? sl.own : x;
+  // clamped row of item k (loads are unconditional); element offsets fit 32 bits (one tensor / slab < 2^31 elements)
+#define DF_ROW(k) min(ty + (k) * R, HW - 1)
+  const bool from_slabs = sl.n > 0 && (!sl.own || c < sl.c_own);
+  if (from_slabs) {
+    // split-K input: the slab loads are issued U slabs at a time (16 independent loads per thread in flight) and added in slab
+    // order, so the sum is bit-identical to the reduce kernel's and the latency chain is n / U long, not n
     const int sld = sl.own ? sl.c_own : ld;
-    const int row0 = n * HW;
-    int so[PER];
+    const float* p0 = (sl.own ? sl.own : x) + row0 * sld + c;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int i = threadIdx.x + k * blockDim.x;
-      const int ic = min(i, items - 1);
-      px[k] = ic / half;
-      jj[k] = ic - px[k] * half;
-      const int c = g * cpg + 2 * jj[k];
-      so[k] = (!sl.own || c < sl.c_own) ? (row0 + px[k]) * sld + c : -1;
-      v[k] = (so[k] >= 0) ? *reinterpret_cast<const float2*>(sbase + so[k])
-                          : *reinterpret_cast<const float2*>(xb + (long)px[k] * ld + 2 * jj[k]);
-    }
+    for (int k = 0; k < PER; ++k) v[k] = *reinterpret_cast<const float2*>(p0 + DF_ROW(k) * sld);
     constexpr int U = PER >= 16 ? 1 : 16 / PER;
     for (int s0 = 1; s0 < sl.n; s0 += U) {
       float2 t[U][PER];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const float* sp = sbase + (long)min(s0 + u, sl.n - 1) * sl.stride;
+        const float* sp = p0 + (long)min(s0 + u, sl.n - 1) * sl.stride;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) t[u][k] = *reinterpret_cast<const float2*>(sp + max(so[k], 0));
+        for (int k = 0; k < PER; ++k) t[u][k] = *reinterpret_cast<const float2*>(sp + DF_ROW(k) * sld);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (s0 + u >= sl.n) break;
+        if (s0 + u < sl.n) {
 #pragma unroll
-        for (int k = 0; k < PER; ++k)
-          if (so[k] >= 0) {
+          for (int k = 0; k < PER; ++k) {
             v[k].x += t[u][k].x;
             v[k].y += t[u][k].y;
           }
-      }
-    }
-    if (sl.own) {       // the producer's epilogue, in the reduce kernel's order: bias, residual; then x is written back
-#pragma unroll
-      for (int k = 0; k < PER; ++k) {
-        if (so[k] < 0) continue;
-        const int c = g * cpg + 2 * jj[k];
-        if (sl.bias) { v[k].x += sl.bias[c]; v[k].y += sl.bias[c + 1]; }
-        if (sl.res) {
-          const float2 r = *reinterpret_cast<const float2*>(sl.res + (long)(row0 + px[k]) * sl.ldr + c);
-          v[k].x += r.x;
-          v[k].y += r.y;
         }
-        if (threadIdx.x + k * blockDim.x < items) *reinterpret_cast<float2*>(sl.hout + (long)(row0 + px[k]) * ld + c) = v[k];
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < PER; ++k) {
-        const int c = g * cpg + 2 * jj[k];
-        float bx = 0.f, by = 0.f;
-        if (sl.bias) { bx = sl.bias[c]; by = sl.bias[c + 1]; }
-        if (sl.rowbias) { bx += sl.rowbias[(long)n * sl.ld_rowbias + c]; by += sl.rowbias[(long)n * sl.ld_rowbias + c + 1]; }
-        v[k].x += bx;
-        v[k].y += by;
       }
     }
-  } else {
+    float bx = 0.f, by = 0.f;
+    if (sl.bias) { bx = sl.bias[c]; by = sl.bias[c + 1]; }
+    if (sl.rowbias) { bx += sl.rowbias[(long)n * sl.ld_rowbias + c]; by += sl.rowbias[(long)n * sl.ld_rowbias + c + 1]; }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int i = threadIdx.x + k * blockDim.x;
-      const int ic = min(i, items - 1);
-      px[k] = ic / half;
-      jj[k] = ic - px[k] * half;
-      v[k] = *reinterpret_cast<const float2*>(xb + (long)px[k] * ld + 2 * jj[k]);
+      v[k].x += bx;
+      v[k].y += by;
     }
+    if (sl.own) {       // the producer's epilogue in the reduce kernel's order (bias, then residual); x is written back
+      if (sl.res) {
+        float2 r[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) r[k] = *reinterpret_cast<const float2*>(sl.res + row0 * sl.ldr + c + DF_ROW(k) * sl.ldr);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+          v[k].x += r[k].x;
+          v[k].y += r[k].y;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < PER; ++k)
+        if (act && ty + k * R < HW) *reinterpret_cast<float2*>(sl.hout + row0 * ld + c + DF_ROW(k) * ld) = v[k];
+    }
+  } else {
+    const float* p0 = x + row0 * ld + c;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] = *reinterpret_cast<const float2*>(p0 + DF_ROW(k) * ld);
   }
+  float s = 0.f;
 #pragma unroll
   for (int k = 0; k < PER; ++k)
-    if (threadIdx.x + k * blockDim.x < items) s += v[k].x + v[k].y;
+    if (act && ty + k * R < HW) s += v[k].x + v[k].y;
   const float cnt = (float)HW * (float)cpg;
-  const float mean = block_sum(s, red) / cnt;
+  const float mean = block_sum_dpp(s, red) / cnt;
   float q = 0.f;
 #pragma unroll
   for (int k = 0; k < PER; ++k)
-    if (threadIdx.x + k * blockDim.x < items) {
+    if (act && ty + k * R < HW) {
       const float a = v[k].x - mean, b = v[k].y - mean;
       q += a * a + b * b;
     }
-  const float rstd = rsqrtf(block_sum(q, red) / cnt + eps);
-  bf16_t* ob = out + (long)n * HW * ldo + g * cpg;
-  bf16_t* rb = raw ? raw + (long)n * HW * ldo + g * cpg : nullptr;
+  const float rstd = rsqrtf(block_sum_dpp(q, red) / cnt + eps);
+  const float sc0 = rstd * gamma[c], sc1 = rstd * gamma[c + 1], sh0 = beta[c], sh1 = beta[c + 1];
+  bf16_t* ob = out + row0 * ldo + c;
+  bf16_t* rb = raw ? raw + row0 * ldo + c : nullptr;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    if (threadIdx.x + k * blockDim.x >= items) continue;
-    const int c = g * cpg + 2 * jj[k];
-    float a = (v[k].x - mean) * rstd * gamma[c] + beta[c];
-    float b = (v[k].y - mean) * rstd * gamma[c + 1] + beta[c + 1];
+    if (!act || ty + k * R >= HW) continue;
+    float a = (v[k].x - mean) * sc0 + sh0;
+    float b = (v[k].y - mean) * sc1 + sh1;
     if (silu) {
       a = silu_f(a);
       b = silu_f(b);
     }
-    *reinterpret_cast<uint32_t*>(ob + (long)px[k] * ldo + 2 * jj[k]) = pack_bf2(a, b);
-    if (rb) *reinterpret_cast<uint32_t*>(rb + (long)px[k] * ldo + 2 * jj[k]) = pack_bf2(v[k].x, v[k].y);
+    *reinterpret_cast<uint32_t*>(ob + DF_ROW(k) * ldo) = pack_bf2(a, b);
+    if (rb) *reinterpret_cast<uint32_t*>(rb + DF_ROW(k) * ldo) = pack_bf2(v[k].x, v[k].y);
   }
+#undef DF_ROW
 }
 
 __global__ void groupnorm_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
@@ -675,7 +667,11 @@ inline int grid_for(long n, int block = 256, int cap = 4096) {
 
 }  // namespace
 
-bool groupnorm_accepts_slabs(int HW, int C) { return C % 64 == 0 && (long)HW * (C / 64) <= 16384; }
+bool groupnorm_accepts_slabs(int HW, int C) {      // shapes the register kernel takes (launch_groupnorm_sl)
+  if (C % 64 != 0 || (long)HW * (C / 64) > 16384) return false;
+  const int half = C / 64, rmax = std::min(HW, 1024 / half);
+  return rmax > 0 && (HW + rmax - 1) / rmax <= 20;
+}
 
 size_t groupnorm_scratch_bytes(int N, int HW, int C) {
   const long items = (long)HW * (C / 64);
@@ -725,19 +721,30 @@ static hipError_t launch_groupnorm_sl(const float* x, int ld, int N, int HW, int
   const long items = (long)HW * (cpg / 2);
   const int nslab = sl.n;
   if (nslab > 0 && items > 16384) return hipErrorInvalidValue;     // the streaming kernel has no slab path
-#define DF_GN_REG(PER, THREADS)                                                                                     \
-  hipLaunchKernelGGL(groupnorm_reg_kernel<PER>, dim3(32, N), dim3(THREADS), 0, s, x, ld, HW, C, cpg, gamma, beta, eps, \
-                     silu, out, ldo, raw_out, sl)
-  if (items <= 256) DF_GN_REG(1, 256);
-  else if (items <= 512) DF_GN_REG(2, 256);
-  else if (items <= 1024) DF_GN_REG(2, 512);
-  else if (items <= 2048) DF_GN_REG(2, 1024);
-  else if (items <= 4096) DF_GN_REG(4, 1024);
-  else if (items <= 8192) DF_GN_REG(8, 1024);
-  else if (items <= 16384) DF_GN_REG(16, 1024);
-  else
+  // thread layout of groupnorm_reg_kernel: R rows per pass x (cpg / 2) channel pairs, PER passes
+  const int half = cpg / 2;
+  const int rmax = std::min(HW, 1024 / std::max(half, 1));
+  const int need = rmax > 0 ? (HW + rmax - 1) / rmax : 1 << 30;
+#define DF_GN_REG(PER)                                                                                                \
+  {                                                                                                                   \
+    const int R = (HW + (PER) - 1) / (PER);                                                                           \
+    const int threads = (half * R + 63) & ~63;                                                                        \
+    hipLaunchKernelGGL(groupnorm_reg_kernel<PER>, dim3(32, N), dim3(threads), 0, s, x, ld, HW, C, cpg, gamma, beta, eps, \
+                       silu, out, ldo, raw_out, sl, R);                                                               \
+  }
+  if (items > 16384 || need > 20 || half < 1) {
+    if (nslab > 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(groupnorm_kernel, dim3(32, N), dim3(1024), 0, s, x, ld, HW, C, cpg, gamma, beta, eps, silu, out,
                        ldo, raw_out);
+  } else if (need <= 1) DF_GN_REG(1)
+  else if (need <= 2) DF_GN_REG(2)
+  else if (need <= 3) DF_GN_REG(3)
+  else if (need <= 4) DF_GN_REG(4)
+  else if (need <= 6) DF_GN_REG(6)
+  else if (need <= 8) DF_GN_REG(8)
+  else if (need <= 12) DF_GN_REG(12)
+  else if (need <= 16) DF_GN_REG(16)
+  else DF_GN_REG(20)
 #undef DF_GN_REG
   return hipGetLastError();
 }
