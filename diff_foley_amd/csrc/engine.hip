@@ -3320,6 +3320,22 @@ int df_test_conv3x3(const uint16_t* A, const uint16_t* W, const float* bias, flo
   });
 }
 
+int df_test_conv3x3_skip(const uint16_t* A, const uint16_t* A2, const uint16_t* W, const float* bias, float* C, int NB, int H,
+                         int Wd, int Cin, int Cin2, int Cout, int tile, int splitk, void* stream) {
+  return guard([&] {
+    GemmParams g = Builder::gp_conv3(A, NB, H, Wd, Cin, W, Cout, 1, 0);
+    Builder::out_f32(g, C, Cout);
+    g.bias = bias;
+    g.A2 = A2; g.lda2 = Cin2; g.Cin2 = Cin2; g.a2_bytes = Builder::op_bytes((size_t)g.M * Cin2 * 2);
+    g.K = 9 * Cin + Cin2;
+    g.w_bytes = Builder::op_bytes((size_t)Cout * g.K * 2);
+    g.splitk = splitk;
+    if (splitk > 1) g.partial = test_partial((size_t)splitk * g.M * g.N * 4);
+    if (!gemm_tile_valid(g, tile, 1, splitk)) fail("tile %d / split-K %d refused this problem", tile, splitk);
+    HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
+  });
+}
+
 // Upsample + conv3x3 through the phase-decomposed form (gemm_m3.hip): W_oihw fp32 [Cout][Cin][3][3] is packed here.
 int df_test_conv3x3_ups4(const uint16_t* A, const float* W_oihw, const float* bias, float* C, uint16_t* w4_scratch, int NB, int H,
                          int Wd, int Cin, int Cout, int tile, int splitk, void* stream) {

@@ -165,7 +165,7 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   if (splitk > 1 && (p.N & 3) != 0) return false;
   if (p.dup_rows > 0 && (p.store_nchw || (p.N & 3) != 0 || (p.ldc & 3) != 0 || (p.ldr & 3) != 0 || (p.ld_rowbias & 3) != 0 || (p.ld_aux & 3) != 0))
     return false;
-  if (p.Cin2 > 0) return false;                 // the folded skip connection exists in the generic stride-1 kernel only
+  if (p.Cin2 > 0) return false;                 // the folded skip connection exists in the generic stride-1 kernel only (a halo-kernel tail was measured slower: DESIGN.md section 7)
   if (p.taps != 9 || p.stride != 1 || p.ups != 0 || p.geglu || batch > 1) return false;
   int bm, bn, th, tw;
   gemm_tile_dims(tile, &bm, &bn);

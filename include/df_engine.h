@@ -235,6 +235,10 @@ int df_test_unet_block(df_ctx* ctx, const char* prefix, int kind, const float* x
                        const float* context_dev, float* out_dev, int N, int H, int W, int Cin, int Cout, int T, void* stream);
 int df_test_conv3x3(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, float* C_dev, int NB, int H,
                     int W, int Cin, int Cout, int stride, int ups, int tile, int splitk, void* stream);
+/* conv3x3 (stride 1) with a folded 1x1 skip connection: C = conv3x3(A; W[:, :9 Cin]) + A2 . W[:, 9 Cin:]^T + bias, one implicit GEMM
+ * with K = 9 Cin + Cin2 (A [NB*H*Wd][Cin], A2 [NB*H*Wd][Cin2], W [Cout][9 Cin + Cin2] operand type; Cin, Cin2 multiples of 64). */
+int df_test_conv3x3_skip(const uint16_t* A_dev, const uint16_t* A2_dev, const uint16_t* W_dev, const float* bias_dev, float* C_dev,
+                         int NB, int H, int W, int Cin, int Cin2, int Cout, int tile, int splitk, void* stream);
 /* nearest-x2 upsample + conv3x3 in the phase-decomposed form (four 2x2-tap convs on the input-resolution map, per-phase
  * weights = sums of the 3x3 taps): A [NB*H*Wd][Cin] operand type, W_oihw fp32 [Cout][Cin][3][3], w4_scratch 16*Cout*Cin
  * operand-type elements, C fp32 [NB*2H*2Wd][Cout]. */

@@ -157,6 +157,34 @@ def test_conv3x3(tile, NB, H, W, Cin, Cout, stride, ups, splitk):
     assert rel_l2(got, ref) < 2e-3
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 17])
+@pytest.mark.parametrize("NB,H,W,Cin,Cin2,Cout,splitk", [
+    (2, 16, 64, 128, 192, 96, 1), (2, 16, 64, 64, 128, 320, 2), (4, 8, 32, 128, 64, 128, 1), (8, 4, 16, 128, 320, 192, 2),
+    (8, 2, 8, 256, 128, 64, 4), (3, 4, 16, 64, 64, 64, 1)])
+def test_conv3x3_with_folded_skip(tile, NB, H, W, Cin, Cin2, Cout, splitk):
+    """ResBlock conv2 with a channel change: conv3x3(h) + conv1x1(x) + bias as ONE implicit GEMM over K = 9 Cin + Cin2
+    (openai_unetmodel.py:255-275: skip_connection(x) + h): the 1x1 is a tenth K range of the generic stride-1 kernel."""
+    E = _eng()
+    h = bf(rnd((NB, Cin, H, W), 31))
+    x = bf(rnd((NB, Cin2, H, W), 32))
+    w3 = bf(rnd((Cout, Cin, 3, 3), 33) / (3 * Cin ** 0.5))
+    w1 = bf(rnd((Cout, Cin2, 1, 1), 34) / Cin2 ** 0.5)
+    b = rnd((Cout,), 35)
+    ref = F.conv2d(h.float(), w3.float(), b, padding=1) + F.conv2d(x.float(), w1.float())
+    a = h.permute(0, 2, 3, 1).contiguous().cuda()
+    a2 = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = torch.cat([w3.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin), w1.reshape(Cout, Cin2)], 1).contiguous().cuda()
+    c = torch.full((NB * H * W, Cout), float("nan"), device="cuda")
+    bc = b.cuda()
+    rc = E.lib(PREC).df_test_conv3x3_skip(ptr(a), ptr(a2), ptr(wp), ptr(bc), ptr(c), NB, H, W, Cin, Cin2, Cout, tile, splitk, stream())
+    if rc != 0 and b"refused" in E.lib(PREC).df_last_error():
+        pytest.skip("tile / split-K combination does not exist for this shape (the halo tiles do not take the folded skip)")
+    assert rc == 0, E.lib(PREC).df_last_error()
+    torch.cuda.synchronize()
+    got = c.cpu().reshape(NB, H, W, Cout).permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < 2e-3
+
+
 @pytest.mark.parametrize("N,HW,C,silu,eps", [(2, 1024, 320, 1, 1e-5), (3, 128, 64, 0, 1e-6), (1, 512, 960, 1, 1e-5),
                                              (1, 65536, 128, 1, 1e-6)])
 def test_groupnorm(N, HW, C, silu, eps):
