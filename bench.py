@@ -235,8 +235,9 @@ def run_mode(precision, sd_dev, a, dev, rank, world, lo, hi, barrier, dump_ops="
 def vae_roofline(model, dev, B):
     """decode_first_stage at batch B (622.2 GFLOP and 0.0989 + 0.6096 B GB of algorithmic traffic)."""
     z = synth.synthetic_xT(B).to(dev)
-    for _ in range(2):
+    for _ in range(6):
         model.decode_first_stage(z)
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     n = 5

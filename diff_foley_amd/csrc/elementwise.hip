@@ -183,12 +183,18 @@ __global__ void groupnorm_kernel(const float* __restrict__ x, int ld, int HW, in
 // 128x512 px x 512 ch per sample).  The one-block-per-(group, sample) kernels above touch 40..64-B slivers of every
 // pixel row and occupy 32*N blocks; here the tensor is walked in pixel chunks with ALL channels (full 512..2048-B
 // rows, one float4 per thread), three launches:
-//   gn_chunk_stats:  per (chunk, sample): per-group (mean, M2) of the chunk, two passes over the chunk (the second
-//                    comes out of L2), written as partials -- numerically a chunked Welford, deterministic;
+//   gn_chunk_stats:  per (chunk, sample): per-group (mean, M2) of the chunk, read once into registers, two passes over the
+//                    registers, written as partials -- numerically a chunked Welford, deterministic;
 //   gn_merge_stats:  per (sample, group): Chan merge of the chunk partials -> (mean, rstd);
 //   gn_chunk_apply:  normalise + affine [+ SiLU] -> operand type, same chunking.
 // HBM traffic: 2 reads + 1 operand-type write of the tensor instead of 3 strided reads.
 constexpr int GN_CHUNK_PX = 256;
+
+// Statistics chunk: 32768 / C pixels (256 | 128 | 64 for C = 128 | 256 | 512), i.e. always 32 float4 per thread -- the chunk is
+// read from memory ONCE into registers and both passes (mean, then centred squares) run on the registers (round 3; the first
+// form re-read a 128..512-KB chunk, which for C = 512 no longer came out of L2: 53 us per norm, 2.5 TB/s).
+__host__ __device__ inline int gn_stats_chunk_px(int C) { return 32768 / C; }
+constexpr int GN_STATS_IT = 32;
 
 __global__ __launch_bounds__(256) void gn_chunk_stats_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
                                                              float* __restrict__ part /*[N][chunks][32][2]*/) {
@@ -196,29 +202,36 @@ __global__ __launch_bounds__(256) void gn_chunk_stats_kernel(const float* __rest
   const int n = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
   const int q = C >> 2;                       // float4 lanes per pixel (32 | 64 | 128)
   const int lane_c = threadIdx.x % q, lane_p = threadIdx.x / q, ppi = 256 / q;   // pixels per iteration
-  const int p0 = chunk * GN_CHUNK_PX, p1 = min(HW, p0 + GN_CHUNK_PX);
+  const int cpx = gn_stats_chunk_px(C);       // == GN_STATS_IT * ppi
+  const int p0 = chunk * cpx, p1 = min(HW, p0 + cpx);
   const float* xb = x + (long)n * HW * ld + lane_c * 4;
   const int qpg = max(cpg >> 2, 1);           // float4 lanes per group (cpg = 4 | 8 | 16)
   const int grp = lane_c / qpg;
-  float s = 0.f;
-  for (int p = p0 + lane_p; p < p1; p += ppi) {
-    const float4 v = *reinterpret_cast<const float4*>(xb + (long)p * ld);
-    s += (v.x + v.y) + (v.z + v.w);
+  float4 v[GN_STATS_IT];
+#pragma unroll
+  for (int it = 0; it < GN_STATS_IT; ++it) {
+    const int p = min(p0 + lane_p + it * ppi, HW - 1);           // clamped: every load is issued, tails are masked below
+    v[it] = *reinterpret_cast<const float4*>(xb + (long)p * ld);
   }
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < GN_STATS_IT; ++it)
+    if (p0 + lane_p + it * ppi < p1) s += (v[it].x + v[it].y) + (v[it].z + v[it].w);
   red[threadIdx.x] = s;
   __syncthreads();
-  // group sum of the chunk: every thread adds the q/… lanes of its group over all pixel lanes (<= 64 LDS reads)
+  // group sum of the chunk: every thread adds the lanes of its group over all pixel lanes (<= 64 LDS reads)
   float gs = 0.f;
   for (int lp = 0; lp < ppi; ++lp)
     for (int k = 0; k < qpg; ++k) gs += red[lp * q + grp * qpg + k];
   const float cnt = (float)(p1 - p0) * (float)cpg;
   const float mean = gs / cnt;
   float m2 = 0.f;
-  for (int p = p0 + lane_p; p < p1; p += ppi) {
-    const float4 v = *reinterpret_cast<const float4*>(xb + (long)p * ld);
-    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-    m2 += (a * a + b * b) + (c * c + d * d);
-  }
+#pragma unroll
+  for (int it = 0; it < GN_STATS_IT; ++it)
+    if (p0 + lane_p + it * ppi < p1) {
+      const float a = v[it].x - mean, b = v[it].y - mean, c = v[it].z - mean, d = v[it].w - mean;
+      m2 += (a * a + b * b) + (c * c + d * d);
+    }
   __syncthreads();
   red[threadIdx.x] = m2;
   __syncthreads();
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(256) void gn_chunk_stats_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(64) void gn_merge_stats_kernel(const float* __restrict__ part, int nchunk, int HW, int cpg,
+__global__ __launch_bounds__(64) void gn_merge_stats_kernel(const float* __restrict__ part, int nchunk, int cpx, int HW, int cpg,
                                                             float eps, float* __restrict__ stat /*[N][32][2]*/) {
   const int n = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
   // Chan merge of the chunk partials: lane l folds chunks l, l+64, ... (independent loads), then a fixed shuffle tree
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(64) void gn_merge_stats_kernel(const float* __restr
   float cnt = 0.f, mean = 0.f, m2 = 0.f;
   for (int c = lane; c < nchunk; c += 64) {
     const float* p = part + (((long)n * nchunk + c) * 32 + g) * 2;
-    const float nb = (float)(min(HW, (c + 1) * GN_CHUNK_PX) - c * GN_CHUNK_PX) * (float)cpg;
+    const float nb = (float)(min(HW, (c + 1) * cpx) - c * cpx) * (float)cpg;
     const float d = p[0] - mean, tot = cnt + nb;
     mean += d * nb / tot;
     m2 += p[1] + d * d * cnt * nb / tot;
@@ -676,7 +689,7 @@ bool groupnorm_accepts_slabs(int HW, int C) {      // shapes the register kernel
 size_t groupnorm_scratch_bytes(int N, int HW, int C) {
   const long items = (long)HW * (C / 64);
   if (items <= 16384 || (C != 128 && C != 256 && C != 512)) return 0;      // register kernels / generic streaming kernel
-  const int nchunk = (HW + GN_CHUNK_PX - 1) / GN_CHUNK_PX;
+  const int cpx = gn_stats_chunk_px(C), nchunk = (HW + cpx - 1) / cpx;
   return ((size_t)N * nchunk * 32 * 2 + (size_t)N * 32 * 2) * sizeof(float);
 }
 
@@ -684,13 +697,14 @@ hipError_t launch_groupnorm_chunked(const float* x, int ld, int N, int HW, int C
                                     float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, float* scratch,
                                     hipStream_t s) {
   if ((C != 128 && C != 256 && C != 512) || (ld & 3) || (ldo & 3) || !scratch) return hipErrorInvalidValue;
-  const int cpg = C / 32, nchunk = (HW + GN_CHUNK_PX - 1) / GN_CHUNK_PX;
+  const int cpg = C / 32, cpx = gn_stats_chunk_px(C), nchunk = (HW + cpx - 1) / cpx;
+  const int nchunk_apply = (HW + GN_CHUNK_PX - 1) / GN_CHUNK_PX;
   float* part = scratch;
   float* stat = scratch + (size_t)N * nchunk * 32 * 2;
   hipLaunchKernelGGL(gn_chunk_stats_kernel, dim3(nchunk, N), dim3(256), 0, s, x, ld, HW, C, cpg, part);
-  hipLaunchKernelGGL(gn_merge_stats_kernel, dim3(32, N), dim3(64), 0, s, part, nchunk, HW, cpg, eps, stat);
-  hipLaunchKernelGGL(gn_chunk_apply_kernel, dim3(nchunk, N), dim3(256), 0, s, x, ld, HW, C, cpg, gamma, beta, stat, silu, out,
-                     ldo, raw_out);
+  hipLaunchKernelGGL(gn_merge_stats_kernel, dim3(32, N), dim3(64), 0, s, part, nchunk, cpx, HW, cpg, eps, stat);
+  hipLaunchKernelGGL(gn_chunk_apply_kernel, dim3(nchunk_apply, N), dim3(256), 0, s, x, ld, HW, C, cpg, gamma, beta, stat, silu,
+                     out, ldo, raw_out);
   return hipGetLastError();
 }
 

@@ -19,11 +19,10 @@ z = synth.synthetic_xT(4).cuda()
 for _ in range(3):
     m.decode_first_stage(z)
 torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(reps):
+import time
+t0 = time.perf_counter()                # wall clock around a synchronised batch (the first torch timing event of a process
+for _ in range(reps):                   # was seen to halve the speed of the launches it brackets)
     m.decode_first_stage(z)
-e1.record()
 torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / reps
+ms = (time.perf_counter() - t0) * 1e3 / reps
 print(f"vae decode B=4: {ms:.3f} ms  ({622.2 * 4 / ms:.1f} TFLOP/s algorithmic, {(0.0989 + 0.6096 * 4) / ms * 1e3:.0f} GB/s algorithmic)")
