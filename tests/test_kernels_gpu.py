@@ -186,7 +186,13 @@ def test_conv3x3_with_folded_skip(tile, NB, H, W, Cin, Cin2, Cout, splitk):
 
 
 @pytest.mark.parametrize("N,HW,C,silu,eps", [(2, 1024, 320, 1, 1e-5), (3, 128, 64, 0, 1e-6), (1, 512, 960, 1, 1e-5),
-                                             (1, 65536, 128, 1, 1e-6)])
+                                             (1, 65536, 128, 1, 1e-6),
+                                             # register kernel: 1 / 3 / 15 / 40 channel pairs per group, row counts that do not
+                                             # divide into its passes, the 20-pass variant, a 1-row tensor
+                                             (2, 1000, 64, 1, 1e-5), (1, 777, 192, 0, 1e-5), (2, 1090, 960, 1, 1e-5), (3, 16, 2560, 1, 1e-5),
+                                             (2, 1, 320, 0, 1e-5), (1, 5461, 192, 1, 1e-6),
+                                             # chunked three-launch form: 256 / 512 channels, a ragged last chunk
+                                             (1, 16384 + 100, 256, 1, 1e-6), (2, 8192 + 33, 512, 0, 1e-6)])
 def test_groupnorm(N, HW, C, silu, eps):
     E = _eng()
     x = rnd((N, C, HW), 6) * 2 + 0.5
