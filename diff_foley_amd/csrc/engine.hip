@@ -2350,7 +2350,10 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
   HIPCHK(hipEventCreate(&e1));
   std::map<std::string, std::vector<TuneCand>> cands;
   static const int tile_cap = getenv("DF_TILE_CAP") ? atoi(getenv("DF_TILE_CAP")) : TILE_ALL;   // tools: A/B a tile family
-  static const int topk = getenv("DF_TUNE_TOPK") ? atoi(getenv("DF_TUNE_TOPK")) : 6;            // 1 = stage 1 only
+  // Candidates per GEMM class that go on to the in-plan stage.  The isolated ranking is a weak predictor of the in-plan time
+  // (operands cold, neighbours' traffic): widening 6 -> 12 -> 40 measured 231.2 -> 235.8 and 232.5 -> 233.7 -> 234.5 steps/s on
+  // two boxes, for ~1 s more tuning per plan (40 plan runs of 4 ms x 4 repetitions).
+  static const int topk = getenv("DF_TUNE_TOPK") ? atoi(getenv("DF_TUNE_TOPK")) : 32;           // 1 = stage 1 only
   for (auto& o : pl->ops) {
     if (!o.is_gemm || o.c_ext) continue;
     const std::string key = tune_key(o);
@@ -2412,31 +2415,51 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
   a.out2 = (float*)(ext + 4 * slab);
   const bool prof_was = c->prof_on;
   const int reps = 3;
-  for (size_t r = 0; r < rounds; ++r) {
-    apply((int)r);
-    std::vector<float> best(pl->ops.size(), 1e30f);
-    for (int rep = 0; rep < reps + 1; ++rep) {   // first repetition warms up
-      c->prof_on = true;
-      c->prof_used = 0;
-      c->prof_fam.clear();
-      c->prof_op.clear();
-      run_ops(c, pl, 0, pl->ops.size(), s, a);
-      c->prof_on = false;
-      HIPCHK(hipStreamSynchronize(s));
-      if (rep == 0) continue;
+  // one in-plan pass over candidate ranks [0, nr): every GEMM class runs its r-th candidate, per-op minimum over `nrep` runs
+  auto evaluate = [&](size_t nr, int nrep) {
+    for (auto& kv : cands)
+      for (auto& cd : kv.second) cd.situ_ms = 0.0;
+    for (size_t r = 0; r < nr; ++r) {
+      apply((int)r);
+      std::vector<float> best(pl->ops.size(), 1e30f);
+      for (int rep = 0; rep < nrep + 1; ++rep) {   // first repetition warms up
+        c->prof_on = true;
+        c->prof_used = 0;
+        c->prof_fam.clear();
+        c->prof_op.clear();
+        run_ops(c, pl, 0, pl->ops.size(), s, a);
+        c->prof_on = false;
+        HIPCHK(hipStreamSynchronize(s));
+        if (rep == 0) continue;
+        for (size_t i = 0; i < pl->ops.size(); ++i) {
+          float ms = 0;
+          HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+          best[i] = std::min(best[i], ms);
+        }
+      }
       for (size_t i = 0; i < pl->ops.size(); ++i) {
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
-        best[i] = std::min(best[i], ms);
+        const Op& o = pl->ops[i];
+        if (!o.is_gemm || o.c_ext) continue;
+        std::vector<TuneCand>& v = cands[tune_key(o)];
+        // a deferred split-K reduce is paid by the next op (the GroupNorm sums the slabs): judge the pair
+        if (r < v.size()) v[r].situ_ms += best[i] + ((o.defer && i + 1 < pl->ops.size()) ? best[i + 1] : 0.f);
       }
     }
-    for (size_t i = 0; i < pl->ops.size(); ++i) {
-      const Op& o = pl->ops[i];
-      if (!o.is_gemm || o.c_ext) continue;
-      std::vector<TuneCand>& v = cands[tune_key(o)];
-      // a deferred split-K reduce is paid by the next op (the GroupNorm sums the slabs): judge the pair
-      if (r < v.size()) v[r].situ_ms += best[i] + ((o.defer && i + 1 < pl->ops.size()) ? best[i + 1] : 0.f);
+  };
+  // stage 2a: every surviving candidate, coarse (2 runs); 2b: the four best of each class again, among good neighbours and
+  // with 6 runs -- the final choice between near-equal candidates used to flip from run to run (227 .. 234 steps/s for the
+  // same build and box), a second, finer round takes most of that variance out
+  static const bool two_pass = !(getenv("DF_TUNE_2PASS") && atoi(getenv("DF_TUNE_2PASS")) == 0);
+  evaluate(rounds, two_pass ? 2 : reps);
+  if (two_pass) {
+    size_t keep = 0;
+    for (auto& kv : cands) {
+      std::vector<TuneCand>& v = kv.second;
+      std::sort(v.begin(), v.end(), [](const TuneCand& x, const TuneCand& y) { return x.situ_ms < y.situ_ms; });
+      if (v.size() > 4) v.resize(4);
+      keep = std::max(keep, v.size());
     }
+    evaluate(keep, 6);
   }
   apply(-1);
   if (getenv("DF_TUNE_LOG") && atoi(getenv("DF_TUNE_LOG"))) {      // tools: the candidates of every GEMM class, both stages
