@@ -441,6 +441,17 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
 }
 
+// Quotient of small non-negative integers by a block-uniform divisor, 4 instructions instead of the ~30 of the general 32-bit
+// division: q = trunc((x + 0.5) * (1/d)) is exact for 0 <= x < 2^22 (the product's error (q+1) 2^-23 stays below the 0.5/d
+// distance of (x + 0.5)/d from the next integer).  The kernels' prologues turn tile rows into (sample, y, x) with up to 60 such
+// divisions per thread before the first operand request can be issued -- ~3 us of the ~4.4 us launch floor of a halo conv.
+struct FastDiv {
+  float inv;
+  int d;
+  __device__ __forceinline__ explicit FastDiv(int d_) : inv(1.0f / (float)d_), d(d_) {}
+  __device__ __forceinline__ int div(int x) const { return (int)(((float)x + 0.5f) * inv); }
+};
+
 // Logical tile id -> (M tile, N tile): M-fastest inside row groups of `gm` M-tiles (gm <= 0: one group = plain M-fastest).
 __device__ __forceinline__ void tile_of(int lid, int nbm, int nbn, int gm, int& mt, int& nt) {
   if (gm <= 0 || gm >= nbm) {
@@ -535,6 +546,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   unsigned a_off2[AP];  // MODE 1 with a folded skip connection: byte offset of the centre pixel in the second tensor
   int a_iy[AP], a_ix[AP];
   const int UH = p.H << p.ups, UW = p.Wd << p.ups;
+  const bool fast_rows = MODE != 0 && p.M + BM < (1 << 22);      // row -> (sample, y, x) by FastDiv (exact below 2^22)
+  const FastDiv fd_ohw(MODE != 0 ? max(p.OH * p.OW, 1) : 1), fd_ow(MODE != 0 ? max(p.OW, 1) : 1);
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     const int m = m0 + r0 + RPP * i;
@@ -547,8 +560,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
       if (p.Cin2 > 0) a_off2[i] = mv ? (unsigned)(((long)m * p.lda2 + c8) * 2) : OOB;
     } else {
       const int ohw = p.OH * p.OW;
-      const int nb = m / ohw, rem = m - nb * ohw;
-      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      int nb, rem, oy;
+      if (fast_rows) {
+        nb = fd_ohw.div(m); rem = m - nb * ohw;
+        oy = fd_ow.div(rem);
+      } else {
+        nb = m / ohw; rem = m - nb * ohw;
+        oy = rem / p.OW;
+      }
+      const int ox = rem - oy * p.OW;
       if (MODE == 3) {
         // rows = INPUT-resolution pixels (OH = H, OW = Wd here); tap (dy, dx) of phase (a, b) reads pixel (y-1+a+dy, x-1+b+dx)
         const int pa = phase >> 1, pb = phase & 1;
@@ -961,6 +981,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   // LDS cycles, SQ_LDS_BANK_CONFLICT).  The halo slot is swizzled by the pixel's x-pair plus SC * (image row counter):
   // conflict-free for TW = 16 (SC = 0) and TW = 8 (SC = 4) at every tap shift.
   const int SC = (TW == 16) ? 0 : 4;
+  // all quotients below are of values < 2^22 (launch_halo checks the patch count): FastDiv instead of 32-bit division
+  const FastDiv fd_hwp(HWp), fd_tw2(TW + 2), fd_pimg(npy * npx), fd_npx(npx), fd_ppx(PPX), fd_tw(TW);
   constexpr int MAXAP = 12;
   unsigned a_off[MAXAP];
 #pragma unroll
@@ -968,13 +990,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
     const int hr = r0 + RPP * i;                 // halo row
     unsigned off = OOB;
     if (i < APASS && hr < HR) {
-      const int pi = hr / HWp, rem = hr - pi * HWp;
-      const int hy = rem / (TW + 2), hx = rem - hy * (TW + 2);
+      const int pi = fd_hwp.div(hr), rem = hr - pi * HWp;
+      const int hy = fd_tw2.div(rem), hx = rem - hy * (TW + 2);
       const int g = mt * PB + pi;                // global patch id
       const int ca = ((tid & 7) ^ (((hx >> 1) + SC * (pi * (TH + 2) + hy)) & 7)) * 8;
       if (g < npatch) {
-        const int n = g / (npy * npx), gr = g - n * (npy * npx);
-        const int y = (gr / npx) * TH + hy - 1, x = (gr % npx) * TW + hx - 1;
+        const int n = fd_pimg.div(g), gr = g - n * (npy * npx);
+        const int gy = fd_npx.div(gr), gx = gr - gy * npx;
+        const int y = gy * TH + hy - 1, x = gx * TW + hx - 1;
         if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd)
           off = (unsigned)((((long)(n * p.H + y) * p.Wd + x) * p.lda + ca) * 2);
       }
@@ -993,8 +1016,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int r = wm * WTM + i * 32 + l31;
-    const int pi = r / PPX, rem = r - pi * PPX;
-    const int y = rem / TW, x = rem - y * TW;
+    const int pi = fd_ppx.div(r), rem = r - pi * PPX;
+    const int y = fd_tw.div(rem), x = rem - y * TW;
     hb[i] = pi * HWp + y * (TW + 2) + x;
     hbx[i] = x;
     hbq[i] = SC * (pi * (TH + 2) + y);
@@ -1114,11 +1137,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   // ---- epilogue: tile row -> NHWC pixel index of its output pixel.  Five integer divisions per row: computed once per
   // row into a BM-entry LDS table behind the operand ring instead of once per 4-column chunk of the epilogue loop.
   auto rowmap_calc = [&](int rr) {
-    const int pi = rr / PPX, rem = rr - pi * PPX;
-    const int y = rem / TW, x = rem - y * TW;
+    const int pi = fd_ppx.div(rr), rem = rr - pi * PPX;
+    const int y = fd_tw.div(rem), x = rem - y * TW;
     const int g = mt * PB + pi;
-    const int n = g / (npy * npx), gr = g - n * (npy * npx);
-    return (g < npatch) ? (n * p.H + (gr / npx) * TH + y) * p.Wd + (gr % npx) * TW + x : p.M;
+    const int n = fd_pimg.div(g), gr = g - n * (npy * npx);
+    const int gy = fd_npx.div(gr), gx = gr - gy * npx;
+    return (g < npatch) ? (n * p.H + gy * TH + y) * p.Wd + gx * TW + x : p.M;
   };
   int* srow = reinterpret_cast<int*>(smem + p.halo_ring_bytes);
   for (int rr = tid; rr < BM; rr += NT) srow[rr] = rowmap_calc(rr);
@@ -1192,6 +1216,7 @@ hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
   }
   const int npatch = p.M / ppx;
   const int nbm = (npatch + PB - 1) / PB, nbn = (p.N + BN - 1) / BN;
+  if ((long)nbm * PB >= (1 << 22)) return hipErrorInvalidValue;      // FastDiv range of the patch decomposition
   hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WGM, WGN, NSTW, EPI>), dim3(nbm * nbn, 1, zdim), dim3(NT), lds, stream, p);
   return hipGetLastError();
 }
