@@ -682,6 +682,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     }                                                                                           \
   }
 
+  // ---- prologue: fill NST-1 ring slots -- as early as the request offsets exist.  Everything below (accumulator init,
+  // fragment offsets, epilogue prefetch: ~150-700 instructions) runs while the first tiles are in flight instead of in front of
+  // them; the epilogue prefetch's loads are then younger than these requests, which only makes the first ring wait stricter.
+  DF_DMA(0, 0);
+  if (NST > 2) DF_DMA(1, 1);
+  if (NST > 3) DF_DMA(2, 2);
+  if (NST > 4) DF_DMA(3, 3);
+  __builtin_amdgcn_sched_barrier(0);
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -750,11 +759,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     ++it;                                                                                       \
   }
   const EpiVec ev = epi_prefetch<BN, NT, EPI>(p, n0, tid);
-  // ---- prologue: fill NST-1 ring slots
-  DF_DMA(0, 0);
-  if (NST > 2) DF_DMA(1, 1);
-  if (NST > 3) DF_DMA(2, 2);
-  if (NST > 4) DF_DMA(3, 3);
 
   int it = 0;
   DF_RING_SYNC((NST - 2) * LPT);       // tile 0 landed and visible
@@ -1011,25 +1015,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
     w_off[i] = (n < p.N && r0 + RPP * i < BN) ? (unsigned)(((long)n * p.K + c8) * 2) : OOB;
   }
 
-  // ---- MFMA row -> halo row of tap (0,0) and output pixel index
-  int hb[TM], hbx[TM], hbq[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int r = wm * WTM + i * 32 + l31;
-    const int pi = fd_ppx.div(r), rem = r - pi * PPX;
-    const int y = fd_tw.div(rem), x = rem - y * TW;
-    hb[i] = pi * HWp + y * (TW + 2) + x;
-    hbx[i] = x;
-    hbq[i] = SC * (pi * (TH + 2) + y);
-  }
-  int fb[TN], sb[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int row = wn * WTN + j * 32 + l31;
-    fb[j] = row * BK;
-    sb[j] = (row >> 1) & 7;
-  }
-
   // DMA helpers -------------------------------------------------------------------------------------------------
   // A halo of channel slice C (absolute slice index) into buffer BUF
 #define DF_HALO_A(C, BUF)                                                                         \
@@ -1054,6 +1039,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
                                                (live && w_off[i] != OOB) ? w_off[i] + kb : OOB, 0, 0, 0); \
   }
 
+  // ---- prologue: A(0), W(0 .. NSTW-2) -- requested as soon as the offsets exist; fragment coordinates, accumulator init and
+  // the epilogue prefetch below run while these are in flight
+  DF_HALO_A(c0, 0);
+#pragma unroll
+  for (int t = 0; t < NSTW - 1; ++t) DF_HALO_W(t, t);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- MFMA row -> halo row of tap (0,0) and output pixel index
+  int hb[TM], hbx[TM], hbq[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * WTM + i * 32 + l31;
+    const int pi = fd_ppx.div(r), rem = r - pi * PPX;
+    const int y = fd_tw.div(rem), x = rem - y * TW;
+    hb[i] = pi * HWp + y * (TW + 2) + x;
+    hbx[i] = x;
+    hbq[i] = SC * (pi * (TH + 2) + y);
+  }
+  int fb[TN], sb[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * WTN + j * 32 + l31;
+    fb[j] = row * BK;
+    sb[j] = (row >> 1) & 7;
+  }
+
   const EpiVec ev = epi_prefetch<BN, NT, EPI>(p, n0, tid);
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -1062,11 +1073,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- prologue: A(0), W(0 .. NSTW-2)
-  DF_HALO_A(c0, 0);
-#pragma unroll
-  for (int t = 0; t < NSTW - 1; ++t) DF_HALO_W(t, t);
 
   // Wait for the operands of tap T (W(c,T); at T = 0 also the halo of slice c) and hand the ring slot / halo buffer read by
   // the previous tap back to the DMA engine.  VM = loads of this wave allowed to be still in flight.  The lgkmcnt(0) makes
