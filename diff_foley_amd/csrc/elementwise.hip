@@ -664,6 +664,21 @@ __global__ void ddim_update_kernel(const float* __restrict__ x, const float* __r
   }
 }
 
+// Inpainting blend of the samplers (ddim.py:206-209, plms.py:147-150, ddpm.py:1239-1241):
+//   img <- q_sample(x0, t) * mask + (1 - mask) * img,   q_sample(x0, t) = sqrt(acp_t) x0 + sqrt(1 - acp_t) noise   (ddpm.py:279-282)
+// mask is indexed modulo mask_n (1 channel broadcast over C: mask_n = H*W per sample handled by the caller's layout [B][1][H][W]).
+__global__ void q_sample_blend_kernel(const float* __restrict__ img, const float* __restrict__ x0,
+                                      const float* __restrict__ noise, const float* __restrict__ mask, float* __restrict__ out,
+                                      long n, long chw, long hw, int mask_c, float a, float b) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long smp = i / chw, r = i - smp * chw;
+    const long mi = mask_c == 1 ? smp * hw + (r % hw) : i;            // [B][1][H][W] or [B][C][H][W]
+    const float m = mask[mi];
+    const float q = a * x0[i] + b * noise[i];
+    out[i] = q * m + (1.0f - m) * img[i];
+  }
+}
+
 __global__ void avgpool_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int HW, int C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * C) return;
@@ -1074,6 +1089,14 @@ hipError_t launch_lincomb(float* out, const float* const* in, const float* coef,
     a.coef[i] = i < nterms ? coef[i] : 0.f;
   }
   hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, a, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_q_sample_blend(const float* img, const float* x0, const float* noise, const float* mask, float* out, long n,
+                                 long chw, long hw, int mask_c, float a, float b, hipStream_t s) {
+  if (n <= 0 || chw <= 0 || hw <= 0 || n % chw != 0 || chw % hw != 0 || (mask_c != 1 && mask_c != (int)(chw / hw)))
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(q_sample_blend_kernel, dim3(grid_for(n)), dim3(256), 0, s, img, x0, noise, mask, out, n, chw, hw, mask_c, a, b);
   return hipGetLastError();
 }
 

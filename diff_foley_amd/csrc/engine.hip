@@ -3000,6 +3000,13 @@ int df_cfg_combine(const float* e2, float* e, int64_t n, float scale, void* stre
 int df_lincomb(float* out, const float* const* in, const float* coef, int nterms, int64_t n, void* stream) {
   return guard([&] { HIPCHK(launch_lincomb(out, in, coef, nterms, (long)n, (hipStream_t)stream)); });
 }
+int df_q_sample_blend(const float* img, const float* x0, const float* noise, const float* mask, float* out, int64_t n, int64_t chw,
+                      int64_t hw, int mask_c, float sqrt_acp, float sqrt_one_minus_acp, void* stream) {
+  return guard([&] {
+    HIPCHK(launch_q_sample_blend(img, x0, noise, mask, out, (long)n, (long)chw, (long)hw, mask_c, sqrt_acp, sqrt_one_minus_acp,
+                                 (hipStream_t)stream));
+  });
+}
 int df_ddim_update(const float* x, const float* e, const float* noise, float* x_prev, float* pred_x0, int64_t n,
                    float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, void* stream) {
   return guard([&] {

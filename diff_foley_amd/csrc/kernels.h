@@ -102,6 +102,9 @@ hipError_t launch_cfg_combine(const float* e2, float* e, long n, float scale, hi
 // out = sum_i coef[i] * in[i]   (up to 4 terms; out may alias any input)
 hipError_t launch_lincomb(float* out, const float* const* in, const float* coef, int nterms, long n, hipStream_t s);
 // DDIM update (ddim.py:258-272): pred_x0 = (x - s1m*e)/sqrt(a_t); x_prev = sqrt(a_prev)*pred_x0 + dir*e + sigma*noise
+// inpainting blend: out = (a x0 + b noise) * mask + (1 - mask) * img; mask [B][mask_c][H][W], mask_c = 1 or C
+hipError_t launch_q_sample_blend(const float* img, const float* x0, const float* noise, const float* mask, float* out, long n,
+                                 long chw, long hw, int mask_c, float a, float b, hipStream_t s);
 hipError_t launch_ddim_update(const float* x, const float* e, const float* noise, float* x_prev, float* pred_x0,
                               long n, float sqrt_at, float s1m, float sqrt_aprev, float dir_coef, float sigma,
                               hipStream_t s);

@@ -78,6 +78,8 @@ _SIGS = {
     "df_griffinlim": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 9,
     "df_cfg_combine": [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p],
     "df_lincomb": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_void_p],
+    "df_q_sample_blend": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                          C.c_float, C.c_float, C.c_void_p],
     "df_ddim_update": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                        C.c_float, C.c_float, C.c_void_p],
     "df_plan_count": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
@@ -436,6 +438,19 @@ def lincomb(terms, out=None):
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
     coefs = (C.c_float * n)(*[float(c) for c, _ in terms])
     _chk(lib().df_lincomb(_ptr(out), ptrs, coefs, n, out.numel(), _stream()))
+    return out
+
+
+def q_sample_blend(img, x0, noise, mask, sqrt_acp, sqrt_one_minus_acp):
+    """img <- q_sample(x0, t) * mask + (1 - mask) * img (the samplers' inpainting blend; ddim.py:206-209, ddpm.py:279-282).
+    img / x0 / noise fp32 [B][C][H][W]; mask [B][1][H][W] or [B][C][H][W]."""
+    B, Cc, H, W = img.shape
+    assert x0.shape == img.shape and noise.shape == img.shape, (x0.shape, noise.shape, img.shape)
+    if mask.dim() != 4 or mask.shape[0] != B or mask.shape[1] not in (1, Cc) or tuple(mask.shape[2:]) != (H, W):
+        raise ValueError(f"mask of shape {tuple(mask.shape)} does not match a latent of shape {tuple(img.shape)} ([B][1|C][H][W])")
+    out = torch.empty_like(img)
+    _chk(lib().df_q_sample_blend(_ptr(img), _ptr(x0), _ptr(noise), _ptr(mask), _ptr(out), img.numel(), Cc * H * W, H * W,
+                                 int(mask.shape[1]), float(sqrt_acp), float(sqrt_one_minus_acp), _stream()))
     return out
 
 

@@ -236,8 +236,7 @@ class LatentDiffusion:
     def sample(self, cond, batch_size=16, return_intermediates=False, x_T=None, verbose=True, timesteps=None,
                quantize_denoised=False, mask=None, x0=None, shape=None, **kwargs):
         self._require()
-        S.reject_unsupported("LatentDiffusion.sample", dict(mask=mask, x0=x0, quantize_denoised=quantize_denoised,
-                                                              start_T=kwargs.get("start_T")),
+        S.reject_unsupported("LatentDiffusion.sample", dict(quantize_denoised=quantize_denoised, start_T=kwargs.get("start_T")),
                              dict(quantize_denoised=False, start_T=None))
         if shape is None:
             shape = (batch_size, self.channels, self.image_size, self.image_size)
@@ -246,7 +245,8 @@ class LatentDiffusion:
         return S.ancestral_sample(self, cond, tuple(shape), x_T=x_T, timesteps=timesteps,
                                   log_every_t=kwargs.get("log_every_t"), return_intermediates=return_intermediates,
                                   noise_fn=kwargs.get("noise_fn"), callback=kwargs.get("callback"),
-                                  img_callback=kwargs.get("img_callback"))
+                                  img_callback=kwargs.get("img_callback"), mask=mask, x0=x0,
+                                  q_noise_fn=kwargs.get("q_noise_fn"))
 
     def _sampler(self, name):
         return {"DDIM": S.DDIMSampler, "DPM_Solver": S.DPMSolverSampler, "PLMS": S.PLMSSampler}[name](self)

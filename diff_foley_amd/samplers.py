@@ -29,7 +29,7 @@ def _warn_batch(conditioning, batch_size):
 # Reference sampler features that are NOT on this path.  The reference classes accept them (ddim.py:58-113, 179-273;
 # plms.py:60-110; dpm_solver/sampler.py:24-56); silently dropping one would return a plausible but wrong sample, so a
 # non-default value raises.  Anything not listed is ignored exactly like the reference's own **kwargs.
-_UNSUPPORTED_DEFAULTS = dict(mask=None, x0=None, quantize_x0=False, score_corrector=None, corrector_kwargs=None,
+_UNSUPPORTED_DEFAULTS = dict(quantize_x0=False, score_corrector=None, corrector_kwargs=None,
                              noise_dropout=0.0, normals_sequence=None)
 
 
@@ -40,6 +40,36 @@ def reject_unsupported(sampler, kwargs, extra=None):
         if k in kwargs and kwargs[k] is not None and kwargs[k] != default:
             raise NotImplementedError(f"{sampler}: {k}={kwargs[k]!r} is not supported by the MI355X sampling path "
                                       f"(only the default {default!r}); see DESIGN.md section 1")
+
+
+class _Inpaint:
+    """mask / x0 of the reference samplers: the known region is re-noised to the current step and pasted over the sample,
+    img <- q_sample(x0, t) * mask + (1 - mask) * img  (ddim.py:206-209, plms.py:147-150, ddpm.py:1239-1241; q_sample ddpm.py:279-282).
+    q_noise_fn(shape) -> tensor replaces torch.randn_like(x0) (tests: the reference's noise sequence)."""
+
+    def __init__(self, model, mask, x0, size, q_noise_fn=None):
+        self.on = mask is not None
+        if not self.on:
+            return
+        assert x0 is not None                                  # like the reference
+        dev = model.device
+        B, C, H, W = size
+        x0 = x0.to(dev, torch.float32)
+        mask = mask.to(dev, torch.float32)
+        if mask.dim() == 3:
+            mask = mask[:, None]
+        assert x0.shape[2:3] == mask.shape[2:3]                # "spatial size has to match" (ddpm.py:1227)
+        mc = C if mask.shape[1] == C and C != 1 else 1
+        self.mask = mask.expand(B, mc, H, W).contiguous()      # broadcast copy, no arithmetic
+        self.x0 = x0.expand(B, C, H, W).contiguous()
+        self.sa = model.sqrt_alphas_cumprod.cpu().numpy()
+        self.s1m = model.sqrt_one_minus_alphas_cumprod.cpu().numpy()
+        self.noise_fn = q_noise_fn
+
+    def blend(self, img, t):
+        noise = self.noise_fn(tuple(self.x0.shape)).to(img.device, torch.float32) if self.noise_fn is not None \
+            else torch.randn_like(self.x0)
+        return E.q_sample_blend(img, self.x0, noise.contiguous(), self.mask, self.sa[int(t)], self.s1m[int(t)])
 
 
 class _Guided:
@@ -91,7 +121,7 @@ class DDIMSampler(object):
     def sample(self, S, batch_size, shape, conditioning=None, eta=0.0, x_T=None, log_every_t=100,
                unconditional_guidance_scale=1.0, unconditional_conditioning=None, temperature=1.0,
                verbose=True, callback=None, img_callback=None, classifier=None, origin_cond=None,
-               classifier_guide_scale=0.0, **kwargs):
+               classifier_guide_scale=0.0, mask=None, x0=None, **kwargs):
         reject_unsupported("DDIMSampler", kwargs)
         _warn_batch(conditioning, batch_size)
         self.make_schedule(S, ddim_eta=eta, verbose=verbose)
@@ -105,8 +135,11 @@ class DDIMSampler(object):
         total = steps.shape[0]
         t_all = torch.tensor(steps.copy(), dtype=torch.float32, device=dev)[:, None].expand(total, batch_size).contiguous()
         inter = {"x_inter": [img], "pred_x0": [img]}
+        paint = _Inpaint(self.model, mask, x0, size, kwargs.get("q_noise_fn"))
         for i in range(total):
             index = total - i - 1
+            if paint.on:                     # ddim.py:206-209
+                img = paint.blend(img, steps[i])
             e_t = eps_fn(img, t_all[i])
             a_t, a_prev = tb.alphas[index], tb.alphas_prev[index]
             if classifier is not None:       # ddim.py:374-380
@@ -140,7 +173,7 @@ class PLMSSampler(object):
     @torch.no_grad()
     def sample(self, S, batch_size, shape, conditioning=None, eta=0.0, x_T=None, log_every_t=100,
                unconditional_guidance_scale=1.0, unconditional_conditioning=None, verbose=True, callback=None,
-               img_callback=None, **kwargs):
+               img_callback=None, mask=None, x0=None, **kwargs):
         if eta != 0:
             raise ValueError("ddim_eta must be 0 for PLMS")
         reject_unsupported("PLMSSampler", kwargs, dict(temperature=1.0))
@@ -156,8 +189,11 @@ class PLMSSampler(object):
         t_all = torch.tensor(steps.copy(), dtype=torch.float32, device=dev)[:, None].expand(total, batch_size).contiguous()
         inter = {"x_inter": [img], "pred_x0": [img]}
         old_eps = []
+        paint = _Inpaint(self.model, mask, x0, size, kwargs.get("q_noise_fn"))
         for i in range(total):
             index = total - i - 1
+            if paint.on:                     # plms.py:147-150
+                img = paint.blend(img, steps[i])
             upd = lambda x, e: E.ddim_update(x, e, tb.alphas[index], tb.alphas_prev[index], 0.0,
                                              tb.sqrt_one_minus_alphas[index], None)
             e_t = eps_fn(img, t_all[i])
@@ -196,7 +232,7 @@ class DPMSolverSampler(object):
                unconditional_conditioning=None, classifier=None, origin_cond=None, classifier_guide_scale=0.0,
                **kwargs):
         # the reference ignores eta / temperature here (sampler.py:24-56 passes neither to DPM_Solver): same
-        reject_unsupported("DPMSolverSampler", kwargs)
+        reject_unsupported("DPMSolverSampler", kwargs, dict(mask=None, x0=None))      # sampler.py:24-56 accepts and drops them
         if S < 2:
             raise AssertionError("DPM-Solver++(2M) needs steps >= order = 2 (dpm_solver.py:1083 asserts steps >= order)")
         _warn_batch(conditioning, batch_size)
@@ -256,7 +292,7 @@ class DPMSolverSampler(object):
 
 @torch.no_grad()
 def ancestral_sample(model, cond, shape, x_T=None, timesteps=None, log_every_t=None, return_intermediates=False,
-                     noise_fn=None, callback=None, img_callback=None):
+                     noise_fn=None, callback=None, img_callback=None, mask=None, x0=None, q_noise_fn=None):
     """LatentDiffusion.p_sample_loop (ddpm.py:1201-1250): 1000-step ancestral sampling, no CFG, clip_denoised False."""
     dev = model.device
     img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32).contiguous()
@@ -268,6 +304,7 @@ def ancestral_sample(model, cond, shape, x_T=None, timesteps=None, log_every_t=N
                                                         "posterior_mean_coef1", "posterior_mean_coef2",
                                                         "posterior_log_variance_clipped")}
     inter = [img]
+    paint = _Inpaint(model, mask, x0, tuple(shape), q_noise_fn)
     for i in reversed(range(0, T)):
         ts = torch.full((b,), float(i), device=dev, dtype=torch.float32)
         eps = eps_fn(img, ts)
@@ -280,6 +317,8 @@ def ancestral_sample(model, cond, shape, x_T=None, timesteps=None, log_every_t=N
         if i != 0:
             terms.append((np.exp(0.5 * tab["posterior_log_variance_clipped"][i]), noise))
         img = E.lincomb(terms)
+        if paint.on:                         # ddpm.py:1239-1241: after the step
+            img = paint.blend(img, i)
         if i % log_every_t == 0 or i == T - 1:
             inter.append(img)
         if callback:

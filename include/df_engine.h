@@ -177,6 +177,11 @@ int df_cfg_combine(const float* e2_dev, float* e_dev, int64_t n, float scale, vo
 /* out = sum_i coef[i]*in[i], 1..4 terms; out may alias an input  (DPM-Solver++ updates dpm_solver.py:504-549,
  * 755-810; PLMS multistep plms.py:219-232; classifier guidance ddim.py:380) */
 int df_lincomb(float* out_dev, const float* const* in_dev, const float* coef, int nterms, int64_t n, void* stream);
+/* Inpainting blend of the samplers (reference ddim.py:206-209, plms.py:147-150, ddpm.py:1239-1241 with q_sample ddpm.py:279-282):
+ * out = (sqrt_acp * x0 + sqrt_one_minus_acp * noise) * mask + (1 - mask) * img.  All tensors fp32 NCHW [B][C][H][W] (n elements,
+ * chw per sample, hw per channel); mask is [B][mask_c][H][W] with mask_c = 1 (broadcast over channels) or C.  out != img. */
+int df_q_sample_blend(const float* img_dev, const float* x0_dev, const float* noise_dev, const float* mask_dev, float* out_dev,
+                      int64_t n, int64_t chw, int64_t hw, int mask_c, float sqrt_acp, float sqrt_one_minus_acp, void* stream);
 /* DDIM update (ddim.py:258-272).  noise may be NULL (eta = 0). */
 int df_ddim_update(const float* x_dev, const float* e_dev, const float* noise_dev, float* x_prev_dev,
                    float* pred_x0_dev, int64_t n, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at,

@@ -11,6 +11,7 @@ with the same signature) and restates the host loop of the reference:
   * dpm_solver_first_update / multistep second update     dpm_solver.py:504-549, 755-810
   * PLMSSampler.plms_sampling / p_sample_plms             diff_foley/models/diffusion/plms.py:113-236
   * LatentDiffusion.p_sample_loop / p_sample / p_mean_variance   ddpm.py:1083-1250
+  * inpainting (mask / x0): q_sample + blend               ddim.py:206-209, plms.py:147-150, ddpm.py:1239-1241, 279-282
 """
 import numpy as np
 import torch
@@ -38,9 +39,19 @@ def classifier_grad(classifier, x, t, origin_cond):
 
 
 @torch.no_grad()
+def q_sample_blend(img, x0, mask, alphas_cumprod, t, noise):
+    """img_orig = q_sample(x0, t); img = img_orig * mask + (1 - mask) * img   (ddim.py:206-209 / plms.py:147-150 /
+    ddpm.py:1239-1241; q_sample = sqrt(acp_t) x0 + sqrt(1 - acp_t) noise, ddpm.py:279-282)."""
+    acp = torch.as_tensor(np.asarray(alphas_cumprod, dtype=np.float64))
+    a = float(torch.sqrt(acp[int(t)]).to(torch.float32))
+    b = float(torch.sqrt(1.0 - acp[int(t)]).to(torch.float32))
+    img_orig = a * x0 + b * noise
+    return img_orig * mask + (1.0 - mask) * img
+
+
 def ddim_sample(apply_model, alphas_cumprod, S, x_T, cond, scale=1.0, uc=None, eta=0.0,
                 log_every_t=100, classifier=None, origin_cond=None, classifier_scale=0.0,
-                noise_fn=None):
+                noise_fn=None, mask=None, x0=None, q_noise_fn=None):
     sch = ddim_schedule(alphas_cumprod, S, eta)
     steps = sch["timesteps"]
     b = x_T.shape[0]
@@ -54,6 +65,9 @@ def ddim_sample(apply_model, alphas_cumprod, S, x_T, cond, scale=1.0, uc=None, e
         a_prev = torch.full((b, 1, 1, 1), float(sch["alphas_prev"][index]))
         sigma_t = torch.full((b, 1, 1, 1), float(sch["sigmas"][index]))
         s1m = torch.full((b, 1, 1, 1), float(sch["sqrt_one_minus_alphas"][index]))
+        if mask is not None:                          # ddim.py:206-209
+            qn = q_noise_fn(x0.shape) if q_noise_fn is not None else torch.randn_like(x0)
+            img = q_sample_blend(img, x0, mask, alphas_cumprod, int(step), qn)
         e_t = _cfg_eps(apply_model, img, ts, cond, scale, uc)
         if classifier is not None:
             g = classifier_grad(classifier, img, ts, origin_cond) * classifier_scale
@@ -132,7 +146,8 @@ def dpm_solver_sample(apply_model, alphas_cumprod, S, x_T, cond, scale=1.0, uc=N
 
 
 @torch.no_grad()
-def plms_sample(apply_model, alphas_cumprod, S, x_T, cond, scale=1.0, uc=None, log_every_t=100):
+def plms_sample(apply_model, alphas_cumprod, S, x_T, cond, scale=1.0, uc=None, log_every_t=100, mask=None, x0=None,
+                q_noise_fn=None):
     sch = ddim_schedule(alphas_cumprod, S, 0.0)
     steps = sch["timesteps"]
     b = x_T.shape[0]
@@ -154,6 +169,9 @@ def plms_sample(apply_model, alphas_cumprod, S, x_T, cond, scale=1.0, uc=None, l
         index = total - i - 1
         ts = torch.full((b,), int(step), dtype=torch.long)
         ts_next = torch.full((b,), int(time_range[min(i + 1, len(time_range) - 1)]), dtype=torch.long)
+        if mask is not None:                          # plms.py:147-150
+            qn = q_noise_fn(x0.shape) if q_noise_fn is not None else torch.randn_like(x0)
+            img = q_sample_blend(img, x0, mask, alphas_cumprod, int(step), qn)
         e_t = _cfg_eps(apply_model, img, ts, cond, scale, uc)
         if len(old_eps) == 0:
             x_prev, _ = x_prev_pred(img, e_t, index)
@@ -176,7 +194,8 @@ def plms_sample(apply_model, alphas_cumprod, S, x_T, cond, scale=1.0, uc=None, l
 
 
 @torch.no_grad()
-def ddpm_sample(apply_model, sched, x_T, cond, timesteps=None, noise_fn=None, log_every_t=200):
+def ddpm_sample(apply_model, sched, x_T, cond, timesteps=None, noise_fn=None, log_every_t=200, mask=None, x0=None,
+                q_noise_fn=None):
     """Ancestral sampling, no CFG (ddpm.py:1201-1250, p_sample :1115-1143, p_mean_variance :1083-1112,
     clip_denoised False for LatentDiffusion, ddpm.py:475)."""
     T = sched["betas"].shape[0] if timesteps is None else timesteps
@@ -193,6 +212,10 @@ def ddpm_sample(apply_model, sched, x_T, cond, timesteps=None, noise_fn=None, lo
         noise = noise_fn(img.shape) if noise_fn is not None else torch.randn(img.shape)
         nonzero = (1 - (ts == 0).float()).reshape(b, 1, 1, 1)
         img = mean + nonzero * (0.5 * logvar).exp() * noise
+        if mask is not None:                          # ddpm.py:1239-1241 (after the step)
+            qn = q_noise_fn(x0.shape) if q_noise_fn is not None else torch.randn_like(x0)
+            img = (ex(sched["sqrt_alphas_cumprod"], ts) * x0 + ex(sched["sqrt_one_minus_alphas_cumprod"], ts) * qn) * mask \
+                + (1.0 - mask) * img
         if i % log_every_t == 0 or i == T - 1:
             inter.append(img)
     return img, inter

@@ -358,6 +358,43 @@ def configs():
     save("g8_full_configs.npz", **out)
 
 
+def inpaint(seed=0):
+    """G10: inpainting (mask / x0) through the reference samplers, tiny config: DDIM-6 and PLMS-6 with CFG 4.5, ancestral 4 steps.
+    q_sample's torch.randn_like(x0) (ddpm.py:279-282) is fed from its own seeded generator so that the sequence can be replayed
+    (the samplers' other noise draws stay on the global generator)."""
+    spec = synth.state_dict_spec(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
+    sd = synth.make_state_dict(spec, seed)
+    cfg = ref_import.load_ldm_config(unet=synth.UNET_TINY, vae=synth.VAE_TINY, cond=synth.COND_TINY)
+    model, ns = ref_import.build_reference_ldm(cfg, sd)
+    B = 2
+    xT = synth.synthetic_xT(B, seed=21)
+    feats = synth.synthetic_cavp(B, 32, 64, seed=1234)
+    x0 = rnd((B, 4, 16, 64), 301)
+    mask = torch.ones(B, 1, 16, 64)
+    mask[:, :, 4:12, 16:48] = 0.0                 # keep the border, regenerate the centre (ddpm.py:1478-1481)
+    gq = torch.Generator().manual_seed(4242)
+    real = torch.randn_like
+    torch.randn_like = lambda t, **kw: torch.randn(t.shape, generator=gq)
+    out = {"x0": x0, "mask": mask, "q_seed": np.int64(4242)}
+    try:
+        with torch.no_grad():
+            c = model.get_learned_conditioning(feats)
+            uc = torch.zeros_like(c)
+            for name in ("DDIM", "PLMS"):
+                gq.manual_seed(4242)
+                z, _ = model.sample_log_diff_sampler(c, B, name, 6, unconditional_guidance_scale=4.5, unconditional_conditioning=uc,
+                                                     x_T=xT.clone(), mask=mask, x0=x0)
+                out[f"{name}_6_z"] = z
+            gq.manual_seed(4242)
+            torch.manual_seed(77)
+            z, _ = model.sample(c, batch_size=B, return_intermediates=True, x_T=xT.clone(), timesteps=4, shape=(B, 4, 16, 64),
+                                verbose=False, mask=mask, x0=x0)
+            out["ancestral_4_z"] = z
+    finally:
+        torch.randn_like = real
+    save("g10_tiny_inpaint.npz", **out)
+
+
 def full_extra(seed=0):
     """G5 extension (round 3): reference DDIM-25 trajectories for seeds 23 and 24, so that a full 25-step B=4 run of BASELINE
     configs[1] can be compared ROW BY ROW with four B=1 reference runs (seeds 21..24; samples are independent, so row i of
@@ -390,6 +427,7 @@ if __name__ == "__main__":
     ap.add_argument("--cavp", action="store_true", help="CAVP video encoder vectors (reference topology, mmcv stand-in)")
     ap.add_argument("--video", action="store_true", help="G9: frame pre-processing vectors (Pillow's own resize outputs)")
     ap.add_argument("--configs", action="store_true", help="G8: BASELINE configs[2] / configs[4] at full size (~8 min)")
+    ap.add_argument("--inpaint", action="store_true", help="G10: mask / x0 inpainting through DDIM, PLMS and the ancestral sampler (tiny)")
     ap.add_argument("--full-extra", action="store_true", help="G5 extension: DDIM-25 reference runs for seeds 23 / 24 (~4 min)")
     a = ap.parse_args()
     torch.set_num_threads(8)
@@ -405,3 +443,5 @@ if __name__ == "__main__":
         configs()
     if a.full_extra:
         full_extra()
+    if a.inpaint:
+        inpaint()

@@ -10,12 +10,20 @@ import diff_foley_amd as P
 from diff_foley_amd import samplers as S, synth
 
 
-@pytest.mark.parametrize("kw", [dict(mask=torch.ones(1)), dict(x0=torch.zeros(1)), dict(quantize_x0=True),
-                                dict(score_corrector=object()), dict(noise_dropout=0.1), dict(corrector_kwargs={"a": 1})])
+@pytest.mark.parametrize("kw", [dict(quantize_x0=True), dict(score_corrector=object()), dict(noise_dropout=0.1),
+                                dict(corrector_kwargs={"a": 1})])
 def test_unsupported_sampler_kwargs_raise(kw):
-    """ddim.py:58-113 accepts these; they select inpainting / VQ / score-correction code that is not built here."""
+    """ddim.py:58-113 accepts these; they select VQ / score-correction code that is not built here.  (mask / x0 -- inpainting --
+    ARE on the path since round 3: tests/test_path_gpu.py::test_tiny_inpainting_vs_golden.)"""
     with pytest.raises(NotImplementedError):
         S.reject_unsupported("DDIMSampler", kw)
+
+
+def test_dpm_solver_refuses_the_mask_its_reference_drops():
+    """dpm_solver/sampler.py:24-56 takes mask / x0 and never uses them: an inpainting request would silently come back as a plain
+    sample, so it raises here."""
+    with pytest.raises(NotImplementedError):
+        S.reject_unsupported("DPMSolverSampler", dict(mask=torch.ones(1, 1, 16, 64)), dict(mask=None, x0=None))
 
 
 def test_default_and_unknown_kwargs_pass():

@@ -125,6 +125,31 @@ def test_g5_tiny_samplers():
     close(z, g["ancestral_6_z"], tol)
 
 
+def test_g10_tiny_inpainting():
+    """mask / x0 through the oracle's DDIM, PLMS and ancestral loops against the reference's own inpainting runs (G10): the
+    known region is re-noised with q_sample(x0, t) every step and pasted over the sample (ddim.py:206-209, plms.py:147-150,
+    ddpm.py:1239-1241).  q_sample's noise is replayed from the generator the golden script fed it from."""
+    g = gold("g10_tiny_inpaint.npz")
+    apply_model, xT, c, uc, vsd = _tiny_sampling_setup()
+    acp = osch.ddpm_schedule()["alphas_cumprod"]
+    x0, mask = g["x0"], g["mask"]
+    gq = torch.Generator()
+    qn = lambda shape: torch.randn(tuple(shape), generator=gq)
+    tol = 2e-4
+    gq.manual_seed(int(g["q_seed"]))
+    z, _ = osamp.ddim_sample(apply_model, acp, 6, xT, c, 4.5, uc, mask=mask, x0=x0, q_noise_fn=qn)
+    close(z, g["DDIM_6_z"], tol)
+    gq.manual_seed(int(g["q_seed"]))
+    z, _ = osamp.plms_sample(apply_model, acp, 6, xT, c, 4.5, uc, mask=mask, x0=x0, q_noise_fn=qn)
+    close(z, g["PLMS_6_z"], tol)
+    gq.manual_seed(int(g["q_seed"]))
+    torch.manual_seed(77)
+    z, _ = osamp.ddpm_sample(apply_model, osch.ddpm_schedule(), xT, c, timesteps=4, mask=mask, x0=x0, q_noise_fn=qn)
+    close(z, g["ancestral_4_z"], tol)
+    # the masked-in region of the result is dominated by x0 only through the last blend: sanity of the mask's orientation
+    assert float((z - xT).abs().mean()) > 0
+
+
 def test_g6_tiny_classifier_and_double_guidance():
     g = gold("g6_tiny_classifier.npz")
     csd = ou.sub_state_dict(tiny_classifier_sd(), "model.")

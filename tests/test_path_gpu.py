@@ -162,6 +162,42 @@ def test_tiny_ancestral_sampler_vs_golden(tiny):
     assert rel_l2(z.cpu(), g["ancestral_6_z"]) < TRAJ_TOL
 
 
+def test_tiny_inpainting_vs_golden(tiny):
+    """mask / x0 (inpainting) through the product samplers against the reference's own runs (G10, tests/golden/make_golden.py
+    --inpaint): DDIM and PLMS with CFG, the ancestral sampler, and the DPM-Solver sampler refusing what its reference drops.
+    The blend runs in df_q_sample_blend (csrc/elementwise.hip); q_sample's noise is replayed through the q_noise_fn hook."""
+    g = gold("g10_tiny_inpaint.npz")
+    from diff_foley_amd import synth
+    B = 2
+    xT = synth.synthetic_xT(B, seed=21)
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+    uc = torch.zeros_like(c)
+    x0, mask = g["x0"], g["mask"]
+    gq = torch.Generator()
+    qn = lambda shape: torch.randn(tuple(shape), generator=gq)
+    for name in ("DDIM", "PLMS"):
+        gq.manual_seed(int(g["q_seed"]))
+        z, _ = tiny.sample_log_diff_sampler(c, B, name, 6, unconditional_guidance_scale=4.5, unconditional_conditioning=uc,
+                                            x_T=xT.clone(), mask=mask, x0=x0, q_noise_fn=qn)
+        assert rel_l2(z.cpu(), g[f"{name}_6_z"]) < TRAJ_TOL, name
+    gq.manual_seed(int(g["q_seed"]))
+    torch.manual_seed(77)
+    z, _ = tiny.sample(c, batch_size=B, return_intermediates=True, x_T=xT.clone(), timesteps=4, shape=(B, 4, 16, 64),
+                       noise_fn=lambda s: torch.randn(s), mask=mask, x0=x0, q_noise_fn=qn)
+    assert rel_l2(z.cpu(), g["ancestral_4_z"]) < TRAJ_TOL
+    # a [B][C][H][W] mask gives the same result as the broadcast [B][1][H][W] one; without a hook the noise is drawn on the device
+    gq.manual_seed(int(g["q_seed"]))
+    z2, _ = tiny.sample_log_diff_sampler(c, B, "DDIM", 6, unconditional_guidance_scale=4.5, unconditional_conditioning=uc,
+                                         x_T=xT.clone(), mask=mask.expand(B, 4, 16, 64), x0=x0, q_noise_fn=qn)
+    assert rel_l2(z2.cpu(), g["DDIM_6_z"]) < TRAJ_TOL
+    z3, _ = tiny.sample_log_diff_sampler(c, B, "DDIM", 6, x_T=xT.clone(), mask=mask, x0=x0)
+    assert torch.isfinite(z3).all()
+    with pytest.raises(NotImplementedError):
+        tiny.sample_log_diff_sampler(c, B, "DPM_Solver", 6, x_T=xT.clone(), mask=mask, x0=x0)
+    with pytest.raises(AssertionError):
+        tiny.sample_log_diff_sampler(c, B, "DDIM", 6, x_T=xT.clone(), mask=mask)          # mask without x0: like the reference
+
+
 def test_tiny_ddim_eta_and_intermediates_shape(tiny):
     """eta > 0 draws noise on the device; only shapes/finite-ness and the log_every_t bookkeeping are checked."""
     from diff_foley_amd import synth
