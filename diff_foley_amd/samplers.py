@@ -58,7 +58,10 @@ class _Inpaint:
         mask = mask.to(dev, torch.float32)
         if mask.dim() == 3:
             mask = mask[:, None]
-        assert x0.shape[2:3] == mask.shape[2:3]                # "spatial size has to match" (ddpm.py:1227)
+        if mask.dim() != 4 or x0.dim() != 4 or mask.shape[1] not in (1, C) or tuple(mask.shape[2:]) not in ((H, W), (1, 1)) or \
+                mask.shape[0] not in (1, B) or tuple(x0.shape[1:]) != (C, H, W) or x0.shape[0] not in (1, B):
+            raise ValueError(f"inpainting: mask {tuple(mask.shape)} / x0 {tuple(x0.shape)} do not broadcast to the latent "
+                             f"{(B, C, H, W)} (mask [B][1|C][H][W], x0 [B][C][H][W])")
         mc = C if mask.shape[1] == C and C != 1 else 1
         self.mask = mask.expand(B, mc, H, W).contiguous()      # broadcast copy, no arithmetic
         self.x0 = x0.expand(B, C, H, W).contiguous()

@@ -582,6 +582,9 @@ def test_notebook_cells_replayed_verbatim(P):
     # unsupported reference kwargs raise instead of being dropped
     with pytest.raises(NotImplementedError):
         latent_diffusion_model.sample_log_diff_sampler(embed_cond_feat, batch_size=sample_num, sampler_name="DDIM",
+                                                       ddim_steps=5, quantize_x0=True)
+    with pytest.raises(ValueError, match="mask"):         # inpainting is on the path; a mask that is no [B][1|C][H][W] map is refused
+        latent_diffusion_model.sample_log_diff_sampler(embed_cond_feat, batch_size=sample_num, sampler_name="DDIM",
                                                        ddim_steps=5, mask=torch.ones(1), x0=torch.zeros(1))
     with pytest.raises(AssertionError):
         latent_diffusion_model.sample_log_diff_sampler(embed_cond_feat, batch_size=sample_num, sampler_name="DPM_Solver",
