@@ -215,6 +215,28 @@ hipError_t launch_pack_conv3d_bn(const float* w, const float* gamma, const float
                      out, bias, O, I, KT, KH, KW, KP);
   return hipGetLastError();
 }
+// nn.MaxPool1d(kernel_size = k) over the frame axis of [B][T][C] features (stride k, floor: T / k windows), cavp_model.py:31, 58-59
+__global__ void maxpool_time_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int T, int C, int k) {
+  const int To = T / k;
+  const long n = (long)B * To * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long bt = i / C;
+    const int to = (int)(bt % To), b = (int)(bt / To);
+    const float* p = x + ((long)b * T + (long)to * k) * C + c;
+    float m = p[0];
+    for (int j = 1; j < k; ++j) m = fmaxf(m, p[(long)j * C]);
+    out[i] = m;
+  }
+}
+
+hipError_t launch_maxpool_time(const float* x, float* out, int B, int T, int C, int k, hipStream_t s) {
+  if (B <= 0 || C <= 0 || k <= 0 || T < k) return hipErrorInvalidValue;
+  const long n = (long)B * (T / k) * C;
+  hipLaunchKernelGGL(maxpool_time_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, s, x, out, B, T, C, k);
+  return hipGetLastError();
+}
+
 hipError_t launch_l2norm_rows(float* x, int rows, int C, hipStream_t s) {
   hipLaunchKernelGGL(l2norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, C);
   return hipGetLastError();

@@ -2750,6 +2750,13 @@ int df_cavp_encode(df_ctx* c, const float* video, float* out, int B, int T, int 
   });
 }
 
+int df_cavp_pool(const float* feat, float* out, int B, int T, int C, int kernel, int normalize, void* stream) {
+  return guard([&] {
+    HIPCHK(launch_maxpool_time(feat, out, B, T, C, kernel, (hipStream_t)stream));
+    if (normalize) HIPCHK(launch_l2norm_rows(out, B * (T / kernel), C, (hipStream_t)stream));
+  });
+}
+
 int df_cond_encode(df_ctx* c, const float* feats, float* out, int B, int T, void* stream) {
   return guard([&] {
     if (!c->has_cond) fail("cond stage not configured");

@@ -140,6 +140,8 @@ hipError_t launch_tcat3(const uint16_t* x, uint16_t* out, int F, int T, int HW, 
 hipError_t launch_pack_conv3d_bn(const float* w, const float* gamma, const float* beta, const float* mean,
                                  const float* var, float eps, uint16_t* out, float* bias, int O, int I, int KT, int KH,
                                  int KW, int KP, hipStream_t s);
+// MaxPool1d(k) over the frame axis of [B][T][C] -> [B][T/k][C] (CAVP contrastive head, cavp_model.py:31, 58-59)
+hipError_t launch_maxpool_time(const float* x, float* out, int B, int T, int C, int k, hipStream_t s);
 hipError_t launch_l2norm_rows(float* x, int rows, int C, hipStream_t s);
 
 // Frame pre-processing in front of the CAVP encoder (Extract_CAVP_Features.forward, demo_util.py:100-104, 150-151):

@@ -52,6 +52,7 @@ _SIGS = {
     "df_config_cond": [C.c_void_p, C.POINTER(CondConfig)],
     "df_config_cavp": [C.c_void_p, C.POINTER(CavpConfig)],
     "df_cavp_encode": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "df_cavp_pool": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "df_config_classifier": [C.c_void_p, C.POINTER(UNetConfig)],
     "df_load_tensor": [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int],
     "df_load_tensor_dev": [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int],
@@ -255,6 +256,21 @@ class Engine:
         out = torch.empty(B, T, self.cavp_embed_dim, device=self.device, dtype=torch.float32)
         _chk(self.L.df_cavp_encode(self._h, _ptr(video), _ptr(out), B, T, H, W, int(bool(normalize)), _stream()), self.L)
         return out
+
+    def cavp_encode_pooled(self, video, normalize=True, kernel=16):
+        """encode_video(pool=True) (cavp_model.py:58-59): MaxPool1d(16) over the frames of the projected features, then the
+        optional L2 normalisation; (B, T // 16, embed), squeezed to (B, embed) for one window like the reference's squeeze(2)."""
+        feat = self.cavp_encode(video, normalize=False)
+        B, T, Cc = feat.shape
+        if T < kernel:
+            raise RuntimeError(f"encode_video(pool=True): {T} frames are fewer than the MaxPool1d window of {kernel}")
+        if normalize and T // kernel > 1:
+            # F.normalize(dim=-1) then runs over the WINDOW axis of the reference's (B, C, T // 16) tensor (squeeze(2) is a no-op
+            # there) -- a shape the contrastive head is never used with; refused rather than guessed
+            raise NotImplementedError("encode_video(pool=True, normalize=True) is defined for one 16-frame window (16..31 frames)")
+        out = torch.empty(B, T // kernel, Cc, device=self.device, dtype=torch.float32)
+        _chk(self.L.df_cavp_pool(_ptr(feat), _ptr(out), B, T, Cc, kernel, int(bool(normalize)), _stream()), self.L)
+        return out[:, 0] if out.shape[1] == 1 else out.permute(0, 2, 1)      # reference layout before squeeze(2): (B, C, T/16)
 
     def load_tensor(self, name, t):
         shape = (C.c_int64 * t.dim())(*t.shape)

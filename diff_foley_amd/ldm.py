@@ -403,9 +403,9 @@ class CAVPInference:
 
     @torch.no_grad()
     def encode_video(self, video, normalize=False, train=False, pool=True):
-        """video (B,T,3,H,W) -> (B,T,embed_dim) for pool=False (cavp_model.py:47-65).  pool=True is the training-time
-        MaxPool1d(16) contrastive head (cavp_model.py:58-59), not used by Stage-2 inference."""
+        """video (B,T,3,H,W) -> (B,T,embed_dim) for pool=False (cavp_model.py:47-65; what Stage-2 inference calls,
+        demo_util.py:161); pool=True adds the contrastive head's MaxPool1d(16) over the frames before the optional normalisation
+        (cavp_model.py:58-59): (B, embed_dim) for 16..31 frames."""
         if pool:
-            raise NotImplementedError("encode_video(pool=True) is the contrastive-training head; inference calls "
-                                      "pool=False (inference/demo_util.py:161)")
+            return self._require().cavp_encode_pooled(video, normalize=normalize)
         return self._require().cavp_encode(video, normalize=normalize)

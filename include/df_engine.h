@@ -102,6 +102,11 @@ int df_cond_encode(df_ctx* ctx, const float* feats_dev, float* out_dev, int B, i
 int df_cavp_encode(df_ctx* ctx, const float* video_dev, float* out_dev, int B, int T, int H, int W, int normalize,
                    void* stream);
 
+/* The pooled form, encode_video(..., pool=True) (cavp_model.py:58-59: nn.MaxPool1d(kernel_size=16) over the frame axis of the
+ * projected features, then the optional F.normalize): feat [B][T][C] fp32 (df_cavp_encode with normalize = 0) -> out
+ * [B][T / kernel][C], rows L2-normalised when normalize != 0. */
+int df_cavp_pool(const float* feat_dev, float* out_dev, int B, int T, int C, int kernel, int normalize, void* stream);
+
 /* ---- UNetModel.forward (openai_unetmodel.py:710-742) through LatentDiffusion.apply_model (ddpm.py:925-1026).
  * The cross-attention context is step-invariant, so it is set once per sample() call: everything of the 16
  * SpatialTransformers' cross-attention that depends on the context only is computed here, not per step -- the K/V

@@ -50,8 +50,26 @@ def test_cavp_tiny_vs_golden_and_oracle(prec):
     _check(f2, ref, prec, "tiny 2x5x96 oracle")
     f1 = m.encode_video(v2[1:].cuda(), normalize=True, pool=False)
     assert torch.equal(f1[0], f2[1])            # same plan, same clip -> bit-identical
-    with pytest.raises(NotImplementedError):
-        m.encode_video(v.cuda(), normalize=True, pool=True)
+    # pool=True (cavp_model.py:58-59): MaxPool1d(16) over the frames of the projected features, then the normalisation --
+    # checked against torch's own max_pool1d / normalize applied to the un-pooled features of the same clip
+    with pytest.raises(RuntimeError, match="fewer than"):
+        m.encode_video(v.cuda(), normalize=True, pool=True)             # 4 frames < one window of 16
+    v3 = synth.synthetic_video(2, 35, 64, seed=9)
+    raw = m.encode_video(v3.cuda(), normalize=False, pool=False).cpu()
+    want = torch.nn.functional.max_pool1d(raw.permute(0, 2, 1), 16).squeeze(2)           # (B, C, 2): two windows, 3 frames dropped
+    got = m.encode_video(v3.cuda(), normalize=False, pool=True).cpu()
+    assert got.shape == want.shape == (2, synth.CAVP_TINY["embed_dim"], 2)
+    assert torch.equal(got, want)
+    with pytest.raises(NotImplementedError):       # the reference would normalise across the two windows there
+        m.encode_video(v3.cuda(), normalize=True, pool=True)
+    raw1 = m.encode_video(v3[:, :20].cuda(), normalize=False, pool=False).cpu()          # one window: squeeze(2) -> (B, C)
+    for norm in (False, True):
+        want = torch.nn.functional.max_pool1d(raw1.permute(0, 2, 1), 16).squeeze(2)
+        if norm:
+            want = torch.nn.functional.normalize(want, dim=-1)
+        got = m.encode_video(v3[:, :20].cuda(), normalize=norm, pool=True).cpu()
+        assert got.shape == want.shape == (2, synth.CAVP_TINY["embed_dim"])
+        assert torch.allclose(got, want, rtol=0, atol=1e-6), float((got - want).abs().max())
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
