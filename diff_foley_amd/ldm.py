@@ -64,13 +64,75 @@ def instantiate_from_config(config):
     return getattr(importlib.import_module(module), cls)(**dict(config.get("params", dict())))
 
 
-class _Unsupported:
-    def __init__(self, what):
-        self.what = what
+class _Facade:
+    """Stands where the reference has a sub-module: the forward entry points code outside the samplers calls
+    (`model.model.diffusion_model(x, t, context=c)`, `model.first_stage_model.decode(z)`, `model.cond_stage_model(feats)`) run
+    on the engine; anything that needs the nn.Module tree itself (parameters, children, weights) raises like before -- the
+    weights live in packed HBM buffers owned by libdfengine.so."""
+    _what = "module"
+
+    def __init__(self, owner):
+        object.__setattr__(self, "_m", owner)
 
     def __getattr__(self, name):
-        raise AttributeError(f"{self.what}.{name}: module tree is not materialised in diff_foley_amd "
+        raise AttributeError(f"{self._what}.{name}: module tree is not materialised in diff_foley_amd "
                              "(weights live in packed HBM buffers owned by libdfengine.so)")
+
+    def eval(self):
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+
+class _UNetFacade(_Facade):
+    """UNetModel.forward(x, timesteps, context) (openai_unetmodel.py:710-742)."""
+    _what = "model.diffusion_model"
+
+    def __call__(self, x, timesteps=None, context=None, y=None, **kwargs):
+        if y is not None:
+            raise NotImplementedError("class-conditional UNet (y=) is not on the path")
+        return self._m.apply_model(x, timesteps, context)
+
+
+class _DiffusionWrapperFacade(_Facade):
+    """DiffusionWrapper (ddpm.py:1545-1571), conditioning_key 'crossattn'."""
+    _what = "model"
+
+    def __init__(self, owner):
+        super().__init__(owner)
+        object.__setattr__(self, "diffusion_model", _UNetFacade(owner))
+        object.__setattr__(self, "conditioning_key", "crossattn")
+
+    def __call__(self, x, t, c_concat=None, c_crossattn=None):
+        if c_concat:
+            raise NotImplementedError("only conditioning_key='crossattn' is on the path")
+        cc = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(list(c_crossattn), 1)
+        return self.diffusion_model(x, t, context=cc)
+
+
+class _FirstStageFacade(_Facade):
+    """AutoencoderKL.decode(z) (autoencoder.py: post_quant_conv -> decoder), i.e. decode_first_stage without its 1/scale_factor."""
+    _what = "first_stage_model"
+
+    def decode(self, z):
+        m = self._m
+        zs = E.lincomb([(float(m.scale_factor), E._dev_f32(z, m.device))])      # decode_first_stage(z * s) == decode(z)
+        return m.decode_first_stage(zs)
+
+    def encode(self, x):
+        raise NotImplementedError("the VAE encoder is not on the sampling path (only post_quant_conv + decoder are loaded)")
+
+
+class _CondStageFacade(_Facade):
+    """cond_stage_model(feats) / .encode(feats) as get_learned_conditioning calls it (ddpm.py:568-579)."""
+    _what = "cond_stage_model"
+
+    def __call__(self, c):
+        return self._m.get_learned_conditioning(c)
+
+    def encode(self, c):
+        return self._m.get_learned_conditioning(c)
 
 
 class LatentDiffusion:
@@ -109,9 +171,9 @@ class LatentDiffusion:
         self._state = None
         self._ctx_owner = None
         self.training = False
-        self.first_stage_model = _Unsupported("first_stage_model")
-        self.cond_stage_model = _Unsupported("cond_stage_model")
-        self.model = _Unsupported("model")
+        self.first_stage_model = _FirstStageFacade(self)
+        self.cond_stage_model = _CondStageFacade(self)
+        self.model = _DiffusionWrapperFacade(self)
 
     # ------------------------------------------------------------------ nn.Module-like plumbing
     def load_state_dict(self, state_dict, strict=False):

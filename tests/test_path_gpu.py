@@ -198,6 +198,32 @@ def test_tiny_inpainting_vs_golden(tiny):
         tiny.sample_log_diff_sampler(c, B, "DDIM", 6, x_T=xT.clone(), mask=mask)          # mask without x0: like the reference
 
 
+def test_module_facades_run_the_engine(tiny):
+    """Code outside the samplers reaches the sub-modules by name (ddim.py:18, 186; ddpm.py:568-579, 739-797, 1552-1571):
+    model.model.diffusion_model(x, t, context=c), model.model(x, t, c_crossattn=[c]), first_stage_model.decode(z),
+    cond_stage_model(feats) run on the engine and agree with apply_model / decode_first_stage / get_learned_conditioning;
+    the module tree itself (parameters, weights) is not there and says so."""
+    x, c = rnd((2, 4, 16, 64), 102).cuda(), rnd((2, 32, 128), 101).cuda()
+    t = torch.tensor([500, 37]).cuda()
+    y = tiny.apply_model(x, t, c)
+    assert torch.equal(tiny.model.diffusion_model(x, t, context=c), y)
+    assert torch.equal(tiny.model(x, t, c_crossattn=[c]), y)
+    assert tiny.model.conditioning_key == "crossattn"
+    z = rnd((1, 4, 16, 64), 103).cuda()
+    want = tiny.decode_first_stage(z)
+    got = tiny.first_stage_model.decode(z / tiny.scale_factor)
+    assert rel_l2(got.cpu(), want.cpu()) < 1e-5
+    feats = rnd((2, 32, 64), 104).cuda()
+    assert torch.equal(tiny.cond_stage_model(feats), tiny.get_learned_conditioning(feats))
+    assert torch.equal(tiny.cond_stage_model.encode(feats), tiny.get_learned_conditioning(feats))
+    with pytest.raises(AttributeError, match="not materialised"):
+        tiny.model.diffusion_model.input_blocks
+    with pytest.raises(AttributeError, match="not materialised"):
+        tiny.first_stage_model.decoder
+    with pytest.raises(NotImplementedError):
+        tiny.first_stage_model.encode(z)
+
+
 def test_tiny_ddim_eta_and_intermediates_shape(tiny):
     """eta > 0 draws noise on the device; only shapes/finite-ness and the log_every_t bookkeeping are checked."""
     from diff_foley_amd import synth
