@@ -29,8 +29,7 @@ def _warn_batch(conditioning, batch_size):
 # Reference sampler features that are NOT on this path.  The reference classes accept them (ddim.py:58-113, 179-273;
 # plms.py:60-110; dpm_solver/sampler.py:24-56); silently dropping one would return a plausible but wrong sample, so a
 # non-default value raises.  Anything not listed is ignored exactly like the reference's own **kwargs.
-_UNSUPPORTED_DEFAULTS = dict(quantize_x0=False, score_corrector=None, corrector_kwargs=None,
-                             noise_dropout=0.0, normals_sequence=None)
+_UNSUPPORTED_DEFAULTS = dict(quantize_x0=False, noise_dropout=0.0, normals_sequence=None)
 
 
 def reject_unsupported(sampler, kwargs, extra=None):
@@ -124,8 +123,11 @@ class DDIMSampler(object):
     def sample(self, S, batch_size, shape, conditioning=None, eta=0.0, x_T=None, log_every_t=100,
                unconditional_guidance_scale=1.0, unconditional_conditioning=None, temperature=1.0,
                verbose=True, callback=None, img_callback=None, classifier=None, origin_cond=None,
-               classifier_guide_scale=0.0, mask=None, x0=None, **kwargs):
+               classifier_guide_scale=0.0, mask=None, x0=None, score_corrector=None, corrector_kwargs=None, **kwargs):
         reject_unsupported("DDIMSampler", kwargs)
+        if score_corrector is not None and classifier is not None:
+            # p_sample_ddim_with_classifier (ddim.py:276-396) takes the argument and never applies it
+            raise NotImplementedError("DDIMSampler: score_corrector is dropped by the reference's classifier-guided step")
         _warn_batch(conditioning, batch_size)
         self.make_schedule(S, ddim_eta=eta, verbose=verbose)
         dev = self.model.device
@@ -144,6 +146,9 @@ class DDIMSampler(object):
             if paint.on:                     # ddim.py:206-209
                 img = paint.blend(img, steps[i])
             e_t = eps_fn(img, t_all[i])
+            if score_corrector is not None:  # ddim.py:249-251 / 360-362: a caller-supplied callback on the guided eps
+                e_t = score_corrector.modify_score(self.model, e_t, img, t_all[i], conditioning, **(corrector_kwargs or {}))
+                e_t = E._dev_f32(e_t, dev)
             a_t, a_prev = tb.alphas[index], tb.alphas_prev[index]
             if classifier is not None:       # ddim.py:374-380
                 g = _classifier_grad(self.model, classifier, img, t_all[i], origin_cond)
@@ -176,7 +181,7 @@ class PLMSSampler(object):
     @torch.no_grad()
     def sample(self, S, batch_size, shape, conditioning=None, eta=0.0, x_T=None, log_every_t=100,
                unconditional_guidance_scale=1.0, unconditional_conditioning=None, verbose=True, callback=None,
-               img_callback=None, mask=None, x0=None, **kwargs):
+               img_callback=None, mask=None, x0=None, score_corrector=None, corrector_kwargs=None, **kwargs):
         if eta != 0:
             raise ValueError("ddim_eta must be 0 for PLMS")
         reject_unsupported("PLMSSampler", kwargs, dict(temperature=1.0))
@@ -186,7 +191,13 @@ class PLMSSampler(object):
         C, H, W = shape
         size = (batch_size, C, H, W)
         img = torch.randn(size, device=dev) if x_T is None else x_T.to(dev, torch.float32).contiguous()
-        eps_fn = _Guided(self.model, conditioning, unconditional_guidance_scale, unconditional_conditioning)
+        guided = _Guided(self.model, conditioning, unconditional_guidance_scale, unconditional_conditioning)
+
+        def eps_fn(x, t):                    # get_model_output (plms.py:178-190): guided eps, then the caller's score corrector
+            e = guided(x, t)
+            if score_corrector is not None:
+                e = E._dev_f32(score_corrector.modify_score(self.model, e, x, t, conditioning, **(corrector_kwargs or {})), dev)
+            return e
         steps = np.flip(tb.timesteps)
         total = steps.shape[0]
         t_all = torch.tensor(steps.copy(), dtype=torch.float32, device=dev)[:, None].expand(total, batch_size).contiguous()
@@ -235,7 +246,7 @@ class DPMSolverSampler(object):
                unconditional_conditioning=None, classifier=None, origin_cond=None, classifier_guide_scale=0.0,
                **kwargs):
         # the reference ignores eta / temperature here (sampler.py:24-56 passes neither to DPM_Solver): same
-        reject_unsupported("DPMSolverSampler", kwargs, dict(mask=None, x0=None))      # sampler.py:24-56 accepts and drops them
+        reject_unsupported("DPMSolverSampler", kwargs, dict(mask=None, x0=None, score_corrector=None))   # sampler.py:24-56 accepts and drops them
         if S < 2:
             raise AssertionError("DPM-Solver++(2M) needs steps >= order = 2 (dpm_solver.py:1083 asserts steps >= order)")
         _warn_batch(conditioning, batch_size)

@@ -198,6 +198,46 @@ def test_tiny_inpainting_vs_golden(tiny):
         tiny.sample_log_diff_sampler(c, B, "DDIM", 6, x_T=xT.clone(), mask=mask)          # mask without x0: like the reference
 
 
+def test_score_corrector_callback(tiny):
+    """score_corrector.modify_score(model, e_t, x, t, c, **corrector_kwargs) (ddim.py:249-251, plms.py:186-188): a caller's
+    callback on the guided eps.  An identity corrector changes nothing; a scaling one gives the trajectory of the scaled eps
+    (checked against the oracle's DDIM loop driven by the product's own eps * k); the classifier-guided step, whose reference
+    drops the argument, refuses it."""
+    from diff_foley_amd import synth
+    B = 2
+    xT = synth.synthetic_xT(B, seed=21)
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+    uc = torch.zeros_like(c)
+    calls = []
+
+    class Corr:
+        def __init__(self, k):
+            self.k = k
+
+        def modify_score(self, model, e_t, x, t, cond, gain=1.0):
+            calls.append((tuple(e_t.shape), float(t[0]), gain))
+            assert model is tiny and cond is c
+            return e_t * (self.k * gain)
+    kw = dict(unconditional_guidance_scale=4.5, unconditional_conditioning=uc)
+    for name in ("DDIM", "PLMS"):
+        z0, _ = tiny.sample_log_diff_sampler(c, B, name, 6, x_T=xT.clone(), **kw)
+        calls.clear()
+        z1, _ = tiny.sample_log_diff_sampler(c, B, name, 6, x_T=xT.clone(), score_corrector=Corr(1.0), **kw)
+        assert torch.equal(z0, z1) and len(calls) == (7 if name == "DDIM" else 8)      # S = 6 -> 7 steps; PLMS: +1 eps at step 0
+    calls.clear()
+    z2, _ = tiny.sample_log_diff_sampler(c, B, "DDIM", 6, x_T=xT.clone(), score_corrector=Corr(0.5),
+                                         corrector_kwargs=dict(gain=1.5), **kw)
+    assert all(g == 1.5 for _, _, g in calls)
+    from oracle import samplers as osamp, schedule as osch
+    eps = lambda x, t, cc: (tiny.model.diffusion_model(x.cuda(), t.cuda().float(), context=cc.cuda()).cpu())
+    zo, _ = osamp.ddim_sample(lambda x, t, cc: 0.75 * eps(x, t, cc), osch.ddpm_schedule()["alphas_cumprod"], 6, xT, c.cpu(), 4.5, uc.cpu())
+    assert rel_l2(z2.cpu(), zo) < 2e-3
+    with pytest.raises(NotImplementedError):
+        tiny.sample_log_with_classifier_diff_sampler(c, origin_cond=synth.synthetic_cavp(B, 33, 64), batch_size=B,
+                                                     sampler_name="DDIM", ddim_steps=4, classifier=object(),
+                                                     classifier_guide_scale=1.0, score_corrector=Corr(1.0), **kw)
+
+
 def test_module_facades_run_the_engine(tiny):
     """Code outside the samplers reaches the sub-modules by name (ddim.py:18, 186; ddpm.py:568-579, 739-797, 1552-1571):
     model.model.diffusion_model(x, t, context=c), model.model(x, t, c_crossattn=[c]), first_stage_model.decode(z),
