@@ -156,11 +156,16 @@ def run_mode(precision, sd_dev, a, dev, rank, world, lo, hi, barrier, dump_ops="
     tb = DDIMTables(model.alphas_cumprod, 25)
     steps = np.flip(tb.timesteps)
     t_all = torch.tensor(steps.copy(), dtype=torch.float32, device=dev)[:, None].expand(25, B).contiguous()
+    # like the context, the time embedding of the 25 steps is announced before the loop (what DDIMSampler.sample does):
+    # it depends on t only; a step then looks its row up (df_unet_set_timesteps / df_unet_forward_cfg_ts)
+    hoist = not a.no_time_hoist
+    if hoist:
+        eng.set_timesteps([float(v) for v in steps], B, 16, 64, True)
 
     def step(i, x):
         i = i % 25
         idx = 25 - i - 1
-        e = eng.unet_forward_cfg(x, t_all[i], 4.5)
+        e = eng.unet_forward_cfg(x, t_all[i], 4.5, ts_index=i if hoist else None)
         xn, _ = E.ddim_update(x, e, tb.alphas[idx], tb.alphas_prev[idx], 0.0, tb.sqrt_one_minus_alphas[idx])
         return xn
 
@@ -253,6 +258,24 @@ def vae_roofline(model, dev, B):
             "bound": "mfma (1005 FLOP/B algorithmic) -- measured far below both ceilings: see profiles/"}
 
 
+def self_launch(n):
+    """Re-executes this script as n ranks of one node: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` (the form the driver uses for N > 1)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,10 +292,17 @@ def main():
                          "the operand type that meets the north-star bound (mel MAE < 1e-3 absolute); bf16 = the literal "
                          "wording of BASELINE configs[1], reported beside it in `modes` (mel MAE 4e-3)")
     ap.add_argument("--dump-ops", default="", help="write a per-op CSV of the instrumented pass")
+    ap.add_argument("--no-time-hoist", action="store_true",
+                    help="compute the time embedding inside every step (4 launches) instead of once per sample() call")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, torch.distributed.run on a free
+        # local port); rank 0 of that job prints the one JSON line, which passes through this process's stdout
+        return self_launch(a.gpus)
     rank, world, local = parallel.init_process_group()
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} (launcher and flag disagree)")
     dev = torch.device("cuda", local)
     B = a.batch
     G = B * world                                           # weak scaling: fixed per-GPU batch
@@ -316,6 +346,9 @@ def main():
                                       "operand type that meets mel MAE < 1e-3 -- the bf16 build is timed in `modes`)")
                                    + " UNet, 32 CAVP context frames, latent 4x16x64, guidance 4.5",
                        "batch_per_gpu": B, "global_batch": G, "parallelism": f"batch-shard x{world}, no step-loop collectives",
+                       "time_embedding": ("inside every step" if a.no_time_hoist else
+                                          "hoisted: all 25 timesteps by df_unet_set_timesteps before the loop, as DDIMSampler.sample "
+                                          "does (depends on t only, like the context operands); a step does one table look-up"),
                        "weight_distribution": main_run["dist"],
                        "engine_setup_s": round(main_run["t_setup"], 3)},
             "step_tflops_algorithmic": round(GFLOP_PER_SAMPLE * N / ms_step, 2),

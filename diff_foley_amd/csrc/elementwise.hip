@@ -637,6 +637,14 @@ __global__ void cfg_combine_kernel(const float* __restrict__ e2, float* __restri
   }
 }
 
+// dst[r][:] = src[:] for r < rows: one row of the hoisted time-embedding table (df_unet_set_timesteps) to every sample
+__global__ void bcast_rows_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int rows, int n4) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    const float4 v = src[i];
+    for (int r = 0; r < rows; ++r) dst[(long)r * n4 + i] = v;
+  }
+}
+
 struct LinArgs {
   const float* in[4];
   float coef[4];
@@ -1077,6 +1085,12 @@ hipError_t launch_pack_ln_linear(const float* w, const float* bias, const float*
 
 hipError_t launch_cfg_combine(const float* e2, float* e, long n, float scale, hipStream_t s) {
   hipLaunchKernelGGL(cfg_combine_kernel, dim3(grid_for(n)), dim3(256), 0, s, e2, e, n, scale);
+  return hipGetLastError();
+}
+
+hipError_t launch_bcast_rows(const float* src, float* dst, int rows, int n, hipStream_t s) {
+  if (n <= 0 || (n & 3) != 0 || rows <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bcast_rows_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, (const float4*)src, (float4*)dst, rows, n / 4);
   return hipGetLastError();
 }
 

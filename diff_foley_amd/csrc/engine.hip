@@ -63,6 +63,7 @@ struct RunArgs {
   float* out = nullptr;          // external output
   float* out2 = nullptr;         // optional second external output (classifier probability in the grad plan)
   float scale = 1.f;             // guidance scale
+  int ts_index = -1;             // >= 0: row of the plan's hoisted time-embedding table (df_unet_set_timesteps)
 };
 
 struct Op {
@@ -89,6 +90,15 @@ struct Plan {
   double gemm_flops = 0, weight_bytes = 0;
   size_t ext_hint = 0;           // largest external (caller-owned) buffer the plan touches, when above 32 MB (autotune dummies)
   size_t n_ctx = 0;              // UNet plans: ops [0, n_ctx) depend on the context only (run by df_unet_set_context)
+  // Hoisted time embedding: ops [op_t0, op_tl) map the timestep to the stacked emb projections E [N][etot] (they depend on t
+  // only); op_tl = "t.lookup" copies row ts_index of Etab [S][etot] to every row of E instead.  df_unet_set_timesteps fills the
+  // table by running [op_t0, op_tl) once per timestep of a sample() call; the step loop then runs [op_tl, end).
+  long op_t0 = -1, op_tl = -1;
+  float* E = nullptr;
+  int etot = 0, e_rows = 0, t_rows = 0;
+  float* Etab = nullptr;         // [etab_S][etot]
+  float* ttab = nullptr;         // [etab_S][t_rows] timesteps as the time ops read them
+  int etab_S = 0, etab_cap = 0;
   std::string name;              // cache key (debug labels)
   void* chk_list = nullptr;      // debug checksums: device array of (pointer, 32-bit words) of every workspace block
   int chk_n = 0;
@@ -96,6 +106,8 @@ struct Plan {
     for (auto& b : owned) (void)hipFree(b.p);
     if (partial) (void)hipFree(partial);
     if (chk_list) (void)hipFree(chk_list);
+    if (Etab) (void)hipFree(Etab);
+    if (ttab) (void)hipFree(ttab);
   }
   void* alloc(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
@@ -1269,6 +1281,7 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
   float* semb = b.buf<float>((size_t)N * temb);
   const int etot = c->emb_total[which];
   float* E = b.buf<float>((size_t)N * etot);
+  pl->op_t0 = (long)pl->ops.size();
   {
     const bf16_t* w0 = c->w_linear(pre + "time_embed.0.weight");
     const float* b0 = c->f32(pre + "time_embed.0.bias");
@@ -1333,6 +1346,18 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
       b.other("t.embproj", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(semb, temb, w, bb, E, etot, N, etot, temb, 0, s); });
     }
     pl->weight_bytes += 2.0 * etot * temb + 2.0 * (temb * mc + temb * temb);
+  }
+  if (!which && etot % 4 == 0) {
+    // the table look-up that replaces the ops above when the caller announced its timesteps (df_unet_set_timesteps): the time
+    // embedding depends on t only, so a sampler computes it for all S steps before the loop, like the context operands
+    pl->op_tl = (long)pl->ops.size();
+    pl->E = E; pl->etot = etot; pl->e_rows = N; pl->t_rows = B_ext;
+    Plan* plp = pl;
+    b.other("t.lookup", [=](hipStream_t s, const RunArgs& a) {
+      if (a.ts_index < 0) return hipSuccess;
+      if (!plp->Etab || a.ts_index >= plp->etab_S) return hipErrorInvalidValue;
+      return launch_bcast_rows(plp->Etab + (size_t)a.ts_index * etot, E, N, etot, s);
+    });
   }
 
   // ---- input packing: NCHW fp32 -> NHWC bf16 (channels padded to 64), CFG duplication folded in
@@ -2804,7 +2829,7 @@ int df_unet_set_context(df_ctx* c, const float* context, int N, int T, void* str
 }
 
 static void unet_run(df_ctx* c, const float* x, const float* t, float* out, int N, int H, int W, bool cfg, float scale,
-                     hipStream_t s) {
+                     hipStream_t s, int ts_index = -1) {
   if (c->ctx_N != N) fail("context has %d rows but the UNet batch is %d (call df_unet_set_context first)", c->ctx_N, N);
   const std::string key = keyf("unet_%d_%d_%d_%d_%d", N, H, W, c->ctx_T, (int)cfg);
   const bool fresh = c->plans.count(key) == 0;
@@ -2819,8 +2844,58 @@ static void unet_run(df_ctx* c, const float* x, const float* t, float* out, int 
     a.aux = c->ctx_copy;
     run_ops(c, p, 0, nctx, s, a);
   }
-  run_ops(c, p, nctx, p->ops.size(), s, a);
+  if (ts_index >= 0) {       // announced timestep: one table look-up instead of the time-embedding ops
+    if (p->op_tl < 0 || !p->Etab) fail("no timestep table for this UNet plan (call df_unet_set_timesteps after df_unet_set_context)");
+    if (ts_index >= p->etab_S) fail("timestep index %d outside the table of %d steps", ts_index, p->etab_S);
+    a.ts_index = ts_index;
+    run_ops(c, p, (size_t)p->op_tl, p->ops.size(), s, a);
+  } else if (p->op_tl >= 0) {
+    run_ops(c, p, nctx, (size_t)p->op_tl, s, a);
+    run_ops(c, p, (size_t)p->op_tl + 1, p->ops.size(), s, a);
+  } else {
+    run_ops(c, p, nctx, p->ops.size(), s, a);
+  }
   c->last_unet = p;
+}
+
+// Time embedding of every step of a sample() call, once, before the loop (it depends on t only; the reference
+// recomputes it inside every UNet call, openai_unetmodel.py:724).  t_host[S] = the timesteps the sampler is going to visit, the
+// same value for every sample of the batch (ddim.py:217 `ts = torch.full((b,), step)`).  Runs the plan's own time-embedding ops
+// per step, so a table row is bit-identical to what the step would have computed in place.
+static void unet_set_timesteps(df_ctx* c, const float* t_host, int S, int N, int H, int W, bool cfg, hipStream_t s) {
+  if (S <= 0) fail("df_unet_set_timesteps: no timesteps");
+  if (c->ctx_N != N) fail("context has %d rows but the UNet batch is %d (call df_unet_set_context first)", c->ctx_N, N);
+  const std::string key = keyf("unet_%d_%d_%d_%d_%d", N, H, W, c->ctx_T, (int)cfg);
+  const bool fresh = c->plans.count(key) == 0;
+  Plan* p = unet_plan(c, N, H, W, c->ctx_T, cfg);
+  if (p->op_tl < 0) fail("this UNet plan has no hoistable time embedding");
+  RunArgs a;
+  if (fresh) {
+    a.aux = c->ctx_copy;
+    run_ops(c, p, 0, p->n_ctx, s, a);
+  }
+  if (S > p->etab_cap) {
+    HIPCHK(hipStreamSynchronize(s));
+    if (p->Etab) (void)hipFree(p->Etab);
+    if (p->ttab) (void)hipFree(p->ttab);
+    p->Etab = p->ttab = nullptr;
+    p->etab_cap = 0;
+    HIPCHK(hipMalloc((void**)&p->Etab, (size_t)S * p->etot * 4));
+    HIPCHK(hipMalloc((void**)&p->ttab, (size_t)S * p->t_rows * 4));
+    p->etab_cap = S;
+  }
+  std::vector<float> tt((size_t)S * p->t_rows);
+  for (int i = 0; i < S; ++i)
+    for (int r = 0; r < p->t_rows; ++r) tt[(size_t)i * p->t_rows + r] = t_host[i];
+  HIPCHK(hipMemcpyAsync(p->ttab, tt.data(), tt.size() * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));       // tt leaves scope
+  p->etab_S = 0;
+  for (int i = 0; i < S; ++i) {
+    a.t = p->ttab + (size_t)i * p->t_rows;
+    run_ops(c, p, (size_t)p->op_t0, (size_t)p->op_tl, s, a);
+    HIPCHK(hipMemcpyAsync(p->Etab + (size_t)i * p->etot, p->E, (size_t)p->etot * 4, hipMemcpyDeviceToDevice, s));
+  }
+  p->etab_S = S;
 }
 
 int df_unet_forward(df_ctx* c, const float* x, const float* t, float* out, int N, int H, int W, void* stream) {
@@ -2830,6 +2905,24 @@ int df_unet_forward(df_ctx* c, const float* x, const float* t, float* out, int N
 int df_unet_forward_cfg(df_ctx* c, const float* x, const float* t, float* out, int B, int H, int W, float scale,
                         void* stream) {
   return guard([&] { unet_run(c, x, t, out, 2 * B, H, W, true, scale, (hipStream_t)stream); });
+}
+
+int df_unet_set_timesteps(df_ctx* c, const float* t_host, int S, int N, int H, int W, int cfg, void* stream) {
+  return guard([&] { unet_set_timesteps(c, t_host, S, cfg ? 2 * N : N, H, W, cfg != 0, (hipStream_t)stream); });
+}
+
+int df_unet_forward_ts(df_ctx* c, const float* x, int ts_index, float* out, int N, int H, int W, void* stream) {
+  return guard([&] {
+    if (ts_index < 0) fail("df_unet_forward_ts: negative timestep index");
+    unet_run(c, x, nullptr, out, N, H, W, false, 1.f, (hipStream_t)stream, ts_index);
+  });
+}
+
+int df_unet_forward_cfg_ts(df_ctx* c, const float* x, int ts_index, float* out, int B, int H, int W, float scale, void* stream) {
+  return guard([&] {
+    if (ts_index < 0) fail("df_unet_forward_cfg_ts: negative timestep index");
+    unet_run(c, x, nullptr, out, 2 * B, H, W, true, scale, (hipStream_t)stream, ts_index);
+  });
 }
 
 // One GEMM operand is addressed with 32-bit buffer offsets (< 2 GiB): the decoder's widest activation is 8H x 8W pixels x

@@ -63,6 +63,10 @@ _SIGS = {
     "df_unet_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "df_unet_forward_cfg": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                             C.c_void_p],
+    "df_unet_set_timesteps": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "df_unet_forward_ts": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "df_unet_forward_cfg_ts": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                               C.c_void_p],
     "df_vae_decode": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "df_classifier_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_void_p],
@@ -333,21 +337,36 @@ class Engine:
         _want_dim("cross-attention context", D, getattr(self, "unet_context_dim", None))
         _chk(self.L.df_unet_set_context(self._h, _ptr(ctx), N, T, _stream()), self.L)
 
-    def unet_forward(self, x, t, out=None):
+    def set_timesteps(self, timesteps, batch, H, W, cfg):
+        """Hoists the time embedding of a whole sample() call out of the step loop (df_unet_set_timesteps): ``timesteps`` are
+        the values the sampler is going to visit, each shared by the whole batch; afterwards ``unet_forward*(…, ts_index=i)``
+        takes the table row instead of the time-embedding launches.  ``batch`` = sampler batch (the CFG plan doubles it)."""
+        ts = (C.c_float * len(timesteps))(*[float(v) for v in timesteps])
+        _chk(self.L.df_unet_set_timesteps(self._h, ts, len(timesteps), int(batch), int(H), int(W), 1 if cfg else 0, _stream()),
+             self.L)
+
+    def unet_forward(self, x, t, out=None, ts_index=None):
         x = _dev_f32(x, self.device)
-        t = _dev_f32(t, self.device)
         N, Cc, H, W = x.shape
         if out is None:
             out = torch.empty(N, self.unet_out_channels, H, W, device=self.device, dtype=torch.float32)
+        if ts_index is not None:
+            _chk(self.L.df_unet_forward_ts(self._h, _ptr(x), int(ts_index), _ptr(out), N, H, W, _stream()), self.L)
+            return out
+        t = _dev_f32(t, self.device)
         _chk(self.L.df_unet_forward(self._h, _ptr(x), _ptr(t), _ptr(out), N, H, W, _stream()), self.L)
         return out
 
-    def unet_forward_cfg(self, x, t, scale, out=None):
+    def unet_forward_cfg(self, x, t, scale, out=None, ts_index=None):
         x = _dev_f32(x, self.device)
-        t = _dev_f32(t, self.device)
         B, Cc, H, W = x.shape
         if out is None:
             out = torch.empty(B, self.unet_out_channels, H, W, device=self.device, dtype=torch.float32)
+        if ts_index is not None:
+            _chk(self.L.df_unet_forward_cfg_ts(self._h, _ptr(x), int(ts_index), _ptr(out), B, H, W, float(scale), _stream()),
+                 self.L)
+            return out
+        t = _dev_f32(t, self.device)
         _chk(self.L.df_unet_forward_cfg(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, float(scale), _stream()), self.L)
         return out
 

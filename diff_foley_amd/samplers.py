@@ -16,6 +16,9 @@ import torch
 from . import engine as E
 from .schedule import DDIMTables, DPMTables
 
+import os as _os
+_NO_HOIST = bool(int(_os.environ.get("DF_NO_THOIST", "0")))      # A/B switch: time embedding inside every step
+
 
 def _warn_batch(conditioning, batch_size):
     if conditioning is not None:
@@ -75,24 +78,40 @@ class _Inpaint:
 
 
 class _Guided:
-    """eps(x, t) with classifier-free guidance; owns the engine context for the duration of a sample()."""
+    """eps(x, t) with classifier-free guidance; owns the engine context for the duration of a sample().
 
-    def __init__(self, model, cond, scale, uc):
+    ``timesteps`` (optional): every timestep value the sampler is going to visit, in its own indexing.  The time embedding
+    (timestep_embedding -> time_embed MLP -> the emb projection of all 22 ResBlocks; util.py:151-171,
+    openai_unetmodel.py:506-511,262) depends on t only, so it is computed for all of them here, before the loop
+    (``df_unet_set_timesteps``), and ``eps_fn(x, t, k)`` takes table row ``k`` instead of four launches per step."""
+
+    def __init__(self, model, cond, scale, uc, timesteps=None, size=None):
         self.m = model
         self.eng = model.engine
         self.cfg = not (uc is None or scale == 1.0)
         self.scale = float(scale)
         cond = model._cond_tensor(cond)
-        if self.cfg:
-            self.eng.set_context(torch.cat([model._cond_tensor(uc), cond]))
-        else:
-            self.eng.set_context(cond)
+        self._ctx = torch.cat([model._cond_tensor(uc), cond]) if self.cfg else cond
+        self.eng.set_context(self._ctx)
         model._ctx_owner = None          # invalidate apply_model's cached context
+        self.hoisted = False
+        if timesteps is not None and size is not None and not _NO_HOIST:
+            B, _, H, W = size
+            self.eng.set_timesteps([float(v) for v in timesteps], B, H, W, self.cfg)
+            self.hoisted = True
 
-    def __call__(self, x, t):
+    def reclaim_context(self):
+        """A caller-supplied callback (score_corrector) may have evaluated the model itself -- ``model.apply_model`` and the
+        ``model.model`` facades set THEIR context in the engine.  Put the sampler's [uncond ; cond] context back."""
+        if self.m._ctx_owner is not None:
+            self.eng.set_context(self._ctx)
+            self.m._ctx_owner = None
+
+    def __call__(self, x, t, k=None):
+        k = k if self.hoisted else None
         if self.cfg:
-            return self.eng.unet_forward_cfg(x, t, self.scale)
-        return self.eng.unet_forward(x, t)
+            return self.eng.unet_forward_cfg(x, t, self.scale, ts_index=k)
+        return self.eng.unet_forward(x, t, ts_index=k)
 
 
 def _classifier_grad(model, classifier, x, t, origin_cond):
@@ -125,34 +144,33 @@ class DDIMSampler(object):
                verbose=True, callback=None, img_callback=None, classifier=None, origin_cond=None,
                classifier_guide_scale=0.0, mask=None, x0=None, score_corrector=None, corrector_kwargs=None, **kwargs):
         reject_unsupported("DDIMSampler", kwargs)
-        if score_corrector is not None and classifier is not None:
-            # p_sample_ddim_with_classifier (ddim.py:276-396) takes the argument and never applies it
-            raise NotImplementedError("DDIMSampler: score_corrector is dropped by the reference's classifier-guided step")
         _warn_batch(conditioning, batch_size)
         self.make_schedule(S, ddim_eta=eta, verbose=verbose)
         dev = self.model.device
         C, H, W = shape
         size = (batch_size, C, H, W)
         img = torch.randn(size, device=dev) if x_T is None else x_T.to(dev, torch.float32).contiguous()
-        eps_fn = _Guided(self.model, conditioning, unconditional_guidance_scale, unconditional_conditioning)
         tb = self.tables
         steps = np.flip(tb.timesteps)
         total = steps.shape[0]
+        eps_fn = _Guided(self.model, conditioning, unconditional_guidance_scale, unconditional_conditioning, steps, size)
         t_all = torch.tensor(steps.copy(), dtype=torch.float32, device=dev)[:, None].expand(total, batch_size).contiguous()
+        t_long = t_all.long() if score_corrector is not None else None     # the reference hands the callback `ts` (int64, ddim.py:217)
         inter = {"x_inter": [img], "pred_x0": [img]}
         paint = _Inpaint(self.model, mask, x0, size, kwargs.get("q_noise_fn"))
         for i in range(total):
             index = total - i - 1
             if paint.on:                     # ddim.py:206-209
                 img = paint.blend(img, steps[i])
-            e_t = eps_fn(img, t_all[i])
-            if score_corrector is not None:  # ddim.py:249-251 / 360-362: a caller-supplied callback on the guided eps
-                e_t = score_corrector.modify_score(self.model, e_t, img, t_all[i], conditioning, **(corrector_kwargs or {}))
-                e_t = E._dev_f32(e_t, dev)
+            e_t = eps_fn(img, t_all[i], i)
             a_t, a_prev = tb.alphas[index], tb.alphas_prev[index]
-            if classifier is not None:       # ddim.py:374-380
+            if classifier is not None:       # ddim.py:374-380: the classifier gradient first ...
                 g = _classifier_grad(self.model, classifier, img, t_all[i], origin_cond)
                 e_t = E.lincomb([(1.0, e_t), (-np.sqrt(np.float32(1.0) - a_t) * classifier_guide_scale, g)])
+            if score_corrector is not None:  # ... then the caller's callback on the guided eps (ddim.py:249-251, 382-384)
+                e_t = score_corrector.modify_score(self.model, e_t, img, t_long[i], conditioning, **(corrector_kwargs or {}))
+                e_t = E._dev_f32(e_t, dev)
+                eps_fn.reclaim_context()
             sigma = tb.sigmas[index]
             noise = None
             if sigma != 0.0:
@@ -191,16 +209,18 @@ class PLMSSampler(object):
         C, H, W = shape
         size = (batch_size, C, H, W)
         img = torch.randn(size, device=dev) if x_T is None else x_T.to(dev, torch.float32).contiguous()
-        guided = _Guided(self.model, conditioning, unconditional_guidance_scale, unconditional_conditioning)
-
-        def eps_fn(x, t):                    # get_model_output (plms.py:178-190): guided eps, then the caller's score corrector
-            e = guided(x, t)
-            if score_corrector is not None:
-                e = E._dev_f32(score_corrector.modify_score(self.model, e, x, t, conditioning, **(corrector_kwargs or {})), dev)
-            return e
         steps = np.flip(tb.timesteps)
         total = steps.shape[0]
+        guided = _Guided(self.model, conditioning, unconditional_guidance_scale, unconditional_conditioning, steps, size)
         t_all = torch.tensor(steps.copy(), dtype=torch.float32, device=dev)[:, None].expand(total, batch_size).contiguous()
+        t_long = t_all.long() if score_corrector is not None else None     # the reference's `ts` / `ts_next` are int64 (plms.py:140-142)
+
+        def eps_fn(x, k):                    # get_model_output (plms.py:178-190): guided eps, then the caller's score corrector
+            e = guided(x, t_all[k], k)
+            if score_corrector is not None:
+                e = E._dev_f32(score_corrector.modify_score(self.model, e, x, t_long[k], conditioning, **(corrector_kwargs or {})), dev)
+                guided.reclaim_context()
+            return e
         inter = {"x_inter": [img], "pred_x0": [img]}
         old_eps = []
         paint = _Inpaint(self.model, mask, x0, size, kwargs.get("q_noise_fn"))
@@ -210,10 +230,10 @@ class PLMSSampler(object):
                 img = paint.blend(img, steps[i])
             upd = lambda x, e: E.ddim_update(x, e, tb.alphas[index], tb.alphas_prev[index], 0.0,
                                              tb.sqrt_one_minus_alphas[index], None)
-            e_t = eps_fn(img, t_all[i])
+            e_t = eps_fn(img, i)
             if len(old_eps) == 0:          # pseudo improved Euler (plms.py:219-223)
                 x_prev, _ = upd(img, e_t)
-                e_next = eps_fn(x_prev, t_all[min(i + 1, total - 1)])
+                e_next = eps_fn(x_prev, min(i + 1, total - 1))
                 e_p = E.lincomb([(0.5, e_t), (0.5, e_next)])
             elif len(old_eps) == 1:
                 e_p = E.lincomb([(1.5, e_t), (-0.5, old_eps[-1])])
@@ -255,14 +275,14 @@ class DPMSolverSampler(object):
         size = (batch_size, C, H, W)
         x = torch.randn(size, device=dev) if x_T is None else x_T.to(dev, torch.float32).contiguous()
         ns = DPMTables(self.model.alphas_cumprod)
-        eps_fn = _Guided(self.model, conditioning, unconditional_guidance_scale, unconditional_conditioning)
         ts = ns.time_steps(S)
-        t_in_all = torch.tensor([ns.model_time(t) for t in ts], dtype=torch.float32, device=dev)[:, None] \
-            .expand(S + 1, batch_size).contiguous()
+        t_model = [ns.model_time(t) for t in ts]
+        eps_fn = _Guided(self.model, conditioning, unconditional_guidance_scale, unconditional_conditioning, t_model[:S], size)
+        t_in_all = torch.tensor(t_model, dtype=torch.float32, device=dev)[:, None].expand(S + 1, batch_size).contiguous()
 
         def model_fn(x, k):          # data prediction x0 = (x - sigma*eps)/alpha   (dpm_solver.py:386-393)
             t = ts[k]
-            noise = eps_fn(x, t_in_all[k])
+            noise = eps_fn(x, t_in_all[k], k)
             if classifier is not None and eps_fn.cfg:      # double guidance (dpm_solver.py:1377-1393)
                 g = _classifier_grad(self.model, classifier, x, t_in_all[k], origin_cond)
                 noise = E.lincomb([(1.0, noise), (-classifier_guide_scale * ns.sigma(t), g)])

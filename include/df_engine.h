@@ -121,6 +121,17 @@ int df_unet_forward(df_ctx* ctx, const float* x_dev, const float* t_dev, float* 
  * the first cross-attention see identical rows in both halves and run on one half only (DF_NO_CFGDEDUP=1 disables). */
 int df_unet_forward_cfg(df_ctx* ctx, const float* x_dev, const float* t_dev, float* eps_out_dev, int B, int H, int W,
                         float guidance_scale, void* stream);
+/* Time embedding of a whole sample() call, hoisted out of the step loop like the context (timestep_embedding util.py:151-171 ->
+ * time_embed openai_unetmodel.py:506-511,724 -> every ResBlock's emb_layers :262: all of it depends on t only, and a sampler
+ * knows its S timesteps before the loop -- ddim.py:193-201, plms.py:127-135, dpm_solver.py:1071-1079).  t_host[S]: the
+ * timesteps (host memory; integer or fractional), each used for every sample of the batch as the reference samplers do
+ * (ddim.py:217).  N, H, W, cfg name the plan (cfg != 0: the CFG plan of df_unet_forward_cfg with B = N).  Call after
+ * df_unet_set_context.  The *_ts entry points then take the INDEX of the step's timestep in that table instead of t_dev and
+ * replace the four time-embedding launches of a step by one table look-up; results are bit-identical to the t_dev forms. */
+int df_unet_set_timesteps(df_ctx* ctx, const float* t_host, int S, int N, int H, int W, int cfg, void* stream);
+int df_unet_forward_ts(df_ctx* ctx, const float* x_dev, int ts_index, float* eps_out_dev, int N, int H, int W, void* stream);
+int df_unet_forward_cfg_ts(df_ctx* ctx, const float* x_dev, int ts_index, float* eps_out_dev, int B, int H, int W,
+                           float guidance_scale, void* stream);
 
 /* ---- LatentDiffusion.decode_first_stage (ddpm.py:739-797 -> autoencoder.py:330-333 -> model.py:630-663)
  * z [B][z_channels][H][W] fp32 -> out [B][out_ch][H*2^(n_mult-1)][W*2^(n_mult-1)] fp32.  Any B: batches whose widest

@@ -198,11 +198,13 @@ def test_tiny_inpainting_vs_golden(tiny):
         tiny.sample_log_diff_sampler(c, B, "DDIM", 6, x_T=xT.clone(), mask=mask)          # mask without x0: like the reference
 
 
-def test_score_corrector_callback(tiny):
-    """score_corrector.modify_score(model, e_t, x, t, c, **corrector_kwargs) (ddim.py:249-251, plms.py:186-188): a caller's
+def test_score_corrector_callback(P, tiny):
+    """score_corrector.modify_score(model, e_t, x, t, c, **corrector_kwargs) (ddim.py:249-251, 382-384, plms.py:186-188): a caller's
     callback on the guided eps.  An identity corrector changes nothing; a scaling one gives the trajectory of the scaled eps
-    (checked against the oracle's DDIM loop driven by the product's own eps * k); the classifier-guided step, whose reference
-    drops the argument, refuses it."""
+    (checked against the oracle's DDIM loop driven by the product's own eps * k); `t` arrives as the reference's int64 `ts`; a
+    corrector that evaluates the model itself (apply_model under ANOTHER conditioning: the engine's context changes hands) leaves
+    the sampler's own [uncond ; cond] context intact for the next step; with classifier guidance the callback sees the eps AFTER
+    the classifier gradient, the reference's order (ddim.py:374-384)."""
     from diff_foley_amd import synth
     B = 2
     xT = synth.synthetic_xT(B, seed=21)
@@ -215,6 +217,8 @@ def test_score_corrector_callback(tiny):
             self.k = k
 
         def modify_score(self, model, e_t, x, t, cond, gain=1.0):
+            assert t.dtype == torch.int64 and t.shape == (B,)
+            model.alphas_cumprod[t]                    # schedule tables are indexed with it (extract_into_tensor -> gather)
             calls.append((tuple(e_t.shape), float(t[0]), gain))
             assert model is tiny and cond is c
             return e_t * (self.k * gain)
@@ -232,10 +236,88 @@ def test_score_corrector_callback(tiny):
     eps = lambda x, t, cc: (tiny.model.diffusion_model(x.cuda(), t.cuda().float(), context=cc.cuda()).cpu())
     zo, _ = osamp.ddim_sample(lambda x, t, cc: 0.75 * eps(x, t, cc), osch.ddpm_schedule()["alphas_cumprod"], 6, xT, c.cpu(), 4.5, uc.cpu())
     assert rel_l2(z2.cpu(), zo) < 2e-3
-    with pytest.raises(NotImplementedError):
-        tiny.sample_log_with_classifier_diff_sampler(c, origin_cond=synth.synthetic_cavp(B, 33, 64), batch_size=B,
-                                                     sampler_name="DDIM", ddim_steps=4, classifier=object(),
-                                                     classifier_guide_scale=1.0, score_corrector=Corr(1.0), **kw)
+
+    # a corrector that calls the model: apply_model and the module facades put THEIR context into the engine (B rows, another
+    # conditioning); the next step's CFG forward needs the sampler's 2B-row context back
+    other = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=77).cuda())
+    seen = []
+
+    class CallsModel:
+        def modify_score(self, model, e_t, x, t, cond):
+            e_other = model.apply_model(x, t, other)
+            e_fac = model.model.diffusion_model(x, t.float(), context=other)
+            seen.append(float((e_other - e_fac).abs().max()))
+            return e_t + 0.0 * e_other
+    for name in ("DDIM", "PLMS"):
+        z0, _ = tiny.sample_log_diff_sampler(c, B, name, 6, x_T=xT.clone(), **kw)
+        z3, _ = tiny.sample_log_diff_sampler(c, B, name, 6, x_T=xT.clone(), score_corrector=CallsModel(), **kw)
+        assert torch.equal(z0, z3), name
+        z4, _ = tiny.sample_log_diff_sampler(c, B, name, 6, x_T=xT.clone(), score_corrector=CallsModel())   # no CFG: same rule
+        z5, _ = tiny.sample_log_diff_sampler(c, B, name, 6, x_T=xT.clone())
+        assert torch.equal(z4, z5), name
+    assert seen and max(seen) == 0.0
+
+    # classifier guidance + corrector: eps' = corrector(eps_cfg - sqrt(1 - a_t) * s * grad)   (ddim.py:374-384)
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_TINY)))
+    cls.load_state_dict(tiny_classifier_sd())
+    cls.attach(tiny)
+    vf = synth.synthetic_cavp(B, 33, 64, seed=4321).cuda()
+    got = []
+
+    class Record:
+        def modify_score(self, model, e_t, x, t, cond):
+            got.append(e_t.clone())
+            return e_t
+    ckw = dict(origin_cond=vf, batch_size=B, sampler_name="DDIM", ddim_steps=4, classifier=cls, classifier_guide_scale=50.0,
+               x_T=xT.clone(), **kw)
+    za, _ = tiny.sample_log_with_classifier_diff_sampler(c, **ckw)
+    zb, _ = tiny.sample_log_with_classifier_diff_sampler(c, score_corrector=Record(), **ckw)
+    assert torch.equal(za, zb) and len(got) == 5
+    # first step: the recorded eps is the CFG eps minus the classifier term, not the bare CFG eps
+    tiny.engine.set_context(torch.cat([uc, c]))
+    from diff_foley_amd.schedule import DDIMTables
+    tb = DDIMTables(tiny.alphas_cumprod, 4)
+    t0 = torch.full((B,), float(np.flip(tb.timesteps)[0]), device="cuda")
+    e_cfg = tiny.engine.unet_forward_cfg(xT.cuda(), t0, 4.5)
+    grad = cls.log_prob_grad(xT.cuda(), t0, vf)
+    want = e_cfg - float(np.sqrt(1.0 - tb.alphas[len(tb.alphas) - 1])) * 50.0 * grad
+    assert rel_l2(got[0].cpu(), want.cpu()) < 1e-5 and rel_l2(got[0].cpu(), e_cfg.cpu()) > 1e-4
+
+
+def test_hoisted_time_embedding_is_bit_identical(tiny):
+    """df_unet_set_timesteps + df_unet_forward(_cfg)_ts: the time embedding of every announced timestep (integer and fractional,
+    as DDIM / DPM-Solver++ visit them) computed before the loop by the plan's own ops; a step that looks its row up returns
+    exactly what the in-step form returns, the samplers give the same latents with and without the hoist, and an index
+    outside the table or a plan without a table is an error, not a silent fallback."""
+    from diff_foley_amd import synth, samplers
+    B = 2
+    eng = tiny.engine
+    x = synth.synthetic_xT(B, seed=5).cuda()
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+    uc = torch.zeros_like(c)
+    ts = [961.0, 41.0, 1.0, 960.2, 40.96, 999.0]
+    eng.set_context(torch.cat([uc, c]))
+    eng.set_timesteps(ts, B, 16, 64, True)
+    for k, t in enumerate(ts):
+        a = eng.unet_forward_cfg(x, torch.full((B,), t, device="cuda"), 4.5)
+        b = eng.unet_forward_cfg(x, None, 4.5, ts_index=k)
+        assert torch.equal(a, b), (k, t)
+    with pytest.raises(RuntimeError):
+        eng.unet_forward_cfg(x, None, 4.5, ts_index=len(ts))
+    eng.set_context(c)
+    with pytest.raises(RuntimeError):                       # the non-CFG plan of this shape has no table yet
+        eng.unet_forward(x, None, ts_index=0)
+    eng.set_timesteps(ts[:2], B, 16, 64, False)
+    assert torch.equal(eng.unet_forward(x, torch.full((B,), ts[1], device="cuda")), eng.unet_forward(x, None, ts_index=1))
+    kw = dict(unconditional_guidance_scale=4.5, unconditional_conditioning=uc)
+    for name, S in (("DDIM", 6), ("PLMS", 6), ("DPM_Solver", 6)):
+        z_h, _ = tiny.sample_log_diff_sampler(c, B, name, S, x_T=x.clone(), **kw)
+        samplers._NO_HOIST = True
+        try:
+            z_i, _ = tiny.sample_log_diff_sampler(c, B, name, S, x_T=x.clone(), **kw)
+        finally:
+            samplers._NO_HOIST = False
+        assert torch.equal(z_h, z_i), name
 
 
 def test_module_facades_run_the_engine(tiny):
