@@ -66,8 +66,11 @@ struct RunArgs {
   int ts_index = -1;             // >= 0: row of the plan's hoisted time-embedding table (df_unet_set_timesteps)
 };
 
+struct OutBuf { const uint16_t* p; long rows; int cols, ld; };   // operand-type output of a non-GEMM op (df_debug_saturations)
+
 struct Op {
   bool is_gemm = false;
+  std::vector<OutBuf> outs;
   GemmParams gp{};
   int tile = 0, batch = 1;
   bool c_ext = false;            // gp.C <- RunArgs.out at run time
@@ -192,6 +195,12 @@ struct df_ctx {
   unsigned long long* chk_dev = nullptr;
   size_t chk_used = 0, chk_cap = 0;
   std::vector<std::string> chk_label;
+  // debug: after every op, the number of operand-type values it stored that sit at the fp16 saturation value +-65504 (fp16
+  // build: conversions clamp there instead of overflowing) / are not finite (bf16 build) -- df_debug_saturations
+  bool sat_on = false;
+  unsigned long long* sat_dev = nullptr;
+  size_t sat_used = 0, sat_cap = 0;
+  std::vector<std::string> sat_label;
 
   ~df_ctx() {
     plans.clear();
@@ -199,6 +208,7 @@ struct df_ctx {
     for (void* p : packed_blocks) (void)hipFree(p);
     for (hipEvent_t e : prof_ev) (void)hipEventDestroy(e);
     if (chk_dev) (void)hipFree(chk_dev);
+    if (sat_dev) (void)hipFree(sat_dev);
     if (ctx_copy) (void)hipFree(ctx_copy);
   }
 
@@ -518,6 +528,10 @@ struct Builder {
     o.tag = tag;
     pl->ops.push_back(std::move(o));
   }
+  // operand-type output of the op emitted last (counted by df_debug_saturations)
+  void emits(const bf16_t* p, long rows, int cols, int ld) {
+    if (p && !pl->ops.empty()) pl->ops.back().outs.push_back({p, rows, cols, ld});
+  }
 
   Op& gemm(GemmParams gp, int batch, const char* tag) {
     Op o;
@@ -628,6 +642,8 @@ struct Builder {
                                             (long)po.gp.M * po.gp.N, po.gp.N, po.gp.bias, po.gp.res, po.gp.ldr, s);
         return launch_groupnorm(xp, ld, NB, HW, C, g, b, eps, silu, o, C, r, s);
       });
+      emits(o, x.rows, C, C);
+      emits(r, x.rows, C, C);
       return o;
     }
     if (sb) {          // large slabs (VAE decoder): pixel-chunked, fully coalesced three-launch form
@@ -635,12 +651,16 @@ struct Builder {
       other("groupnorm", [=](hipStream_t s, const RunArgs&) {
         return launch_groupnorm_chunked(xp, ld, NB, HW, C, g, b, eps, silu, o, C, r, scr, s);
       });
+      emits(o, x.rows, C, C);
+      emits(r, x.rows, C, C);
       pl->release(scr);
       return o;
     }
     other("groupnorm", [=](hipStream_t s, const RunArgs&) {
       return launch_groupnorm(xp, ld, NB, HW, C, g, b, eps, silu, o, C, r, s);
     });
+    emits(o, x.rows, C, C);
+    emits(r, x.rows, C, C);
     return o;
   }
   void layernorm(const F32& x, const std::string& p, bf16_t* o) {
@@ -649,6 +669,7 @@ struct Builder {
     const float* xp = x.p;
     const int ld = x.ld, rows = x.rows, C = x.C;
     other("layernorm", [=](hipStream_t s, const RunArgs&) { return launch_layernorm(xp, ld, rows, C, g, b, 1e-5f, o, s); });
+    emits(o, rows, C, C);
   }
   bf16_t* cast2d(const F32& x) {
     bf16_t* o = buf<bf16_t>((size_t)x.rows * x.C);
@@ -656,6 +677,7 @@ struct Builder {
     const int ld = x.ld, C = x.C;
     const long rows = x.rows;
     other("cast", [=](hipStream_t s, const RunArgs&) { return launch_cast_bf16_2d(xp, ld, o, rows, C, s); });
+    emits(o, rows, C, C);
     return o;
   }
 
@@ -704,6 +726,7 @@ struct Builder {
         if (scr) return launch_groupnorm_chunked(h1, cout, NB, HW, cout, gm, bt, eps, 1, a2, cout, nullptr, scr, s);
         return launch_groupnorm(h1, cout, NB, HW, cout, gm, bt, eps, 1, a2, cout, nullptr, s);
       });
+      emits(a2, M, cout, cout);
       pl->release(scr);
     }
     pl->release(h1);
@@ -917,6 +940,7 @@ struct Builder {
     other("attn.self", [=](hipStream_t s, const RunArgs&) {
       return launch_attention(qk, 2 * C, qk + C, 2 * C, vt, ldvt, o, C, NBp, heads, D, T, T, scale, s);
     });
+    emits(o, Mp, C, C);
     {
       GemmParams g = gp_linear(o, Mp, C, c->w_linear(nm(tb + ".attn1.to_out.0.weight")), C);
       produces_t0(g);
@@ -969,6 +993,7 @@ struct Builder {
     other("attn.cross", [=](hipStream_t s, const RunArgs&) {
       return launch_attention(q2, C, ctxK, C, ctxVt, ldvtc, o, C, NB, heads, D, T, Tc, scale, s);
     });
+    emits(o, M, C, C);
     {
       GemmParams g = gp_linear(o, M, C, c->w_linear(nm(tb + ".attn2.to_out.0.weight")), C);
       produces_t0(g);
@@ -2251,6 +2276,50 @@ void checksum_after_op(df_ctx* c, Plan* pl, size_t op_index, hipStream_t s) {
   ++c->chk_used;
 }
 
+// Operand-type values at the saturation point of the operand format: fp16 build -- |v| == 65504, where pack_bf2 / f2bf clamp
+// (common.h); bf16 build -- non-finite (bf16 keeps the fp32 range and is not clamped).  One 64-bit atomic add per wavefront.
+__global__ __launch_bounds__(256) void sat_count_kernel(const uint16_t* p, long rows, int cols, int ld, unsigned long long* slot) {
+  const long total = rows * (long)cols;
+  unsigned long long acc = 0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / cols;
+    const uint16_t v = p[r * ld + (e - r * cols)];
+#if defined(DF_OPERAND_F16)
+    acc += (v & 0x7FFFu) == 0x7BFFu;
+#else
+    acc += (v & 0x7F80u) == 0x7F80u;
+#endif
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(slot, acc);
+}
+
+void saturations_after_op(df_ctx* c, Plan* pl, size_t op_index, hipStream_t s) {
+  if (c->sat_used >= c->sat_cap) return;
+  const Op& o = pl->ops[op_index];
+  std::vector<OutBuf> outs = o.outs;
+  if (o.is_gemm) {
+    const GemmParams& g = o.gp;
+    const long rows = (long)g.M * (g.taps == 4 ? 4 : 1) + g.dup_rows;     // dup_rows: rows [M, M + dup_rows) repeat [0, M)
+    const int cols = g.geglu ? g.N / 2 : (g.vt ? g.vt_col0 : g.N);
+    if (g.out_bf16 && g.C && !o.c_ext && !g.store_nchw)
+      for (int z = 0; z < (g.splitk > 1 ? 1 : o.batch); ++z) outs.push_back({(const uint16_t*)g.C + (long)z * g.c_bs, rows, cols, g.ldc});
+    if (g.aux) outs.push_back({g.aux, rows, g.N, g.ld_aux});
+    if (g.vt) outs.push_back({g.vt, (long)(g.M / g.vt_T) * (g.N - g.vt_col0), g.vt_T, g.ldvt});
+  }
+  for (auto& b : outs) {
+    const long total = b.rows * (long)b.cols;
+    if (total <= 0) continue;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 1024);
+    hipLaunchKernelGGL(sat_count_kernel, dim3(blocks), dim3(256), 0, s, b.p, b.rows, b.cols, b.ld, c->sat_dev + c->sat_used);
+  }
+  char lab[160];
+  snprintf(lab, sizeof lab, "%s#%zu:%s", pl->name.c_str(), op_index, o.tag);
+  c->sat_label.push_back(lab);
+  ++c->sat_used;
+}
+
 void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const RunArgs& a) {
   for (size_t i = begin; i < end; ++i) {
     Op& o = pl->ops[i];
@@ -2287,6 +2356,7 @@ void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const
       c->prof_used += 2;
     }
     if (c->chk_on) checksum_after_op(c, pl, i, s);
+    if (c->sat_on) saturations_after_op(c, pl, i, s);
     static const bool trace = getenv("DF_TRACE_OPS") && atoi(getenv("DF_TRACE_OPS"));     // debug: name + sync every op
     if (trace) {
       fprintf(stderr, "[df] %s#%zu %s%s\n", pl->name.c_str(), i, o.tag, o.is_gemm ? (" tile " + std::to_string(o.tile) + " sk " + std::to_string(o.gp.splitk)).c_str() : "");
@@ -2341,6 +2411,28 @@ static void tune_cache_save() {
   fclose(f);
 }
 
+// Set by df_tune_cache_import: another rank's choices were handed to this process.  Plans then take every choice the cache holds
+// for their GEMMs whether or not df_autotune is on here -- the ranks of a job must run the SAME tiles and split-K factors
+// (identical fp32 summation order, bit-equal results; parallel.broadcast_packed_model), and an importing rank that never asked
+// for tuning used to fall back to the heuristic tiles silently.
+static bool g_tune_imported = false;
+
+static void apply_tune_cache(Plan* pl) {
+  auto& tc = tune_cache();
+  for (auto& o : pl->ops) {
+    if (!o.is_gemm || o.c_ext) continue;
+    auto it = tc.find(tune_key(o));
+    if (it == tc.end()) continue;
+    const TuneChoice& ch = it->second;
+    const size_t need = (size_t)ch.sk * o.gp.M * o.gp.N * 4 * (o.gp.taps == 4 ? 4 : 1);
+    if (!gemm_tile_valid(o.gp, ch.tile, o.batch, ch.sk) || (ch.sk > 1 && need > pl->partial_bytes)) continue;
+    o.tile = ch.tile;
+    o.gp.splitk = ch.sk;
+    o.gp.gm = ch.gm;
+    o.gp.partial = pl->partial;
+  }
+}
+
 void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
   {
     auto& tc = tune_cache();      // in-memory for the life of the process (+ the file when DF_TUNE_CACHE is set)
@@ -2348,16 +2440,7 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
     for (auto& o : pl->ops)
       if (o.is_gemm && !o.c_ext && !tc.count(tune_key(o))) all = false;
     if (all) {
-      for (auto& o : pl->ops) {
-        if (!o.is_gemm || o.c_ext) continue;
-        const TuneChoice& ch = tc[tune_key(o)];
-        const size_t need = (size_t)ch.sk * o.gp.M * o.gp.N * 4 * (o.gp.taps == 4 ? 4 : 1);
-        if (!gemm_tile_valid(o.gp, ch.tile, o.batch, ch.sk) || (ch.sk > 1 && need > pl->partial_bytes)) continue;
-        o.tile = ch.tile;
-        o.gp.splitk = ch.sk;
-        o.gp.gm = ch.gm;
-        o.gp.partial = pl->partial;
-      }
+      apply_tune_cache(pl);
       tune_cache_save();     // DF_TUNE_CACHE may name a file this process has not written yet
       return;
     }
@@ -2564,7 +2647,7 @@ Plan* get_plan(df_ctx* c, const std::string& key, const std::function<void(Plan*
   }
   std::unique_ptr<Plan> p(new Plan());
   build(p.get());
-  if (c->autotune) {
+  if (c->autotune || g_tune_imported) {
     // tuning may try larger split-K factors than the cost model picked: give the scratch some head-room
     size_t want = 0;
     for (auto& o : p->ops)
@@ -2576,6 +2659,8 @@ Plan* get_plan(df_ctx* c, const std::string& key, const std::function<void(Plan*
   if (c->autotune) {
     autotune_plan(c, p.get(), c->pack_stream);
     HIPCHK(hipStreamSynchronize(c->pack_stream));
+  } else if (g_tune_imported) {
+    apply_tune_cache(p.get());
   }
   Plan* r = p.get();
   r->name = key;
@@ -3156,6 +3241,7 @@ int df_tune_cache_import(const char* text, int64_t n) {
       if (sscanf(t.substr(pos, e - pos).c_str(), "%159s %d %d %d", key, &ch.tile, &ch.sk, &ch.gm) == 4) {
         if (ch.tile < 0 || ch.tile >= TILE_ALL || ch.sk < 1 || ch.sk > 64) fail("tune cache line out of range: %s", key);
         tune_cache()[key] = ch;
+        g_tune_imported = true;
       }
       pos = e + 1;
     }
@@ -3193,6 +3279,40 @@ int df_debug_checksum_label(df_ctx* c, int64_t index, char* buf, int64_t len) {
   return guard([&] {
     if (index < 0 || (size_t)index >= c->chk_label.size() || len <= 0) fail("checksum label %lld out of range", (long long)index);
     snprintf(buf, (size_t)len, "%s", c->chk_label[(size_t)index].c_str());
+  });
+}
+
+int df_debug_saturations(df_ctx* c, int enable, int64_t capacity) {
+  return guard([&] {
+    HIPCHK(hipDeviceSynchronize());
+    c->sat_on = enable != 0;
+    c->sat_used = 0;
+    c->sat_label.clear();
+    if (enable) {
+      const size_t cap = capacity > 0 ? (size_t)capacity : (size_t)1 << 16;
+      if (cap > c->sat_cap) {
+        if (c->sat_dev) (void)hipFree(c->sat_dev);
+        HIPCHK(hipMalloc((void**)&c->sat_dev, cap * 8));
+        c->sat_cap = cap;
+      }
+      HIPCHK(hipMemset(c->sat_dev, 0, c->sat_cap * 8));
+    }
+  });
+}
+
+int df_debug_saturations_read(df_ctx* c, uint64_t* out, int64_t cap, int64_t* n) {
+  return guard([&] {
+    HIPCHK(hipDeviceSynchronize());
+    *n = (int64_t)c->sat_used;
+    const size_t k = std::min((size_t)std::max<int64_t>(cap, 0), c->sat_used);
+    if (k) HIPCHK(hipMemcpy(out, c->sat_dev, k * 8, hipMemcpyDeviceToHost));
+  });
+}
+
+int df_debug_saturation_label(df_ctx* c, int64_t index, char* buf, int64_t len) {
+  return guard([&] {
+    if (index < 0 || (size_t)index >= c->sat_label.size() || len <= 0) fail("saturation label %lld out of range", (long long)index);
+    snprintf(buf, (size_t)len, "%s", c->sat_label[(size_t)index].c_str());
   });
 }
 

@@ -103,11 +103,16 @@ def broadcast_packed_model(model, batch_size, src=0, size_len=64, context_frames
     carry its own betas / alphas_cumprod: without them the importing ranks would sample with the config's schedule) and the
     autotuner's choices of ``src`` (when its engine tuned the exported plans): every rank then runs the SAME tiles and
     split-K factors -- identical fp32 summation order, bit-equal results across ranks -- and only ``src`` pays a tuning pass.
-    Returns seconds spent in (pack + export, broadcast, import) on this rank and the payload sizes."""
+    The imported choices are applied to every plan an importing rank builds, whether or not it called ``model.autotune()``
+    (``df_tune_cache_import``); they are keyed by GEMM shape, so the guarantee covers ranks with EQUAL shard sizes -- a ragged
+    last shard (``shard_range``) has its own M, finds no entry and runs the cost model's tiles (or its own tuning pass).
+    Every rank must have called ``model.cuda(device)`` before.  Returns seconds spent in (pack + export, broadcast, import) on this rank and the payload sizes."""
     import io
     import time
     from .schedule import BUFFER_NAMES
     rank = dist.get_rank() if dist.is_initialized() else 0
+    if model.engine is None:
+        raise RuntimeError("broadcast_packed_model: call model.cuda(device) on every rank first")
     dev = model.device
     t0 = time.perf_counter()
     manifest = blob = side = None

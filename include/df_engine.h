@@ -229,6 +229,15 @@ int df_tune_cache_import(const char* text, int64_t n);
 int df_debug_checksums(df_ctx* ctx, int enable, int64_t capacity);
 int df_debug_checksums_read(df_ctx* ctx, uint64_t* out, int64_t cap, int64_t* n);
 int df_debug_checksum_label(df_ctx* ctx, int64_t index, char* buf, int64_t len);
+/* Debug: while enabled, every op of every plan is followed by a count of the operand-type values it stored that sit at the
+ * saturation point of the operand format -- fp16 build: |v| == 65504, where every fp32 -> fp16 conversion of the kernels
+ * clamps instead of overflowing (csrc/common.h op_clamp); bf16 build: non-finite values.  Covers the operand-type outputs of
+ * every GEMM epilogue (C, the aux copy, the transposed V) and of the norm / cast / attention ops.  A non-zero count means the
+ * fp16 build has lost information in that op (a trained checkpoint's activations left the fp16 range): use the bf16 build.
+ * The reference computes in fp32 and has no such limit (openai_unetmodel.py:24-28: convert_module_to_f16 is a stub). */
+int df_debug_saturations(df_ctx* ctx, int enable, int64_t capacity);
+int df_debug_saturations_read(df_ctx* ctx, uint64_t* out, int64_t cap, int64_t* n);
+int df_debug_saturation_label(df_ctx* ctx, int64_t index, char* buf, int64_t len);
 /* Run ONE op family in isolation for unit tests (see tests/test_kernels_gpu.py). */
 int df_test_gemm_epi(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, const float* res_dev, void* C_dev,
                      int M, int N, int K, int act /*0 none, 1 SiLU, 2 ReLU*/, int out_operand, int tile, int splitk,

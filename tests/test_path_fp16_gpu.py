@@ -36,6 +36,56 @@ def full(P):
     return m
 
 
+def test_fp16_default_and_saturation_counter(P, tiny):
+    """(a) the facade's default operand type is fp16, the build that meets the north-star tolerance.  (b) fp16 operands saturate
+    at +-65504 (csrc/common.h op_clamp) -- silently, as far as the sample is concerned; df_debug_saturations counts, per op,
+    the operand-type values stored AT the saturation point.  Procedural weights never get there (all counts 0); with one
+    SpatialTransformer's GEGLU projection scaled until its outputs pass 6e4 the counter fires on that block's st.ff1 (and
+    on nothing in front of it), Engine.check_saturations() raises and names the op, and the bf16 build (fp32 range) runs the
+    same weights without a count."""
+    from diff_foley_amd import synth, engine as E
+    assert E.default_precision() == "fp16" or "DF_PRECISION" in __import__("os").environ
+    cfg = P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
+    B = 2
+    x = synth.synthetic_xT(B, seed=3).cuda()
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+    t = torch.tensor([500.0, 37.0]).cuda()
+    eng = tiny.engine
+    eng.debug_saturations(True)
+    try:
+        y0 = tiny.apply_model(x, t, c)
+        res = eng.debug_saturations_read()
+        assert len(res) > 50 and all(n == 0 for _, n in res), [r for r in res if r[1]][:5]
+        assert any("st.ff1" in lab for lab, _ in res) and any("groupnorm" in lab for lab, _ in res)
+        eng.check_saturations()
+    finally:
+        eng.debug_saturations(False)
+    sd = dict(tiny_state_dict())
+    key = [k for k in sd if k.endswith("input_blocks.2.1.transformer_blocks.0.ff.net.0.proj.weight")]
+    assert len(key) == 1
+    sd[key[0]] = sd[key[0]] * 3.0e4
+    runs = {}
+    for prec in ("fp16", "bf16"):
+        m = P.LatentDiffusion(precision=prec, **cfg)
+        m.load_state_dict(sd)
+        m.cuda()
+        m.engine.debug_saturations(True)
+        y = m.apply_model(x, t, m.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda()))
+        runs[prec] = (m, m.engine.debug_saturations_read(), y)
+    m, res, y = runs["fp16"]
+    hit = [(lab, n) for lab, n in res if n]
+    assert hit and "st.ff1" in hit[0][0], hit[:4]          # the first op that saturates is the scaled GEGLU projection
+    first = [lab for lab, _ in res].index(hit[0][0])
+    assert all(n == 0 for _, n in res[:first])
+    with pytest.raises(RuntimeError, match="saturated"):
+        m.engine.check_saturations()
+    mb, resb, yb = runs["bf16"]
+    assert all(n == 0 for _, n in resb) and torch.isfinite(yb).all()
+    mb.engine.check_saturations()
+    assert rel_l2(y.cpu(), yb.cpu()) > 1e-2               # the clamp changed the fp16 build's result: this is what the counter is for
+    assert torch.isfinite(y0).all()
+
+
 def test_fp16_tiny_forward_and_samplers(tiny):
     from diff_foley_amd import synth
     g = gold("g3_tiny_unet.npz")

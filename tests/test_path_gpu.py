@@ -28,7 +28,9 @@ def P():
 @pytest.fixture(scope="module")
 def tiny(P):
     from diff_foley_amd import synth
-    m = P.LatentDiffusion(**P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
+    # this file pins the bf16-operand build (BASELINE configs[1]'s literal "bf16 UNet"); the facade's DEFAULT is the fp16
+    # build, the one that meets the north-star tolerance -- its parity tests are tests/test_path_fp16_gpu.py
+    m = P.LatentDiffusion(precision="bf16", **P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
     m.load_state_dict(tiny_state_dict())
     m.cuda()
     return m
@@ -36,7 +38,7 @@ def tiny(P):
 
 @pytest.fixture(scope="module")
 def full(P):
-    m = P.LatentDiffusion(**P.stage2_config())
+    m = P.LatentDiffusion(precision="bf16", **P.stage2_config())
     m.load_state_dict(full_state_dict())
     m.cuda()
     return m
@@ -272,11 +274,11 @@ def test_score_corrector_callback(P, tiny):
                x_T=xT.clone(), **kw)
     za, _ = tiny.sample_log_with_classifier_diff_sampler(c, **ckw)
     zb, _ = tiny.sample_log_with_classifier_diff_sampler(c, score_corrector=Record(), **ckw)
-    assert torch.equal(za, zb) and len(got) == 5
-    # first step: the recorded eps is the CFG eps minus the classifier term, not the bare CFG eps
-    tiny.engine.set_context(torch.cat([uc, c]))
     from diff_foley_amd.schedule import DDIMTables
     tb = DDIMTables(tiny.alphas_cumprod, 4)
+    assert torch.equal(za, zb) and len(got) == len(tb.timesteps)
+    # first step: the recorded eps is the CFG eps minus the classifier term, not the bare CFG eps
+    tiny.engine.set_context(torch.cat([uc, c]))
     t0 = torch.full((B,), float(np.flip(tb.timesteps)[0]), device="cuda")
     e_cfg = tiny.engine.unet_forward_cfg(xT.cuda(), t0, 4.5)
     grad = cls.log_prob_grad(xT.cuda(), t0, vf)
@@ -443,9 +445,31 @@ def test_full_ddim_first4_steps_vs_golden(full):
     assert err < TRAJ_TOL
 
 
-def test_full_ddim25_mel_mae(full):
-    """North-star parity metric: decoded mel MAE vs the reference CPU sampler on identical seeds/inputs
-    (B=1, 25-step DDIM, CFG 4.5; BASELINE.json config 1)."""
+def _bf16_ddim25_mel(full, seed):
+    from diff_foley_amd import synth
+    g = gold("g5_full_samplers.npz")
+    xT = synth.synthetic_xT(1, seed=seed)
+    c = full.get_learned_conditioning(synth.synthetic_cavp(1, 32, 512, seed=1234 + seed - 21).cuda())
+    z, _ = full.sample_log_diff_sampler(c, 1, "DDIM", 25, unconditional_guidance_scale=4.5,
+                                        unconditional_conditioning=torch.zeros_like(c), x_T=xT.clone())
+    return full.decode_first_stage(z)[:, 0].cpu(), g[f"ddim25_mel_{seed}"]
+
+
+@pytest.mark.xfail(strict=True, reason="bf16 MFMA operands (2^-9 per operand) put the 25-step mel at MAE ~4.5e-3: the north-star "
+                                       "bound (< 1e-3, absolute) is met by the fp16-operand build only, which is the facade's "
+                                       "default (tests/test_path_fp16_gpu.py::test_fp16_full_ddim25_mel_mae_absolute)")
+def test_full_ddim25_mel_mae_north_star_bound_bf16(full):
+    """The bound exactly as BASELINE.json states it -- mel-spec MAE < 1e-3 vs the CPU reference -- applied to the bf16 build.
+    It does NOT hold (strict xfail: the day it does, this marker must go); what the bf16 build is held to is the
+    range-normalised regression bound of test_full_ddim25_mel_mae_bf16_regression below."""
+    mel, mr = _bf16_ddim25_mel(full, 21)
+    assert (mel - mr).abs().mean().item() < 1e-3
+
+
+def test_full_ddim25_mel_mae_bf16_regression(full):
+    """Regression tripwire of the bf16-operand build (NOT the north-star tolerance, see the strict xfail above): decoded mel MAE
+    vs the reference CPU sampler on identical seeds/inputs (B=1, 25-step DDIM, CFG 4.5; BASELINE.json config 1) below 1e-3 of
+    the reference mel's range and below 1.5 % of its sigma."""
     from diff_foley_amd import synth
     g = gold("g5_full_samplers.npz")
     for seed in (21, 22):
@@ -460,9 +484,8 @@ def test_full_ddim25_mel_mae(full):
         span = (mr.max() - mr.min()).item()
         print(f"seed {seed}: z rel-L2 {rel_l2(z.cpu(), zr):.3e}; mel MAE {mae:.3e} (mel std {mr.std().item():.3f}, "
               f"range [{mr.min().item():.2f}, {mr.max().item():.2f}]); MAE on the [0,1]-normalised mel {mae / span:.3e}")
-        # north-star tolerance: mel-spec MAE < 1e-3 with the mel in [0,1] (data_preprocess/wav2spec.py:142-155 clips the
-        # training mels to [0,1]).  The random-weight decoder is not confined to [0,1], so the reference mel's own
-        # range is used as the unit; the absolute bound keeps the bf16-vs-fp32 error at < 1.5 % of the signal's sigma.
+        # training mels live in [0,1] (data_preprocess/wav2spec.py:142-155); the random-weight decoder is not confined to it,
+        # so the reference mel's own range is the unit here; the second bound keeps the bf16-vs-fp32 error below 1.5 % of sigma
         assert mae / span < 1e-3
         assert mae < 1.5e-2 * mr.std().item()
 
