@@ -83,8 +83,21 @@ enum GemmTile {
   TILE_HALO_128x64_D = 15, TILE_HALO_256x64_D = 16,
   // 192 output pixels (three 4x16 patches) x 64 couts, 4 wavefronts of 96x32: (8192, 320) becomes 43 x 5 = 215 blocks on 256 CUs
   // where the 256x64 tile gives 160 (the model's channel counts are 5 * 2^k: power-of-two tiles leave 3/8 of the CUs idle)
-  TILE_HALO_192x64 = 17, TILE_ALL = 18
+  TILE_HALO_192x64 = 17,
+  // generic kernel with a DEEP WEIGHT RING (gemm_impl.h NSTB): activations double-buffered (L2 hits), weights requested 5-11 K
+  // steps ahead -- for the M <= 512 layers whose 26-59 MB of weights arrive cold from HBM every step
+  TILE_256x64_W = 18, TILE_128x64_W = 19, TILE_128x128_W = 20, TILE_ALL = 21
 };
+static inline bool gemm_tile_is_deepw(int cfg) { return cfg >= TILE_256x64_W && cfg <= TILE_128x128_W; }
+// ring depths (activation ring, weight ring) of the generic tiles; 0 for halo tiles
+static inline void gemm_tile_rings(int cfg, int* nsta, int* nstb) {
+  static const int a[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 2, 2, 2};
+  static const int b[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 10, 12, 6};
+  *nsta = a[cfg];
+  *nstb = b[cfg];
+}
+// 64-column slots of row statistics a LayerNorm-folded GEMM can fold per row (gemm_impl.h LNS): C <= 1280
+static inline int gemm_ln_max_slots() { return 20; }
 
 static inline bool gemm_tile_is_halo(int cfg) {
   return (cfg >= TILE_HALO_128x64 && cfg <= TILE_HALO_128x128) || cfg == TILE_HALO_128x64_D || cfg == TILE_HALO_256x64_D ||
@@ -96,7 +109,7 @@ static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
   static const int d[TILE_ALL][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
                                      {128, 64},  {256, 64}, {128, 128}, {128, 256}, {256, 128},
                                      {128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
-                                     {128, 64}, {256, 64}, {192, 64}};
+                                     {128, 64}, {256, 64}, {192, 64}, {256, 64}, {128, 64}, {128, 128}};
   *bm = d[cfg][0];
   *bn = d[cfg][1];
 }

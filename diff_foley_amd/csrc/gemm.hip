@@ -21,6 +21,8 @@ hipError_t launch_gemm_m1(int tile_cfg, int epi, const GemmParams& p, int zdim, 
 hipError_t launch_gemm_m2(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 hipError_t launch_gemm_halo(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 hipError_t launch_gemm_m3(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
+hipError_t launch_gemm_w0(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
+hipError_t launch_gemm_w12(int mode, int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 
 namespace {
 
@@ -128,7 +130,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
 bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int nk = p.K / 64;
   if (p.taps == 4) {     // phase-decomposed upsample conv (MODE 3): a subset of the generic tiles, plain epilogues only
-    static const bool ok3[TILE_ALL] = {false, false, false, true, false, false, false, false, true, true, true, true, true, true, false, false, false, false};
+    static const bool ok3[TILE_ALL] = {false, false, false, true, false, false, false, false, true, true, true, true, true, true, false, false, false, false,
+                                       false, false, false};
     if (tile < 0 || tile >= TILE_ALL || !ok3[tile] || batch > 1) return false;
     if (p.geglu || p.vt || p.ln_stats || p.stats || p.w_rows > 0 || p.sm_w > 0 || p.Cin2 > 0 || p.res || p.store_nchw) return false;
     if (splitk > 1 && (p.N & 3) != 0) return false;
@@ -141,13 +144,7 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
     gemm_tile_dims(tile, &bm_, &bn_);
     if (p.vt && (splitk > 1 || batch > 1 || p.vt_col0 % bn_ != 0)) return false;   // transposed-V tiles are whole tiles
     if (p.ln_stats && (batch > 1 || (p.geglu && splitk > 1))) return false;
-    if (p.ln_stats && splitk <= 1) {     // row partials: <= 5 float2 per thread, parked in LDS behind the ring
-      static const int nst[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0};
-      const int threads = (tile == TILE_128x256 || tile == TILE_256x128) ? 512 : 256;
-      const size_t ring = (size_t)(bm_ + bn_) * 128 * nst[tile], stage = (size_t)bm_ * (bn_ + 4) * 4 + (size_t)bm_ * 8;
-      if (bm_ * p.ln_slots > 5 * threads) return false;
-      if ((size_t)bm_ * p.ln_slots * 8 > ring || std::max(ring, stage) > 160 * 1024) return false;
-    }
+    if (p.ln_stats && p.ln_slots > gemm_ln_max_slots()) return false;    // thread r folds the partials of tile row r (<= 20 slots)
     if (p.stats && batch > 1) return false;
     if (p.w_rows > 0 && (batch > 1 || p.taps != 1 || p.w_rows % bm_ != 0 || p.M % p.w_rows != 0)) return false;
     if (p.sm_w > 0 && (p.sm_w != 32 || splitk > 1 || !p.ln_stats || !p.out_bf16 || p.w_rows <= 0 || (p.N & 31) != 0 || p.geglu ||
@@ -211,6 +208,7 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
       return hipErrorInvalidValue;
     e = launch_gemm_m3(tile_cfg, epi, p, zdim, stream);
   } else if (gemm_tile_is_halo(tile_cfg)) e = launch_gemm_halo(tile_cfg, epi, p, zdim, stream);
+  else if (gemm_tile_is_deepw(tile_cfg)) e = (mode == 0) ? launch_gemm_w0(tile_cfg, epi, p, zdim, stream) : launch_gemm_w12(mode, tile_cfg, epi, p, zdim, stream);
   else if (mode == 0) e = (tile_cfg <= TILE_256x128) ? launch_gemm_m0a(tile_cfg, epi, p, zdim, stream) : launch_gemm_m0b(tile_cfg, epi, p, zdim, stream);
   else if (mode == 1) e = launch_gemm_m1(tile_cfg, epi, p, zdim, stream);
   else e = launch_gemm_m2(tile_cfg, epi, p, zdim, stream);
@@ -225,7 +223,7 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
     if ((q.N & 3) != 0 || (q.ldc & 3) != 0 || q.store_nchw) return hipErrorInvalidValue;
 #define DF_RED3(SK) case SK: hipLaunchKernelGGL(splitk_reduce_vec_kernel<SK>, dim3(blocks), dim3(256), 0, stream, q); break;
     switch (p.splitk) {
-      DF_RED3(2) DF_RED3(4) DF_RED3(8) DF_RED3(16) DF_RED3(32)
+      DF_RED3(2) DF_RED3(3) DF_RED3(4) DF_RED3(6) DF_RED3(8) DF_RED3(12) DF_RED3(16) DF_RED3(24) DF_RED3(32)
       default: hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, q); break;
     }
 #undef DF_RED3
@@ -241,7 +239,7 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
       if (blocks > 4096) blocks = 4096;
 #define DF_RED(SK) case SK: hipLaunchKernelGGL(splitk_reduce_vec_kernel<SK>, dim3(blocks), dim3(256), 0, stream, p); break;
       switch (p.splitk) {
-        DF_RED(2) DF_RED(4) DF_RED(8) DF_RED(16) DF_RED(32)
+        DF_RED(2) DF_RED(3) DF_RED(4) DF_RED(6) DF_RED(8) DF_RED(12) DF_RED(16) DF_RED(24) DF_RED(32)
         default: hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p); break;
       }
 #undef DF_RED

@@ -465,7 +465,13 @@ __device__ __forceinline__ void tile_of(int lid, int nbm, int nbn, int gm, int& 
   mt = grp * gm + (rem - nt * rows);
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI>
+// NSTB = depth of the W ring when it differs from the A ring's NST ("deep weight ring" tiles for the weight-streaming layers):
+// the weight tiles are requested NSTB - 1 K steps ahead, the activation tiles NST - 1.  Why: M <= 512 layers stream 26-59 MB of
+// weights that arrive COLD from HBM every step (1.7 GB of weights per step against 256 MB of Infinity Cache), and every weight
+// tile is requested by all M tiles of the layer at once, so the UNIQUE bytes in flight are (blocks x W bytes in flight per
+// block) / (M tiles).  With one 16 KB stage per block that is ~1.5 MB chip-wide = 0.8 TB/s at ~2 us of loaded HBM latency --
+// the rate these layers were measured at.  Activations are L2 hits (just written, re-read by every N tile): two stages suffice.
+template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI, int NSTB = NST>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // host pass only needs the launch stub (LDS-DMA builtins do not parse there)
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -476,6 +482,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the DMA pass");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(NST >= 2 && NST <= 5, "ring depth");
+  static_assert(NSTB >= NST && NSTB <= 16, "weight ring depth");
+  constexpr int WD = NSTB - NST;              // extra K steps the weight requests run ahead of the activation requests
+  constexpr int WSLOT = BN * BK * 2;          // bytes of one weight ring slot
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WGN, wn = wid % WGN;
@@ -495,19 +504,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   tile_of(lid, nbm, nbn, p.gm, mt_, nt_);
   const int m0 = mt_ * BM, n0 = nt_ * BN;
 
-  // LayerNorm folded into this GEMM: the producer's per-row (sum, sumsq) partials of this tile's rows are one
-  // contiguous run of BM * ln_slots float2; every thread requests its share FIRST (<= LNPT 8-byte loads, in flight
-  // under the operand prologue), keeps it in registers through the main loop, and after the loop the shares are exchanged
-  // through the (dead) ring so that thread r < BM folds row r's slots to (mean, rstd).  Nothing on the critical path waits
-  // for these loads.
-  constexpr int LNPT = 5;
+  // LayerNorm folded into this GEMM: thread r < BM requests the producer's per-row (sum, sumsq) partials of tile row r FIRST
+  // (<= LNS 8-byte loads, in flight under the operand prologue) and folds them to (mean, rstd) just before the first ring wait
+  // -- by then they have landed (loads retire in order and these are older than the operand requests).  Two registers per thread
+  // ride through the main loop; any tile shape can serve the 1280-channel level (20 slots per row), and nothing is exchanged
+  // through LDS after the loop.  (Rounds 2-3 carried <= 5 thread-linear float2 per thread and reduced after the loop: 256-row
+  // tiles at C = 1280 did not fit, and the exchange cost a barrier + an LDS round trip per block.)
+  constexpr int LNS = 20;
   const bool ln_on = MODE == 0 && (EPI == EPI_LNC || EPI == EPI_GEGLU || EPI == EPI_XS) && p.ln_stats != nullptr;
-  float2 lnv[LNPT];
+  float2 lnv[LNS];
   if (ln_on) {
-    const int cnt = min(BM, p.M - m0) * p.ln_slots;
-    const float2* sp = p.ln_stats + (long)m0 * p.ln_slots;
+    const float2* sp = p.ln_stats + (long)min(m0 + min(tid, BM - 1), p.M - 1) * p.ln_slots;
 #pragma unroll
-    for (int i = 0; i < LNPT; ++i) lnv[i] = sp[min(tid + i * NT, cnt - 1)];
+    for (int i = 0; i < LNS; ++i)
+      if (i < p.ln_slots) lnv[i] = sp[i];
   }
 
   int z = blockIdx.z;
@@ -674,17 +684,34 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
         ++d_tap;                                                                                \
       }                                                                                         \
     }                                                                                           \
-    {                                                                                           \
+    if constexpr (WD == 0) {                                                                    \
       const unsigned kb = live ? k0b : OOB;                                                     \
       _Pragma("unroll") for (int i = 0; i < BP; ++i)                                            \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(dmaB + ((ST) * BN + i * RPP) * (BK * 2)), 16, \
                                                  b_off[i] + kb, 0, 0, 0);                       \
+    } else {   /* deep weight ring: tile T + WD into the running write slot */                  \
+      DF_DMA_W((T) + WD);                                                                       \
     }                                                                                           \
+  }
+  // weight tile TW into the W ring's running write slot (deep-ring tiles only)
+  int w_wr = 0, w_rd = 0;        // byte offsets of the W ring's write / read slot
+#define DF_DMA_W(TW)                                                                              \
+  {                                                                                             \
+    const unsigned kbw = ((TW) < nt) ? ((p.dbg & 1) ? 0u : (unsigned)(kt0 + (TW)) * (BK * 2)) : OOB; \
+    _Pragma("unroll") for (int i = 0; i < BP; ++i)                                              \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(dmaB + w_wr + i * RPP * (BK * 2)), 16, \
+                                               b_off[i] + kbw, 0, 0, 0);                        \
+    w_wr += WSLOT;                                                                              \
+    if (w_wr == NSTB * WSLOT) w_wr = 0;                                                         \
   }
 
   // ---- prologue: fill NST-1 ring slots -- as early as the request offsets exist.  Everything below (accumulator init,
   // fragment offsets, epilogue prefetch: ~150-700 instructions) runs while the first tiles are in flight instead of in front of
   // them; the epilogue prefetch's loads are then younger than these requests, which only makes the first ring wait stricter.
+  if constexpr (WD > 0) {     // the weight stream leads: tiles 0 .. WD-1 first, then the pairs [A(i), W(i + WD)] of the steady state
+#pragma unroll
+    for (int tw = 0; tw < WD; ++tw) DF_DMA_W(tw);
+  }
   DF_DMA(0, 0);
   if (NST > 2) DF_DMA(1, 1);
   if (NST > 3) DF_DMA(2, 2);
@@ -720,7 +747,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
       DSTA[i] = *reinterpret_cast<const bf16x8*>(fA[i][S] + (ST) * BM * BK * 2);                \
     _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
-      DSTB[j] = *reinterpret_cast<const bf16x8*>(fB[j][S] + (ST) * BN * BK * 2);                \
+      DSTB[j] = *reinterpret_cast<const bf16x8*>(fB[j][S] + (WD == 0 ? (ST) * BN * BK * 2 : w_rd)); \
   }
 #define DF_MMA(SRCA, SRCB, ACC)                                                                   \
   {                                                                                             \
@@ -754,14 +781,32 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     DF_MMA(a1, b1, acc);                                                                        \
     DF_FRAG(a1, b1, 3, ST);                                                                     \
     DF_MMA(a0, b0, acc);                                                                        \
-    DF_RING_SYNC((NST - 2) * LPT);                                                              \
+    DF_RING_SYNC((NST - 2) * LPT + (WD > 0 ? BP : 0));   /* deep W ring: the W request paired with A(it+1) is younger */ \
     DF_MMA(a1, b1, acc);                                                                        \
     ++it;                                                                                       \
+    if constexpr (WD > 0) {                                                                     \
+      w_rd += WSLOT;                                                                            \
+      if (w_rd == NSTB * WSLOT) w_rd = 0;                                                       \
+    }                                                                                           \
   }
   const EpiVec ev = epi_prefetch<BN, NT, EPI>(p, n0, tid);
 
+  float2 ln_mr = make_float2(0.f, 1.f);
+  if (ln_on) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNS; ++i)
+      if (i < p.ln_slots) {
+        s1 += lnv[i].x;
+        s2 += lnv[i].y;
+      }
+    const float inv = 1.0f / (float)p.ln_C;
+    const float mean = s1 * inv;
+    ln_mr = make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
+  }
+
   int it = 0;
-  DF_RING_SYNC((NST - 2) * LPT);       // tile 0 landed and visible
+  DF_RING_SYNC((NST - 2) * LPT + (WD > 0 ? BP : 0));       // tile 0 landed and visible
   while (it < nt) {
     DF_ITER(0);
     if (it >= nt) break;
@@ -780,29 +825,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     }
   }
   wait_vmcnt<0>();                     // dead-slot requests of the last iterations must land before LDS is released
-
-  float2 ln_mr = make_float2(0.f, 1.f);
-  if (ln_on) {
-    // the partials rode in registers through the main loop (no LDS beside the ring: every tile shape stays available to
-    // the LayerNorm-folded GEMMs of the 1280-channel level); now the ring is dead and they are exchanged through it
-    __builtin_amdgcn_s_barrier();      // every wave is done reading the ring
-    float2* sLn = reinterpret_cast<float2*>(smem);
-#pragma unroll
-    for (int i = 0; i < LNPT; ++i)
-      if (tid + i * NT < BM * p.ln_slots) sLn[tid + i * NT] = lnv[i];
-    __syncthreads();
-  }
-  if (ln_on && tid < BM) {
-    const float2* sLn = reinterpret_cast<const float2*>(smem) + tid * p.ln_slots;
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < p.ln_slots; ++i) {
-      s1 += sLn[i].x;
-      s2 += sLn[i].y;
-    }
-    const float inv = 1.0f / (float)p.ln_C;
-    const float mean = s1 * inv;
-    ln_mr = make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
-  }
 
   // ---- epilogue
   if (p.dbg & 2) {   // tools: keep the accumulators alive, store nothing
@@ -1174,25 +1196,24 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI>
+template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI, int NSTB = NST>
 hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  constexpr size_t ring = (size_t)(BM + BN) * BK * 2 * NST;                    // operand ring
+  constexpr size_t ring = ((size_t)BM * NST + (size_t)BN * NSTB) * BK * 2;     // operand rings (A: NST slots, W: NSTB slots)
   constexpr size_t stage = (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8 + (MODE == 3 ? (size_t)BM * 4 : 0);   // epilogue tile + (mean, rstd) row table (+ MODE 3 pixel table)
   const size_t base = ring > stage ? ring : stage;
-  // LayerNorm-folded GEMMs park the producer's row partials behind the ring: BM * ln_slots float2
-  const size_t lds = base;           // LayerNorm row partials are exchanged through the dead ring after the main loop
-  if ((size_t)BM * p.ln_slots * 8 > ring) return hipErrorInvalidValue;
+  const size_t lds = base;
+  if (p.ln_stats && p.ln_slots > 20) return hipErrorInvalidValue;     // LNS of the kernel
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
     const size_t cap = std::min<size_t>(160 * 1024, base + (size_t)5 * 64 * WGM * WGN * 8);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE, EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE, EPI, NSTB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE, EPI>), dim3(nbm * nbn, 1, MODE == 3 ? 4 * zdim : zdim), dim3(64 * WGM * WGN), lds, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE, EPI, NSTB>), dim3(nbm * nbn, 1, MODE == 3 ? 4 * zdim : zdim), dim3(64 * WGM * WGN), lds, stream, p);
   return hipGetLastError();
 }
 
