@@ -3494,6 +3494,31 @@ int df_test_ln_chain(const uint16_t* A0, const uint16_t* W0, const float* b0, co
   });
 }
 
+// The LayerNorm-folded GEGLU projection alone, on caller-owned operands (timing probes: tools/pgeglu_probe.py).  stats [M][K/64]
+// float2, cs / bias [N1]; dbg = debug switches of the persistent kernel (ffn.hip) or DF_GEMM_DBG of the generic one.
+int df_test_geglu(const uint16_t* A, const uint16_t* W, const void* stats, const float* cs, const float* bias, uint16_t* out, int M,
+                  int K, int N1, int tile, int dbg, void* stream) {
+  return guard([&] {
+    GemmParams g = Builder::gp_linear(A, M, K, W, N1);
+    g.ln_stats = (const float2*)stats; g.ln_slots = K / 64; g.ln_C = K; g.ln_eps = 1e-5f; g.ln_cs = cs;
+    g.bias = bias;
+    Builder::out_b16(g, out, N1 / 2);
+    g.geglu = 1;
+    g.splitk = 1;
+    g.dbg = dbg;
+    if (dbg & 64) g.partial = test_partial((size_t)1024 * 32 * 8);     // per-block clock stamps (read back with df_test_scratch_read)
+    if (!gemm_tile_valid(g, tile, 1, 1)) fail("tile %d not valid for this GEGLU projection", tile);
+    HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
+  });
+}
+
+int df_test_scratch_read(void* host, int64_t bytes) {
+  return guard([&] {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host, test_partial((size_t)bytes), (size_t)bytes, hipMemcpyDeviceToHost));
+  });
+}
+
 int df_test_linear_rows(const float* a, int lda, const float* tvals, int t_B, const uint16_t* W, const float* bias,
                         float* out, int ldo, int M, int N, int K, int act, int lds_variant, void* stream) {
   return guard([&] {

@@ -86,13 +86,17 @@ enum GemmTile {
   TILE_HALO_192x64 = 17,
   // generic kernel with a DEEP WEIGHT RING (gemm_impl.h NSTB): activations double-buffered (L2 hits), weights requested 5-11 K
   // steps ahead -- for the M <= 512 layers whose 26-59 MB of weights arrive cold from HBM every step
-  TILE_256x64_W = 18, TILE_128x64_W = 19, TILE_128x128_W = 20, TILE_ALL = 21
+  TILE_256x64_W = 18, TILE_128x64_W = 19, TILE_128x128_W = 20,
+  // persistent LayerNorm-folded GEGLU projection (ffn.hip): 2 resident blocks per CU walk a tile queue, one continuous operand
+  // stream across tiles, epilogue out of the accumulator registers.  128 x 128 tiles (C <= 640) / 64 x 128 tiles.
+  TILE_PGEGLU_128 = 21, TILE_PGEGLU_64 = 22, TILE_ALL = 23
 };
+static inline bool gemm_tile_is_pgeglu(int cfg) { return cfg == TILE_PGEGLU_128 || cfg == TILE_PGEGLU_64; }
 static inline bool gemm_tile_is_deepw(int cfg) { return cfg >= TILE_256x64_W && cfg <= TILE_128x128_W; }
 // ring depths (activation ring, weight ring) of the generic tiles; 0 for halo tiles
 static inline void gemm_tile_rings(int cfg, int* nsta, int* nstb) {
-  static const int a[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 2, 2, 2};
-  static const int b[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 10, 12, 6};
+  static const int a[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 2, 2, 2, 2, 3};
+  static const int b[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 10, 12, 6, 2, 3};
   *nsta = a[cfg];
   *nstb = b[cfg];
 }
@@ -109,7 +113,7 @@ static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
   static const int d[TILE_ALL][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
                                      {128, 64},  {256, 64}, {128, 128}, {128, 256}, {256, 128},
                                      {128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
-                                     {128, 64}, {256, 64}, {192, 64}, {256, 64}, {128, 64}, {128, 128}};
+                                     {128, 64}, {256, 64}, {192, 64}, {256, 64}, {128, 64}, {128, 128}, {128, 128}, {64, 128}};
   *bm = d[cfg][0];
   *bn = d[cfg][1];
 }

@@ -22,6 +22,8 @@ hipError_t launch_gemm_m2(int tile_cfg, int epi, const GemmParams& p, int zdim, 
 hipError_t launch_gemm_halo(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 hipError_t launch_gemm_m3(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 hipError_t launch_gemm_w0(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
+hipError_t launch_gemm_pgeglu(int tile_cfg, const GemmParams& p, hipStream_t stream);
+bool pgeglu_valid(const GemmParams& p, int tile, int batch, int splitk);
 hipError_t launch_gemm_w12(int mode, int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 
 namespace {
@@ -131,12 +133,13 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int nk = p.K / 64;
   if (p.taps == 4) {     // phase-decomposed upsample conv (MODE 3): a subset of the generic tiles, plain epilogues only
     static const bool ok3[TILE_ALL] = {false, false, false, true, false, false, false, false, true, true, true, true, true, true, false, false, false, false,
-                                       false, false, false};
+                                       false, false, false, false, false};
     if (tile < 0 || tile >= TILE_ALL || !ok3[tile] || batch > 1) return false;
     if (p.geglu || p.vt || p.ln_stats || p.stats || p.w_rows > 0 || p.sm_w > 0 || p.Cin2 > 0 || p.res || p.store_nchw) return false;
     if (splitk > 1 && (p.N & 3) != 0) return false;
     return splitk == 1 || nk / splitk >= 2;
   }
+  if (gemm_tile_is_pgeglu(tile)) return pgeglu_valid(p, tile, batch, splitk);
   if (!gemm_tile_is_halo(tile)) {
     if (tile < 0 || tile >= TILE_ALL) return false;
     if (p.geglu && ((p.N & 63) != 0 || (p.ldc & 3) != 0)) return false;   // GEGLU needs the vectorised block epilogue
@@ -178,6 +181,10 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
 }
 
 hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t stream) {
+  if (gemm_tile_is_pgeglu(tile_cfg)) {
+    if (!pgeglu_valid(p, tile_cfg, batch, p.splitk)) return hipErrorInvalidValue;
+    return launch_gemm_pgeglu(tile_cfg, p, stream);
+  }
   const int zdim = (p.splitk > 1) ? p.splitk : (batch > 0 ? batch : 1);
   if (p.ln_stats || p.stats || p.vt) {     // these epilogues exist in the vectorised paths only
     const bool vec = !p.store_nchw && (p.N & 63) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.ld_rowbias & 3) == 0 &&

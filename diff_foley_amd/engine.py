@@ -101,6 +101,9 @@ _SIGS = {
     "df_debug_checksums": [C.c_void_p, C.c_int, C.c_int64],
     "df_debug_checksums_read": [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(C.c_int64)],
     "df_debug_checksum_label": [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64],
+    "df_test_geglu": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                      C.c_int, C.c_void_p],
+    "df_test_scratch_read": [C.c_void_p, C.c_int64],
     "df_debug_saturations": [C.c_void_p, C.c_int, C.c_int64],
     "df_debug_saturations_read": [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(C.c_int64)],
     "df_debug_saturation_label": [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64],
@@ -142,8 +145,8 @@ def lib(precision=None):
                                "(there is no CPU/torch fallback for the sampling path)")
         L = C.CDLL(path)
         for name, args in _SIGS.items():
-            if os.environ.get("DF_LIB_OVERRIDE") and name.startswith(("df_test_", "df_debug_", "df_tune_cache_")) and not hasattr(L, name):
-                continue                      # A/B against an older build that predates a unit-test / debug entry point
+            if os.environ.get("DF_LIB_OVERRIDE") and not hasattr(L, name):
+                continue                      # tools: A/B against an older build that predates an entry point
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = C.c_int

@@ -342,7 +342,10 @@ def _ln_chain_ref(A0, W0, b0, res, gamma, beta, W1, b1, mode):
 @pytest.mark.parametrize("M,C,T,tile0,sk0,tile1,sk1", [
     (1024, 320, 256, 3, 1, 3, 1), (1024, 320, 256, 13, 1, 2, 1), (512, 640, 64, 1, 1, 12, 1), (128, 1280, 16, 3, 4, 3, 1),
     (256, 128, 64, 0, 1, 0, 1), (512, 64, 128, 4, 1, 13, 1), (2048, 320, 1024, 9, 1, 8, 1), (128, 1280, 16, 3, 4, 3, 2),
-    (512, 1280, 64, 19, 1, 18, 1), (512, 1280, 64, 20, 2, 20, 1), (256, 640, 64, 18, 1, 19, 1)])
+    (512, 1280, 64, 19, 1, 18, 1), (512, 1280, 64, 20, 2, 20, 1), (256, 640, 64, 18, 1, 19, 1),
+    # 21 / 22: the persistent GEGLU kernel (ffn.hip); valid for mode 1 only -- several tiles per block, ragged last row tile
+    (8192, 320, 1024, 3, 1, 21, 1), (2048, 640, 256, 3, 1, 21, 1), (512, 1280, 64, 3, 1, 22, 1), (1024, 320, 256, 13, 1, 22, 1),
+    (192, 128, 64, 0, 1, 21, 1), (4096, 640, 256, 3, 1, 22, 1)])
 def test_ln_folded_gemm_chain(mode, M, C, T, tile0, sk0, tile1, sk1):
     """LayerNorm never runs as a kernel in the SpatialTransformer: statistics come out of the producer's epilogue and
     the consumer applies them (csrc/gemm.hip epilogue_block / splitk_reduce_vec_kernel)."""
@@ -350,7 +353,10 @@ def test_ln_folded_gemm_chain(mode, M, C, T, tile0, sk0, tile1, sk1):
     if sk1 > 1 and mode != 0:
         pytest.skip("split-K consumers exist only for the plain LN-folded projection")
     N1 = {0: C, 1: 8 * C if C <= 320 else 2 * C, 2: 3 * C}[mode]
-    bn = {0: 128, 1: 64, 2: 128, 3: 64, 4: 128, 8: 256, 9: 128, 10: 128, 11: 64, 12: 128, 13: 64, 14: 128, 18: 64, 19: 64, 20: 128}
+    bn = {0: 128, 1: 64, 2: 128, 3: 64, 4: 128, 8: 256, 9: 128, 10: 128, 11: 64, 12: 128, 13: 64, 14: 128, 18: 64, 19: 64, 20: 128,
+          21: 128, 22: 128}
+    if tile1 in (21, 22) and mode != 1:
+        pytest.skip("the persistent kernel is the GEGLU projection only")
     if mode == 2 and (2 * C) % bn[tile1] != 0:
         tile1 = 3                                   # the transposed-V columns must start on a tile boundary
     A0 = bf(rnd((M, C), 40))
