@@ -84,8 +84,9 @@ enum GemmTile {
   // 192 output pixels (three 4x16 patches) x 64 couts, 4 wavefronts of 96x32: (8192, 320) becomes 43 x 5 = 215 blocks on 256 CUs
   // where the 256x64 tile gives 160 (the model's channel counts are 5 * 2^k: power-of-two tiles leave 3/8 of the CUs idle)
   TILE_HALO_192x64 = 17,
-  // generic kernel with a DEEP WEIGHT RING (gemm_impl.h NSTB): activations double-buffered (L2 hits), weights requested 5-11 K
-  // steps ahead -- for the M <= 512 layers whose 26-59 MB of weights arrive cold from HBM every step
+  // RESERVED ids (round-4 experiment, measured and not built: experiments/deep_weight_ring_tiles.md): generic kernel with a deep
+  // weight ring (gemm_impl.h NSTB: activations double-buffered, weights requested 5-11 K steps ahead) for the M <= 512 layers
+  // whose 26-59 MB of weights arrive cold from HBM every step.  No better than the shared ring on any layer (tools/cold_probe.py).
   TILE_256x64_W = 18, TILE_128x64_W = 19, TILE_128x128_W = 20,
   // persistent LayerNorm-folded GEGLU projection (ffn.hip): 2 resident blocks per CU walk a tile queue, one continuous operand
   // stream across tiles, epilogue out of the accumulator registers.  128 x 128 tiles (C <= 640) / 64 x 128 tiles.

@@ -140,6 +140,7 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
     return splitk == 1 || nk / splitk >= 2;
   }
   if (gemm_tile_is_pgeglu(tile)) return pgeglu_valid(p, tile, batch, splitk);
+  if (gemm_tile_is_deepw(tile)) return false;      // measured, not built into the product (gemm.h)
   if (!gemm_tile_is_halo(tile)) {
     if (tile < 0 || tile >= TILE_ALL) return false;
     if (p.geglu && ((p.N & 63) != 0 || (p.ldc & 3) != 0)) return false;   // GEGLU needs the vectorised block epilogue
@@ -215,7 +216,7 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
       return hipErrorInvalidValue;
     e = launch_gemm_m3(tile_cfg, epi, p, zdim, stream);
   } else if (gemm_tile_is_halo(tile_cfg)) e = launch_gemm_halo(tile_cfg, epi, p, zdim, stream);
-  else if (gemm_tile_is_deepw(tile_cfg)) e = (mode == 0) ? launch_gemm_w0(tile_cfg, epi, p, zdim, stream) : launch_gemm_w12(mode, tile_cfg, epi, p, zdim, stream);
+  else if (gemm_tile_is_deepw(tile_cfg)) e = hipErrorInvalidValue;
   else if (mode == 0) e = (tile_cfg <= TILE_256x128) ? launch_gemm_m0a(tile_cfg, epi, p, zdim, stream) : launch_gemm_m0b(tile_cfg, epi, p, zdim, stream);
   else if (mode == 1) e = launch_gemm_m1(tile_cfg, epi, p, zdim, stream);
   else e = launch_gemm_m2(tile_cfg, epi, p, zdim, stream);
