@@ -2469,11 +2469,10 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
     GemmParams g = o.gp;
     std::vector<TuneCand>& v = cands[key];
     for (int t = 0; t < TILE_ALL && t < tile_cap; ++t) {
-      // deep-weight-ring tiles also try 3 * 2^k splits: 2 M tiles x 20 N tiles x 6 = 240 blocks fill 256 CUs where 4 / 8 give 160 / 320
-      static const int sks_pow2[] = {1, 2, 4, 8, 16, 32}, sks_w[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
-      const int* sks = gemm_tile_is_deepw(t) ? sks_w : sks_pow2;
-      const int nsks = gemm_tile_is_deepw(t) ? 10 : 6;
-      for (int si = 0; si < nsks; ++si) {
+      // 3 * 2^k splits too: 2 M tiles x 20 N tiles x 6 = 240 blocks fill 256 CUs where 4 / 8 give 160 / 320 (tools/cold_probe.py:
+      // sk 3 / 6 / 12 are the best factor of most weight-streaming layers)
+      static const int sks[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+      for (int si = 0; si < 10; ++si) {
         const int sk = sks[si];
         if (!gemm_tile_valid(g, t, o.batch, sk)) { if (sk > 1) break; else continue; }
         const size_t need = (size_t)sk * g.M * g.N * 4 * (g.taps == 4 ? 4 : 1);
