@@ -3595,6 +3595,7 @@ int df_test_conv3x3(const uint16_t* A, const uint16_t* W, const float* bias, flo
     g.splitk = splitk;
     g.dbg = getenv("DF_GEMM_DBG") ? atoi(getenv("DF_GEMM_DBG")) : 0;
     if (splitk > 1) g.partial = test_partial((size_t)splitk * g.M * g.N * 4);
+    else if (g.dbg & 64) g.partial = test_partial((size_t)4096 * 32 * 8);      // halo kernels: per-block clock stamps
     HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
   });
 }

@@ -963,6 +963,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   const int wm = wid / WGN, wn = wid % WGN;
   const int l31 = lane & 31, lh = lane >> 5;
 
+  // tools (p.dbg bit 6, split-K 1): thread 0 stamps the shader clock at phase boundaries into p.partial[block][32] (uint64)
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if ((p.dbg & 64) && tid == 0 && n_stamp < 32)
+      reinterpret_cast<unsigned long long*>(p.partial)[(long)blockIdx.x * 32 + n_stamp++] = __builtin_amdgcn_s_memtime();
+  };
+  stamp();
   const int TH = p.th, TW = p.tw, HWp = (TH + 2) * (TW + 2), PPX = TH * TW;
   const int PB = BM / PPX;                      // patches per block
   const int HR = PB * HWp;                      // halo rows
@@ -1067,6 +1074,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
 #pragma unroll
   for (int t = 0; t < NSTW - 1; ++t) DF_HALO_W(t, t);
   __builtin_amdgcn_sched_barrier(0);
+  stamp();
 
   // ---- MFMA row -> halo row of tap (0,0) and output pixel index
   int hb[TM], hbx[TM], hbq[TM];
@@ -1148,7 +1156,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
     DF_HALO_MMA(af0, bf0);                                                                      \
   }
 
+  stamp();
   DF_HALO_SYNC(0);
+  stamp();
   for (int cs = 0; cs < nc; ++cs) {
     DF_TAP(0)
     DF_TAP(1)
@@ -1159,8 +1169,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
     DF_TAP(6)
     DF_TAP(7)
     DF_TAP(8)
+    stamp();
   }
   wait_vmcnt<0>();
+  stamp();
 
   // ---- epilogue: tile row -> NHWC pixel index of its output pixel.  Five integer divisions per row: computed once per
   // row into a BM-entry LDS table behind the operand ring instead of once per 4-column chunk of the epilogue loop.
@@ -1178,6 +1190,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   auto rowmap = [&](int rr) { return srow[rr]; };
   if constexpr (EPI != EPI_ANY) {
     epilogue_block<BM, BN, NT, TM, TN, EPI>(p, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap, ev);
+    stamp();
   } else {
     const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
                         (p.ld_rowbias & 3) == 0 && (p.ld_aux & 3) == 0;
