@@ -376,17 +376,17 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       v.x = mr.y * (v.x - mr.x * cs.x); v.y = mr.y * (v.y - mr.x * cs.y);                                           \
       v.z = mr.y * (v.z - mr.x * cs.z); v.w = mr.y * (v.w - mr.x * cs.w);                                           \
     }                                                                                                               \
-    if (has_bias) {                                                                                                 \
+    if (has_bias_l) {                                                                                               \
       const float4 b = hb0;                                                                                         \
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
     }                                                                                                               \
-    if (has_rb) {                                                                                                   \
+    if (has_rb_l) {                                                                                                 \
       const int ri = (rps_sh >= 0) ? ((p.rowbias_mode == 1) ? (rc >> rps_sh) : (rc & (p.rows_per_sample - 1)))      \
                                    : ((p.rowbias_mode == 1) ? (rc / p.rows_per_sample) : (rc % p.rows_per_sample)); \
       const float4 b = *reinterpret_cast<const float4*>(&p.rowbias[(long)ri * p.ld_rowbias + cc]);                  \
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
     }                                                                                                               \
-    if (has_res) {                                                                                                  \
+    if (has_res_l) {                                                                                                \
       const float4 b = *reinterpret_cast<const float4*>(&p.res[(long)batch * p.res_bs + (long)rc * p.ldr + cc]);    \
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;                                                               \
     }                                                                                                               \
@@ -426,6 +426,47 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       }                                                                                                             \
     }                                                                                                               \
   }
+  // Per-sample bias (FiLM) and fp32 residual of the plain epilogues: ALL their loads first, then added into the parked tile.
+  // Inside the store loop each of them was `load; s_waitcnt vmcnt(0)` per iteration (run-time-optional loads sit behind branches,
+  // and the residual may alias C, so nothing could be hoisted over the previous iteration's store): a chain of up to 2 x 16
+  // round trips, 6.9 k of the 52 k cycles of a full-resolution conv (tools/halo_stamps.py).  Same summation order as before
+  // ((acc + bias) + FiLM) + residual, so results are bit-identical; every thread touches only the elements it stores later.
+  bool pre_added = false;
+  if constexpr (EPI == EPI_PROD || EPI == EPI_LEAN) {
+    constexpr int ITERS = BM * CPR / NT;
+    if (has_rb || has_res) {
+      float4 rbv[ITERS], rsv[ITERS];
+      if (has_rb) {
+#pragma unroll
+        for (int ei = 0; ei < ITERS; ++ei) {
+          const int e = tid + ei * NT, r = e / CPR, c4 = (e - r * CPR) * 4;
+          const int rc = min(rowmap(r), p.M - 1), cc = min(n0 + c4, p.N - 4);
+          const int ri = (rps_sh >= 0) ? ((p.rowbias_mode == 1) ? (rc >> rps_sh) : (rc & (p.rows_per_sample - 1)))
+                                       : ((p.rowbias_mode == 1) ? (rc / p.rows_per_sample) : (rc % p.rows_per_sample));
+          rbv[ei] = *reinterpret_cast<const float4*>(&p.rowbias[(long)ri * p.ld_rowbias + cc]);
+        }
+      }
+      if (has_res) {
+#pragma unroll
+        for (int ei = 0; ei < ITERS; ++ei) {
+          const int e = tid + ei * NT, r = e / CPR, c4 = (e - r * CPR) * 4;
+          const int rc = min(rowmap(r), p.M - 1), cc = min(n0 + c4, p.N - 4);
+          rsv[ei] = *reinterpret_cast<const float4*>(&p.res[(long)batch * p.res_bs + (long)rc * p.ldr + cc]);
+        }
+      }
+#pragma unroll
+      for (int ei = 0; ei < ITERS; ++ei) {
+        const int e = tid + ei * NT, r = e / CPR, c4 = (e - r * CPR) * 4;
+        float4 v = *reinterpret_cast<const float4*>(&sC[r * LDC + c4]);
+        if (has_bias) { v.x += hb0.x; v.y += hb0.y; v.z += hb0.z; v.w += hb0.w; }
+        if (has_rb) { v.x += rbv[ei].x; v.y += rbv[ei].y; v.z += rbv[ei].z; v.w += rbv[ei].w; }
+        if (has_res) { v.x += rsv[ei].x; v.y += rsv[ei].y; v.z += rsv[ei].z; v.w += rsv[ei].w; }
+        *reinterpret_cast<float4*>(&sC[r * LDC + c4]) = v;
+      }
+      pre_added = true;
+    }
+  }
+  const bool has_bias_l = has_bias && !pre_added, has_rb_l = has_rb && !pre_added, has_res_l = has_res && !pre_added;
   if constexpr (EPI == EPI_PROD) DF_EPI_LOOP(5)
   else if constexpr (EPI == EPI_LNC) DF_EPI_LOOP(2)
   else if constexpr (EPI == EPI_ANY) {
