@@ -220,6 +220,10 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
   const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   float2* sRow = reinterpret_cast<float2*>(sC + BM * LDC);   // (mean, rstd) of tile row r (LayerNorm-folded GEMMs)
   const float4 hb0 = ev.hb0, hb1 = ev.hb1, hc0 = ev.hc0, hc1 = ev.hc1;
+#define DF_EPI_STAMP(K) \
+  if ((p.dbg & 64) && p.splitk <= 1 && p.partial && tid == 0) \
+    reinterpret_cast<unsigned long long*>(p.partial)[(long)blockIdx.x * 32 + 24 + (K)] = __builtin_amdgcn_s_memtime();
+  DF_EPI_STAMP(0)
   __builtin_amdgcn_s_barrier();            // every wave is done reading the operand ring
   if ((EPI == EPI_LNC || EPI == EPI_GEGLU || EPI == EPI_XS) && p.ln_stats && tid < BM) sRow[tid] = ln_mr;
 #pragma unroll
@@ -230,6 +234,7 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       for (int r = 0; r < 16; ++r)
         sC[(wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wcol0 + j * 32 + l31] = acc[i][j][r];
   __syncthreads();
+  DF_EPI_STAMP(1)
   const bool has_bias = p.bias != nullptr, has_rb = p.rowbias != nullptr, has_res = p.res != nullptr;
   if constexpr (EPI == EPI_SPLITK) {
     float* part = p.partial + (long)z * p.M * p.N;
@@ -466,7 +471,46 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       pre_added = true;
     }
   }
+  DF_EPI_STAMP(2)
   const bool has_bias_l = has_bias && !pre_added, has_rb_l = has_rb && !pre_added, has_res_l = has_res && !pre_added;
+  // Lean store loops for the two common cases.  The general loop below decides everything per iteration (output type, second
+  // copy, duplicated rows, activations, 64-bit index products): ~90 instruction slots = 375 cycles per 16-byte store, 4.5 k cycles
+  // for the 12 stores of a full-resolution conv tile (tools/halo_stamps.py).  A thread keeps one column chunk and walks rows at a
+  // fixed stride, so here an iteration is: tile row -> output row, one LDS read, (bias), store.
+  if constexpr (EPI == EPI_LEAN || EPI == EPI_PROD) {
+    constexpr int ITERS = BM * CPR / NT, RSTEP = NT / CPR;
+    const bool plain = !p.dup_rows && !p.silu && !p.relu && (EPI == EPI_PROD || (!p.out_bf16 && !p.aux));
+    if (plain) {
+      const int rb0 = tid / CPR, c4 = (tid - rb0 * CPR) * 4, col = n0 + c4;
+      const bool colok = col < p.N;
+      const long cbase = (long)batch * p.c_bs + col;
+#pragma unroll
+      for (int ei = 0; ei < ITERS; ++ei) {
+        const int r = rb0 + ei * RSTEP;
+        const int row = rowmap(r);
+        float4 v = *reinterpret_cast<const float4*>(&sC[r * LDC + c4]);
+        if (has_bias_l) { v.x += hb0.x; v.y += hb0.y; v.z += hb0.z; v.w += hb0.w; }
+        const bool ok = colok && row < p.M;
+        if constexpr (EPI == EPI_PROD) {
+          const float s1 = row16_sum(ok ? (v.x + v.y) + (v.z + v.w) : 0.f);
+          const float s2 = row16_sum(ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f);
+          if (ok) {
+            if ((tid & 15) == 0) p.stats[(long)row * p.stats_slots + (col >> 6)] = make_float2(s1, s2);
+            if (!p.no_c_store) {
+              if (p.out_bf16)
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + cbase + (long)row * p.ldc) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+              else
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + cbase + (long)row * p.ldc) = v;
+            }
+            if (p.aux) *reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+          }
+        } else {
+          if (ok) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + cbase + (long)row * p.ldc) = v;
+        }
+      }
+      return;
+    }
+  }
   if constexpr (EPI == EPI_PROD) DF_EPI_LOOP(5)
   else if constexpr (EPI == EPI_LNC) DF_EPI_LOOP(2)
   else if constexpr (EPI == EPI_ANY) {

@@ -29,6 +29,8 @@ buf = buf.reshape(4096, 32)
 nb = int((buf[:, 0] > 0).sum())
 print("blocks:", nb)
 for blk in (0, 1, 8, 100, nb - 1):
-    row = buf[blk]
-    n = int((row > 0).sum())
-    print(f"block {blk:3d}: " + " ".join(f"{int(d):6d}" for d in np.diff(row[:n].astype(np.int64))), " total", int(row[n - 1] - row[0]))
+    row = buf[blk].astype(np.int64)
+    n = int((row[:24] > 0).sum())
+    epi = " | epilogue_block: barrier+park %d, FiLM/residual pre-add %d, store loop %d" % (
+        int(row[25] - row[24]), int(row[26] - row[25]), int(row[n - 1] - row[26])) if row[26] > 0 else ""
+    print(f"block {blk:3d}: " + " ".join(f"{int(d):6d}" for d in np.diff(row[:n])), " total", int(row[n - 1] - row[0]), epi)
