@@ -11,7 +11,7 @@ import sys
 
 
 def family(name):
-    if "gemm_bf16" in name or "halo" in name or "splitk" in name:
+    if "gemm_bf16" in name or "halo" in name or "splitk" in name or "geglu_persistent" in name:
         return "gemm"
     if "attention" in name:
         return "attention"
@@ -37,7 +37,7 @@ def steady(rows, marker, steps):
     return rows[idx[-steps - 1]:idx[-1]], steps
 
 
-marker = sys.argv[4] if len(sys.argv) > 4 else "timestep_embedding_b16_kernel"
+marker = sys.argv[4] if len(sys.argv) > 4 else "bcast_rows_kernel"      # t.lookup: first kernel of a step (time embedding hoisted)
 out = {"note": "bytes per launch = 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes, dispatches of the last full steps only",
        "marker_kernel": marker}
 per_kernel = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])

@@ -1,6 +1,6 @@
 """Per-kernel SQ counters of the denoise step from two rocprofv3 --pmc passes (tools/sq_counters.sh).
 
-Only the dispatches of the last 4 full denoise steps are used (a step starts at timestep_embedding_b16_kernel), so tuning /
+Only the dispatches of the last 4 full denoise steps are used (a step starts at bcast_rows_kernel = t.lookup), so tuning /
 packing launches never enter.  Units (checked on this chip against kernel durations): SQ_BUSY_CYCLES is summed over the 32
 shader engines, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (32 per SE; = MFMA instructions x 32 clk for 32x32x16),
 SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT over the 256 CUs (8 per SE), SQ_WAVE_CYCLES / SQ_WAIT_* count 4-cycle quanta per wave.
@@ -18,7 +18,7 @@ import json
 import re
 import sys
 
-MARK = "timestep_embedding_b16_kernel"
+MARK = "bcast_rows_kernel"      # first kernel of a step since the time embedding is hoisted (t.lookup); was timestep_embedding_b16_kernel
 
 
 def short(name):
@@ -54,7 +54,9 @@ def main():
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(int)
     steps = None
-    for sub in ("a", "b"):
+    import os
+    subs = ("a", "b", "c") if os.path.isdir(f"{d}/c") else ("a", "b")
+    for sub in subs:
         rows, st = load(f"{d}/{sub}")
         steps = st or steps
         for name, c in rows:
@@ -81,6 +83,13 @@ def main():
             "wait_inst_lds": c.get("a:SQ_WAIT_INST_LDS", 0.0) / wc,
             "waves_per_simd": 4 * wc / (32 * busy_a),
             "waves_per_launch": c.get("a:SQ_WAVES", 0.0) / max(cnt[k], 1),
+            # issue-slot view (pass c, round 4): instructions per wavefront by class
+            **{key: c[f"c:{cn}"] / max(c.get("a:SQ_WAVES", 1.0), 1.0) for cn, key in (
+                ("SQ_INSTS_MFMA", "mfma_insts_per_wave"), ("SQ_INSTS_VALU_MFMA_MOPS_F16", "mfma_mops_f16_per_wave"),
+                ("SQ_INSTS_VMEM_RD", "vmem_rd_insts_per_wave"), ("SQ_INSTS_VMEM_WR", "vmem_wr_insts_per_wave"),
+                ("SQ_INSTS_SMEM", "smem_insts_per_wave"), ("SQ_INSTS_LDS", "lds_insts_per_wave")) if f"c:{cn}" in c},
+            **({"valu_insts_per_wave": c["b:SQ_INSTS_VALU"] / max(c.get("a:SQ_WAVES", 1.0), 1.0)} if "b:SQ_INSTS_VALU" in c else {}),
+            **({"salu_insts_per_wave": c["b:SQ_INSTS_SALU"] / max(c.get("a:SQ_WAVES", 1.0), 1.0)} if "b:SQ_INSTS_SALU" in c else {}),
         })
     if not res:
         raise SystemExit("no kernel carries SQ_BUSY_CYCLES: counters seen = %s" % sorted({k for c in agg.values() for k in c})[:20])
@@ -88,7 +97,7 @@ def main():
     tot = sum(r["busy_us_per_step"] for r in res)
     fam = collections.defaultdict(lambda: [0.0, 0.0])
     for r in res:
-        f = "gemm" if ("gemm_bf16" in r["kernel"] or "halo" in r["kernel"] or "splitk" in r["kernel"]) else (
+        f = "gemm" if ("gemm_bf16" in r["kernel"] or "halo" in r["kernel"] or "splitk" in r["kernel"] or "geglu_persistent" in r["kernel"]) else (
             "attention" if "attention" in r["kernel"] else ("groupnorm" if "groupnorm" in r["kernel"] else "other"))
         fam[f][0] += r["busy_us_per_step"]
         fam[f][1] += r["mfma_busy"] * r["busy_us_per_step"]
