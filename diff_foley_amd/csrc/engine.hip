@@ -2468,7 +2468,9 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
     if (cands.count(key)) continue;
     GemmParams g = o.gp;
     std::vector<TuneCand>& v = cands[key];
+    static const unsigned long tile_skip = getenv("DF_TILE_SKIP") ? strtoul(getenv("DF_TILE_SKIP"), nullptr, 0) : 0ul;   // tools: bit mask
     for (int t = 0; t < TILE_ALL && t < tile_cap; ++t) {
+      if ((tile_skip >> t) & 1) continue;
       // 3 * 2^k splits too: 2 M tiles x 20 N tiles x 6 = 240 blocks fill 256 CUs where 4 / 8 give 160 / 320 (tools/cold_probe.py:
       // sk 3 / 6 / 12 are the best factor of most weight-streaming layers)
       static const int sks[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};

@@ -84,20 +84,20 @@ enum GemmTile {
   // 192 output pixels (three 4x16 patches) x 64 couts, 4 wavefronts of 96x32: (8192, 320) becomes 43 x 5 = 215 blocks on 256 CUs
   // where the 256x64 tile gives 160 (the model's channel counts are 5 * 2^k: power-of-two tiles leave 3/8 of the CUs idle)
   TILE_HALO_192x64 = 17,
-  // RESERVED ids (round-4 experiment, measured and not built: experiments/deep_weight_ring_tiles.md): generic kernel with a deep
-  // weight ring (gemm_impl.h NSTB: activations double-buffered, weights requested 5-11 K steps ahead) for the M <= 512 layers
-  // whose 26-59 MB of weights arrive cold from HBM every step.  No better than the shared ring on any layer (tools/cold_probe.py).
-  TILE_256x64_W = 18, TILE_128x64_W = 19, TILE_128x128_W = 20,
+  // PRODUCER-SPECIALISED generic tiles (round 4; gemm_impl.h PS): 4 consumer wavefronts (2 x 2) run the MFMAs, 4 producer
+  // wavefronts issue the LDS-DMA requests of the ring -- 8 wavefronts, one of each role per SIMD.  (ids 18-20 were the deep
+  // weight-ring tiles of an earlier round-4 experiment: experiments/deep_weight_ring_tiles.md; never built into the product.)
+  TILE_PS_256x128 = 18, TILE_PS_128x128 = 19, TILE_PS2_128x128 = 20,      // PS2: 8 producer wavefronts (12 in the block)
   // persistent LayerNorm-folded GEGLU projection (ffn.hip): 2 resident blocks per CU walk a tile queue, one continuous operand
   // stream across tiles, epilogue out of the accumulator registers.  128 x 128 tiles (C <= 640) / 64 x 128 tiles.
   TILE_PGEGLU_128 = 21, TILE_PGEGLU_64 = 22, TILE_ALL = 23
 };
 static inline bool gemm_tile_is_pgeglu(int cfg) { return cfg == TILE_PGEGLU_128 || cfg == TILE_PGEGLU_64; }
-static inline bool gemm_tile_is_deepw(int cfg) { return cfg >= TILE_256x64_W && cfg <= TILE_128x128_W; }
+static inline bool gemm_tile_is_ps(int cfg) { return cfg >= TILE_PS_256x128 && cfg <= TILE_PS2_128x128; }
 // ring depths (activation ring, weight ring) of the generic tiles; 0 for halo tiles
 static inline void gemm_tile_rings(int cfg, int* nsta, int* nstb) {
-  static const int a[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 2, 2, 2, 2, 3};
-  static const int b[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 10, 12, 6, 2, 3};
+  static const int a[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3};
+  static const int b[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3};
   *nsta = a[cfg];
   *nstb = b[cfg];
 }
@@ -114,7 +114,7 @@ static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
   static const int d[TILE_ALL][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
                                      {128, 64},  {256, 64}, {128, 128}, {128, 256}, {256, 128},
                                      {128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
-                                     {128, 64}, {256, 64}, {192, 64}, {256, 64}, {128, 64}, {128, 128}, {128, 128}, {64, 128}};
+                                     {128, 64}, {256, 64}, {192, 64}, {256, 128}, {128, 128}, {128, 128}, {128, 128}, {64, 128}};
   *bm = d[cfg][0];
   *bn = d[cfg][1];
 }

@@ -212,7 +212,13 @@ __device__ __forceinline__ EpiVec epi_prefetch(const GemmParams& p, int n0, int 
 // (bf16) store: rows leave the CU as full 128..512-B contiguous runs instead of 4-B-per-lane column slivers.
 // ROWMAP(r) gives the output row (NHWC pixel index) of tile row r, or >= p.M when the row does not exist.
 // Requires N % 4 == 0, ldc % 4 == 0 and row-major output (the caller falls back to epilogue_band otherwise).
-template <int BM, int BN, int NT, int TM, int TN, int EPI, class RowMap>
+// What a wavefront that takes no part in epilogue_block has to execute so that the block's barriers still count it:
+// exactly epilogue_block's barriers (keep in step with it).
+__device__ __forceinline__ void epilogue_block_idle() {
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();
+}
+template <int BM, int BN, int NT, int TM, int TN, int EPI, bool PARK = true, class RowMap>
 __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int batch, float* sC,
                                                f32x16 (&acc)[TM][TN], int wrow0, int wcol0, int n0, int tid,
                                                RowMap rowmap, const EpiVec& ev, float2 ln_mr = make_float2(0.f, 1.f)) {
@@ -226,13 +232,15 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
   DF_EPI_STAMP(0)
   __builtin_amdgcn_s_barrier();            // every wave is done reading the operand ring
   if ((EPI == EPI_LNC || EPI == EPI_GEGLU || EPI == EPI_XS) && p.ln_stats && tid < BM) sRow[tid] = ln_mr;
+  if constexpr (PARK) {        // (producer wavefronts of a producer-specialised block hold no accumulators: they join at the store loops)
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        sC[(wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wcol0 + j * 32 + l31] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r)
+          sC[(wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wcol0 + j * 32 + l31] = acc[i][j][r];
+  }
   __syncthreads();
   DF_EPI_STAMP(1)
   const bool has_bias = p.bias != nullptr, has_rb = p.rowbias != nullptr, has_res = p.res != nullptr;
@@ -556,13 +564,27 @@ __device__ __forceinline__ void tile_of(int lid, int nbm, int nbn, int gm, int& 
 // tile is requested by all M tiles of the layer at once, so the UNIQUE bytes in flight are (blocks x W bytes in flight per
 // block) / (M tiles).  With one 16 KB stage per block that is ~1.5 MB chip-wide = 0.8 TB/s at ~2 us of loaded HBM latency --
 // the rate these layers were measured at.  Activations are L2 hits (just written, re-read by every N tile): two stages suffice.
-template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI, int NSTB = NST>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p) {
+//
+// PS = 1 (round 4): PRODUCER-SPECIALISED block.  The block carries a second set of WGM x WGN wavefronts that do nothing but issue
+// the LDS-DMA requests of the operand ring; the first set ("consumers") only reads fragments and runs MFMAs.  Motivation
+// (tools/halo_stamps.py, tools/pgeglu_stamps.py): an LDS-DMA request blocks the issuing wavefront for ~100 cycles and a
+// wavefront issues in order, so in the symmetric kernel a K step costs (requests per wave x ~100) + (MFMAs per wave x 32)
+// cycles -- the "17.5 B/clk per block" delivery wall every tile shape, ring depth and wave count showed.  Two co-resident
+// blocks overlap the two phases by accident of phase (30 B/clk); here the overlap is by construction: each SIMD holds one
+// consumer and one producer wavefront, the SIMD issues the producer's VMEM requests while the consumer's MFMAs run.  Both sets
+// meet at the same one s_barrier per K step; the ring protocol (slot of tile it-1 refilled during tile it) is unchanged.
+// PS = 2: two producer wavefronts per consumer (12 wavefronts): a wavefront sustains one request per ~130 cycles, 4 producers
+// deliver ~31 B/clk (tools/gemm_bench.py: 128 x 128 tile, 1030 cycles per K step against 512 of MFMA).
+// After the K loop the first WGM x WGN producers join the consumers in the epilogue's store loops (2 * NT threads); further
+// producers only keep the epilogue's barriers company.
+template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI, int NSTB = NST, int PS = 0>
+__global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void gemm_bf16_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // host pass only needs the launch stub (LDS-DMA builtins do not parse there)
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int NT = 64 * WGM * WGN;          // threads (4 or 8 wavefronts)
-  constexpr int RPP = NT / 8;                 // LDS rows filled per DMA pass of the block
+  constexpr int NT = 64 * WGM * WGN;          // threads (4 or 8 wavefronts); PS: the CONSUMER threads
+  constexpr int NTP = PS ? NT * PS : NT;      // threads that issue the DMA requests (PS: PS producer wavefronts per consumer wavefront)
+  constexpr int RPP = NTP / 8;                // LDS rows filled per DMA pass of the block
   constexpr int AP = BM / RPP, BP = BN / RPP;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the DMA pass");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -571,7 +593,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   constexpr int WD = NSTB - NST;              // extra K steps the weight requests run ahead of the activation requests
   constexpr int WSLOT = BN * BK * 2;          // bytes of one weight ring slot
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  static_assert(PS == 0 || NSTB == NST, "producer-specialised blocks use the shared ring");
+  const int raw_wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const bool producer = PS && raw_wid >= WGM * WGN;            // wave-uniform role
+  // role-local thread / wave index: the staging coordinates of a producer are those the same thread index has in the symmetric kernel
+  const int tid = producer ? (int)threadIdx.x - NT : (int)threadIdx.x, lane = tid & 63, wid = producer ? raw_wid - WGM * WGN : raw_wid;
   const int wm = wid / WGN, wn = wid % WGN;
   const int l31 = lane & 31, lh = lane >> 5;
 
@@ -598,7 +624,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   constexpr int LNS = 20;
   const bool ln_on = MODE == 0 && (EPI == EPI_LNC || EPI == EPI_GEGLU || EPI == EPI_XS) && p.ln_stats != nullptr;
   float2 lnv[LNS];
-  if (ln_on) {
+  if (ln_on && !producer) {
     const float2* sp = p.ln_stats + (long)min(m0 + min(tid, BM - 1), p.M - 1) * p.ln_slots;
 #pragma unroll
     for (int i = 0; i < LNS; ++i)
@@ -797,10 +823,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
 #pragma unroll
     for (int tw = 0; tw < WD; ++tw) DF_DMA_W(tw);
   }
-  DF_DMA(0, 0);
-  if (NST > 2) DF_DMA(1, 1);
-  if (NST > 3) DF_DMA(2, 2);
-  if (NST > 4) DF_DMA(3, 3);
+  if (!PS || producer) {
+    DF_DMA(0, 0);
+    if (NST > 2) DF_DMA(1, 1);
+    if (NST > 3) DF_DMA(2, 2);
+    if (NST > 4) DF_DMA(3, 3);
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   f32x16 acc[TM][TN];
@@ -851,7 +879,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
 #define DF_RING_SYNC(VM)                                                                          \
   {                                                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* my reads of the slot about to be refilled are done */ \
-    wait_vmcnt<(VM)>();              /* next tile landed: <= NST-2 younger tiles of this wave in flight */ \
+    if constexpr (PS == 0) wait_vmcnt<(VM)>();   /* next tile landed: <= NST-2 younger tiles of this wave in flight */ \
     __builtin_amdgcn_s_barrier();    /* all parts of it visible; everyone is done with the current slot */  \
   }
   // (A three-fragment-set form with pinned issue order was measured slower for this kernel: 221 vs 224.5 steps/s.)
@@ -859,7 +887,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
   {                                                                                             \
     bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];                                                      \
     DF_FRAG(a0, b0, 0, ST);                                                                     \
-    DF_DMA(it + NST - 1, ((ST) + NST - 1) % NST);                                               \
+    if constexpr (PS == 0) DF_DMA(it + NST - 1, ((ST) + NST - 1) % NST);                        \
     DF_FRAG(a1, b1, 1, ST);                                                                     \
     DF_MMA(a0, b0, acc);                                                                        \
     DF_FRAG(a0, b0, 2, ST);                                                                     \
@@ -874,10 +902,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
       if (w_rd == NSTB * WSLOT) w_rd = 0;                                                       \
     }                                                                                           \
   }
-  const EpiVec ev = epi_prefetch<BN, NT, EPI>(p, n0, tid);
+  // epilogue roles: in a producer-specialised block BOTH wave sets run the store loops (2 * NT threads, block-linear index);
+  // only the consumers park accumulators
+  constexpr int NTE = PS ? 2 * NT : NT;
+  const int etid = (int)threadIdx.x;
+  const EpiVec ev = epi_prefetch<BN, NTE, EPI>(p, n0, etid);
 
   float2 ln_mr = make_float2(0.f, 1.f);
-  if (ln_on) {
+  if (ln_on && !producer) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < LNS; ++i)
@@ -890,7 +922,90 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     ln_mr = make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
   }
 
+  if constexpr (PS != 0) {
+    if (producer) {
+      // the producer's K loop: request tile it + NST - 1 into the slot tile it - 1 was read from, wait until tile it + 1 has
+      // landed (<= NST - 2 younger tiles of this wave in flight), meet the consumers at the K-step barrier
+      wait_vmcnt<(NST - 2) * LPT>();
+      __builtin_amdgcn_s_barrier();
+#define DF_PITER(ST)                                                                              \
+  {                                                                                             \
+    DF_DMA(pit + NST - 1, ((ST) + NST - 1) % NST);                                              \
+    wait_vmcnt<(NST - 2) * LPT>();                                                              \
+    __builtin_amdgcn_s_barrier();                                                               \
+    ++pit;                                                                                      \
+  }
+      int pit = 0;
+      while (pit < nt) {
+        DF_PITER(0);
+        if (pit >= nt) break;
+        DF_PITER(1);
+        if (NST > 2) {
+          if (pit >= nt) break;
+          DF_PITER(2 % NST);
+        }
+        if (NST > 3) {
+          if (pit >= nt) break;
+          DF_PITER(3 % NST);
+        }
+        if (NST > 4) {
+          if (pit >= nt) break;
+          DF_PITER(4 % NST);
+        }
+      }
+#undef DF_PITER
+      wait_vmcnt<0>();       // the dead-slot requests of the last iterations land before the epilogue's first barrier
+      if (p.dbg & 2) return;
+      if (PS > 1 && wid >= WGM * WGN) {        // surplus producers: the two barriers of epilogue_block, nothing else
+        epilogue_block_idle();
+        return;
+      }
+      if constexpr (MODE != 3) {     // the store loops of the block epilogue (no accumulators to park)
+        f32x16 none[TM][TN];
+        bool vec_ok = true;
+        if constexpr (EPI == EPI_ANY)
+          vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.ld_rowbias & 3) == 0 &&
+                   (p.res_bs & 3) == 0 && (p.c_bs & 3) == 0 && (p.ld_aux & 3) == 0;
+        if (vec_ok)
+          epilogue_block<BM, BN, NTE, TM, TN, EPI, false>(p, z, batch, reinterpret_cast<float*>(smem), none, 0, 0, n0, etid,
+                                                          [&](int r) { return m0 + r; }, ev);
+      }
+      return;
+    }
+  }
   int it = 0;
+  if constexpr (PS != 0) {
+    // consumer K loop of a producer-specialised block: ONE loop body with a running ring-slot offset (the NST-times unrolled form
+    // with its mid-body exits made the register allocator rotate the accumulator set between the unrolled bodies: copies and
+    // spills inside the MFMA stream).  VALU is idle in this role, the v_add per fragment address is free.
+    int sa = 0, sb = 0;                     // byte offsets of the current slot in the A / W rings
+#define DF_FRAGD(DSTA, DSTB, S)                                                                   \
+  {                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) DSTA[i] = *reinterpret_cast<const bf16x8*>(fA[i][S] + sa); \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) DSTB[j] = *reinterpret_cast<const bf16x8*>(fB[j][S] + sb); \
+  }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();           // tile 0 landed (the producers waited for it) and visible
+#pragma unroll 1
+    for (; it < nt; ++it) {
+      bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+      DF_FRAGD(a0, b0, 0);
+      DF_FRAGD(a1, b1, 1);
+      DF_MMA(a0, b0, acc);
+      DF_FRAGD(a0, b0, 2);
+      DF_MMA(a1, b1, acc);
+      DF_FRAGD(a1, b1, 3);
+      DF_MMA(a0, b0, acc);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of this slot are done: it may be refilled
+      __builtin_amdgcn_s_barrier();
+      DF_MMA(a1, b1, acc);
+      sa += BM * BK * 2;
+      if (sa == NST * BM * BK * 2) sa = 0;
+      sb += BN * BK * 2;
+      if (sb == NST * BN * BK * 2) sb = 0;
+    }
+#undef DF_FRAGD
+  } else {
   DF_RING_SYNC((NST - 2) * LPT + (WD > 0 ? BP : 0));       // tile 0 landed and visible
   while (it < nt) {
     DF_ITER(0);
@@ -909,7 +1024,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
       DF_ITER(4 % NST);
     }
   }
-  wait_vmcnt<0>();                     // dead-slot requests of the last iterations must land before LDS is released
+  }
+  if constexpr (PS == 0) wait_vmcnt<0>();   // dead-slot requests of the last iterations must land before LDS is released
 
   // ---- epilogue
   if (p.dbg & 2) {   // tools: keep the accumulators alive, store nothing
@@ -924,7 +1040,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     // OUTPUT tensor: M = 4 * rows.  Row table behind the epilogue tile (launch_cfg reserves BM ints).
     int* srow = reinterpret_cast<int*>(smem + (size_t)BM * (BN + 4) * 4 + (size_t)BM * 8);
     __builtin_amdgcn_s_barrier();
-    for (int rr = tid; rr < BM; rr += NT) {
+    for (int rr = etid; rr < BM; rr += NTE) {
       const int m = m0 + rr, hw = p.OH * p.OW;
       const int nb = m / hw, rem = m - nb * hw, oy = rem / p.OW, ox = rem - oy * p.OW;
       srow[rr] = (m < p.M) ? ((nb * 2 * p.OH + 2 * oy + (phase >> 1)) * 2 * p.OW + 2 * ox + (phase & 1)) : 4 * p.M;
@@ -934,12 +1050,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
     pe.M = 4 * p.M;
     auto rowmap = [&](int rr) { return srow[rr]; };
     if constexpr (EPI != EPI_ANY) {
-      epilogue_block<BM, BN, NT, TM, TN, EPI>(pe, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap, ev);
+      epilogue_block<BM, BN, NTE, TM, TN, EPI>(pe, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, etid, rowmap, ev);
     } else {
       const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.ld_rowbias & 3) == 0 &&
                           (p.ld_aux & 3) == 0;
       if (vec_ok) {
-        epilogue_block<BM, BN, NT, TM, TN, EPI>(pe, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap, ev);
+        epilogue_block<BM, BN, NTE, TM, TN, EPI>(pe, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, etid, rowmap, ev);
       } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -951,14 +1067,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmParams p)
       }
     }
   } else if constexpr (EPI != EPI_ANY) {     // the host routes only vectorisable, row-major problems to the specialised kernels
-    epilogue_block<BM, BN, NT, TM, TN, EPI>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid,
+    epilogue_block<BM, BN, NTE, TM, TN, EPI>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, etid,
                                              [&](int r) { return m0 + r; }, ev, ln_mr);
   } else {
     const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
                         (p.ld_rowbias & 3) == 0 && (p.res_bs & 3) == 0 && (p.c_bs & 3) == 0 && (p.ld_aux & 3) == 0;
     if (vec_ok) {
-      epilogue_block<BM, BN, NT, TM, TN, EPI>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0,
-                                               tid, [&](int r) { return m0 + r; }, ev, ln_mr);
+      epilogue_block<BM, BN, NTE, TM, TN, EPI>(p, z, batch, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0,
+                                               etid, [&](int r) { return m0 + r; }, ev, ln_mr);
       return;
     }
 #pragma unroll
@@ -1294,7 +1410,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
 #endif
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI, int NSTB = NST>
+template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI, int NSTB = NST, int PS = 0>
 hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   constexpr size_t ring = ((size_t)BM * NST + (size_t)BN * NSTB) * BK * 2;     // operand rings (A: NST slots, W: NSTB slots)
@@ -1306,12 +1422,13 @@ hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     const size_t cap = std::min<size_t>(160 * 1024, base + (size_t)5 * 64 * WGM * WGN * 8);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE, EPI, NSTB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE, EPI, NSTB, PS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE, EPI, NSTB>), dim3(nbm * nbn, 1, MODE == 3 ? 4 * zdim : zdim), dim3(64 * WGM * WGN), lds, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WGM, WGN, NST, MODE, EPI, NSTB, PS>), dim3(nbm * nbn, 1, MODE == 3 ? 4 * zdim : zdim),
+                     dim3(64 * WGM * WGN * (1 + PS)), lds, stream, p);
   return hipGetLastError();
 }
 

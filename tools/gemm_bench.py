@@ -13,7 +13,7 @@ from diff_foley_amd import engine as E
 
 TILES = {0: "128x128", 1: "128x64", 2: "64x128", 3: "64x64", 4: "32x128", 5: "H128x64", 6: "H256x64", 7: "H128x128", 8: "128x256", 9: "256x128",
          10: "128x128s", 11: "128x64s", 12: "64x128s", 13: "64x64s", 14: "32x128s", 15: "H128x64d", 16: "H256x64d", 17: "H192x64",
-         18: "256x64w", 19: "128x64w", 20: "128x128w"}
+         18: "P256x128", 19: "P128x128", 20: "P2_128x128"}
 # (name, kind, NB, H, W, Cin, Cout) for conv ; (name, 'lin', M, N, K)
 SHAPES = [
     ("conv 320->320 @16x64", "conv", 8, 16, 64, 320, 320),
