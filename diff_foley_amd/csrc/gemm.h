@@ -90,14 +90,17 @@ enum GemmTile {
   TILE_PS_256x128 = 18, TILE_PS_128x128 = 19, TILE_PS2_128x128 = 20,      // PS2: 8 producer wavefronts (12 in the block)
   // persistent LayerNorm-folded GEGLU projection (ffn.hip): 2 resident blocks per CU walk a tile queue, one continuous operand
   // stream across tiles, epilogue out of the accumulator registers.  128 x 128 tiles (C <= 640) / 64 x 128 tiles.
-  TILE_PGEGLU_128 = 21, TILE_PGEGLU_64 = 22, TILE_ALL = 23
+  TILE_PGEGLU_128 = 21, TILE_PGEGLU_64 = 22,
+  // producer-specialised halo conv tiles: 4 consumer + 4 producer wavefronts.  (8 producers -- 12 wavefronts, 168 VGPRs each --
+  // spill in the tap loop: 32 us against 21.8 us on the 320 -> 320 conv at 16 x 64; measured and not kept.)
+  TILE_HALO_PS_192x64 = 23, TILE_HALO_PS_128x64 = 24, TILE_HALO_PS_128x128 = 25, TILE_ALL = 26
 };
 static inline bool gemm_tile_is_pgeglu(int cfg) { return cfg == TILE_PGEGLU_128 || cfg == TILE_PGEGLU_64; }
 static inline bool gemm_tile_is_ps(int cfg) { return cfg >= TILE_PS_256x128 && cfg <= TILE_PS2_128x128; }
 // ring depths (activation ring, weight ring) of the generic tiles; 0 for halo tiles
 static inline void gemm_tile_rings(int cfg, int* nsta, int* nstb) {
-  static const int a[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3};
-  static const int b[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3};
+  static const int a[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3, 0, 0, 0};
+  static const int b[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3, 0, 0, 0};
   *nsta = a[cfg];
   *nstb = b[cfg];
 }
@@ -106,7 +109,11 @@ static inline int gemm_ln_max_slots() { return 20; }
 
 static inline bool gemm_tile_is_halo(int cfg) {
   return (cfg >= TILE_HALO_128x64 && cfg <= TILE_HALO_128x128) || cfg == TILE_HALO_128x64_D || cfg == TILE_HALO_256x64_D ||
-         cfg == TILE_HALO_192x64;
+         cfg == TILE_HALO_192x64 || (cfg >= TILE_HALO_PS_192x64 && cfg <= TILE_HALO_PS_128x128);
+}
+// threads of a halo tile that issue its DMA requests (the LDS staging geometry follows from them: 8 threads per 128-B row)
+static inline int gemm_halo_dma_threads(int cfg) {
+  return (cfg == TILE_HALO_256x64 || cfg == TILE_HALO_256x64_D) ? 512 : 256;
 }
 static inline int gemm_halo_ring(int cfg) { return (cfg == TILE_HALO_128x64_D || cfg == TILE_HALO_256x64_D) ? 8 : 4; }
 
@@ -114,7 +121,8 @@ static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
   static const int d[TILE_ALL][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
                                      {128, 64},  {256, 64}, {128, 128}, {128, 256}, {256, 128},
                                      {128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
-                                     {128, 64}, {256, 64}, {192, 64}, {256, 128}, {128, 128}, {128, 128}, {128, 128}, {64, 128}};
+                                     {128, 64}, {256, 64}, {192, 64}, {256, 128}, {128, 128}, {128, 128}, {128, 128}, {64, 128},
+                                     {192, 64}, {128, 64}, {128, 128}};
   *bm = d[cfg][0];
   *bn = d[cfg][1];
 }

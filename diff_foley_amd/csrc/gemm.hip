@@ -132,7 +132,7 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int nk = p.K / 64;
   if (p.taps == 4) {     // phase-decomposed upsample conv (MODE 3): a subset of the generic tiles, plain epilogues only
     static const bool ok3[TILE_ALL] = {false, false, false, true, false, false, false, false, true, true, true, true, true, true, false, false, false, false,
-                                       false, false, false, false, false};     // (no producer-specialised MODE 3 instantiation)
+                                       false, false, false, false, false, false, false, false};     // (no producer-specialised MODE 3 instantiation)
     if (tile < 0 || tile >= TILE_ALL || !ok3[tile] || batch > 1) return false;
     if (p.geglu || p.vt || p.ln_stats || p.stats || p.w_rows > 0 || p.sm_w > 0 || p.Cin2 > 0 || p.res || p.store_nchw) return false;
     if (splitk > 1 && (p.N & 3) != 0) return false;
@@ -170,12 +170,13 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   int bm, bn, th, tw;
   gemm_tile_dims(tile, &bm, &bn);
   if (!halo_patch(p.H, p.Wd, bm, &th, &tw)) return false;
-  const int threads = (tile == TILE_HALO_256x64 || tile == TILE_HALO_256x64_D) ? 512 : 256, rpp = threads / 8;
+  const int threads = gemm_halo_dma_threads(tile), rpp = threads / 8;
   const int hr = (bm / (th * tw)) * (th + 2) * (tw + 2);
   const int apass = (hr + rpp - 1) / rpp, wpass = (bn + rpp - 1) / rpp;
   if (apass > 12) return false;
   const int nstw = gemm_halo_ring(tile);   // weight ring depth (4; 8 for the weight-streaming variants)
-  if (((size_t)2 * apass * rpp + (size_t)nstw * wpass * rpp) * 128 + (size_t)bm * 4 > 160 * 1024) return false;
+  if (((size_t)2 * apass * rpp + (size_t)nstw * wpass * rpp) * 128 + (size_t)std::max(bm, hr) * 4 > 160 * 1024) return false;
+  if ((p.lda & 7) != 0) return false;           // the halo-row table keeps a 3-bit key in the low bits of a pixel's byte offset
   const int nchunk = p.Cin / 64;
   return splitk == 1 || nchunk / splitk >= 1;
 }

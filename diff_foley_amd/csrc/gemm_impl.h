@@ -1147,11 +1147,14 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 // ahead; the 9 taps are unrolled so every wait is a compile-time `vmcnt` (loads retire in issue order):
 //   wait for W(c,t):  younger = W(+1) .. W(+NSTW-2) and, for t in 1..NSTW-1, the A(c+1) request issued at tap 0.
 // Zero padding and ragged edges come from out-of-bounds buffer offsets (hardware writes zeros to LDS).
-template <int BM, int BN, int WGM, int WGN, int NSTW, int EPI>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams p) {
+// PS > 0: producer-specialised block (see gemm_bf16_kernel): PS producer wavefronts per consumer wavefront issue every halo and
+// weight request in the symmetric kernel's order (so the counted waits are the same); consumers read fragments and run MFMAs.
+template <int BM, int BN, int WGM, int WGN, int NSTW, int EPI, int PS = 0>
+__global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NT = 64 * WGM * WGN;          // threads
-  constexpr int RPP = NT / 8;                 // LDS rows written per DMA pass of the whole block
+  constexpr int NT = 64 * WGM * WGN;          // threads (PS: the consumer threads)
+  constexpr int NTP = PS ? NT * PS : NT;      // threads that issue the DMA requests
+  constexpr int RPP = NTP / 8;                // LDS rows written per DMA pass of the whole block
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int WPASS = (BN + RPP - 1) / RPP; // weight passes per tap
@@ -1160,14 +1163,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int raw_wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const bool producer = PS && raw_wid >= WGM * WGN;            // wave-uniform role; tid / wid are role-local
+  const int tid = producer ? (int)threadIdx.x - NT : (int)threadIdx.x, lane = tid & 63, wid = producer ? raw_wid - WGM * WGN : raw_wid;
   const int wm = wid / WGN, wn = wid % WGN;
   const int l31 = lane & 31, lh = lane >> 5;
+  constexpr int NTE = PS ? 2 * NT : NT;       // threads of the epilogue's store loops (consumers + the first WGM x WGN producers)
+  const int etid = (int)threadIdx.x;
 
   // tools (p.dbg bit 6, split-K 1): thread 0 stamps the shader clock at phase boundaries into p.partial[block][32] (uint64)
   int n_stamp = 0;
   auto stamp = [&]() {
-    if ((p.dbg & 64) && tid == 0 && n_stamp < 32)
+    if ((p.dbg & 64) && etid == 0 && n_stamp < 32)
       reinterpret_cast<unsigned long long*>(p.partial)[(long)blockIdx.x * 32 + n_stamp++] = __builtin_amdgcn_s_memtime();
   };
   stamp();
@@ -1218,23 +1225,35 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
   // all quotients below are of values < 2^22 (launch_halo checks the patch count): FastDiv instead of 32-bit division
   const FastDiv fd_hwp(HWp), fd_tw2(TW + 2), fd_pimg(npy * npx), fd_npx(npx), fd_ppx(PPX), fd_tw(TW);
   constexpr int MAXAP = 12;
+  // Halo row -> source pixel, ONE decomposition per halo row of the block (round 4): every thread of the block (both roles)
+  // resolves the rows hr = thread, thread + block, ... into a table entry (byte offset of the pixel's channel 0 | 3-bit swizzle
+  // key, or ~0 outside the image) in LDS behind the ring; the requesting threads then pick up their <= 12 rows with one ds_read
+  // and 4 VALU instructions each.  (Before: 12 x (3 FastDiv chains + bounds) = ~540 VALU instructions per thread in front of the
+  // first request -- tools/halo_stamps.py: 5.4 k cycles from kernel start to the end of the offset arithmetic.)
+  unsigned* atab = reinterpret_cast<unsigned*>(smem + p.halo_ring_bytes);
+  for (int hr = (int)threadIdx.x; hr < HR; hr += NT * (1 + PS)) {
+    const int pi = fd_hwp.div(hr), rem = hr - pi * HWp;
+    const int hy = fd_tw2.div(rem), hx = rem - hy * (TW + 2);
+    const int g = mt * PB + pi;                  // global patch id
+    unsigned e = 0xffffffffu;
+    if (g < npatch) {
+      const int n = fd_pimg.div(g), gr = g - n * (npy * npx);
+      const int gy = fd_npx.div(gr), gx = gr - gy * npx;
+      const int y = gy * TH + hy - 1, x = gx * TW + hx - 1;
+      if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd)
+        e = (unsigned)((((long)(n * p.H + y) * p.Wd + x) * p.lda) * 2) | (unsigned)(((hx >> 1) + SC * (pi * (TH + 2) + hy)) & 7);
+    }
+    atab[hr] = e;
+  }
+  __syncthreads();
   unsigned a_off[MAXAP];
 #pragma unroll
   for (int i = 0; i < MAXAP; ++i) {
     const int hr = r0 + RPP * i;                 // halo row
     unsigned off = OOB;
-    if (i < APASS && hr < HR) {
-      const int pi = fd_hwp.div(hr), rem = hr - pi * HWp;
-      const int hy = fd_tw2.div(rem), hx = rem - hy * (TW + 2);
-      const int g = mt * PB + pi;                // global patch id
-      const int ca = ((tid & 7) ^ (((hx >> 1) + SC * (pi * (TH + 2) + hy)) & 7)) * 8;
-      if (g < npatch) {
-        const int n = fd_pimg.div(g), gr = g - n * (npy * npx);
-        const int gy = fd_npx.div(gr), gx = gr - gy * npx;
-        const int y = gy * TH + hy - 1, x = gx * TW + hx - 1;
-        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.Wd)
-          off = (unsigned)((((long)(n * p.H + y) * p.Wd + x) * p.lda + ca) * 2);
-      }
+    if (i < APASS && hr < HR && (!PS || producer)) {
+      const unsigned e = atab[hr];
+      if (e != 0xffffffffu) off = (e & ~7u) + ((((unsigned)tid & 7u) ^ (e & 7u)) << 4);     // lda % 8 == 0: the low 4 bits of a pixel offset are free
     }
     a_off[i] = off;
   }
@@ -1271,9 +1290,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
 
   // ---- prologue: A(0), W(0 .. NSTW-2) -- requested as soon as the offsets exist; fragment coordinates, accumulator init and
   // the epilogue prefetch below run while these are in flight
-  DF_HALO_A(c0, 0);
+  if (!PS || producer) {
+    DF_HALO_A(c0, 0);
 #pragma unroll
-  for (int t = 0; t < NSTW - 1; ++t) DF_HALO_W(t, t);
+    for (int t = 0; t < NSTW - 1; ++t) DF_HALO_W(t, t);
+  }
   __builtin_amdgcn_sched_barrier(0);
   stamp();
 
@@ -1296,7 +1317,58 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
     sb[j] = (row >> 1) & 7;
   }
 
-  const EpiVec ev = epi_prefetch<BN, NT, EPI>(p, n0, tid);
+  const EpiVec ev = epi_prefetch<BN, NTE, EPI>(p, n0, etid);
+  // tile row -> NHWC pixel index of its output pixel (epilogue).  Five integer divisions per row: computed once per row into
+  // a BM-entry LDS table behind the operand ring instead of once per 4-column chunk of the epilogue loop.
+  auto rowmap_calc = [&](int rr) {
+    const int pi = fd_ppx.div(rr), rem = rr - pi * PPX;
+    const int y = fd_tw.div(rem), x = rem - y * TW;
+    const int g = mt * PB + pi;
+    const int n = fd_pimg.div(g), gr = g - n * (npy * npx);
+    const int gy = fd_npx.div(gr), gx = gr - gy * npx;
+    return (g < npatch) ? (n * p.H + gy * TH + y) * p.Wd + gx * TW + x : p.M;
+  };
+  int* srow = reinterpret_cast<int*>(smem + p.halo_ring_bytes);
+  auto rowmap = [&](int rr) { return srow[rr]; };
+
+  if constexpr (PS != 0) {
+    if (producer) {
+      // producer K loop: per tap, the weight request NSTW - 1 taps ahead (+ at tap 0 the next slice's halo), the counted wait for
+      // the next tap's operands -- DF_HALO_SYNC's rule, the issue order is the symmetric kernel's -- and the tap barrier
+      wait_vmcnt<(NSTW - 2) * WPASS>();
+      __builtin_amdgcn_s_barrier();
+#define DF_PTAP(T)                                                                                \
+  {                                                                                             \
+    const int it_ = cs * 9 + (T);                                                               \
+    DF_HALO_W(it_ + NSTW - 1, (it_ + NSTW - 1) % NSTW);                                         \
+    if ((T) == 0) DF_HALO_A(c0 + cs + 1, (cs + 1) & 1);                                         \
+    if (((T) + 1) % 9 >= 1 && ((T) + 1) % 9 <= NSTW - 1) wait_vmcnt_dyn((NSTW - 2) * WPASS + APASS); \
+    else wait_vmcnt<(NSTW - 2) * WPASS>();                                                      \
+    __builtin_amdgcn_s_barrier();                                                               \
+  }
+      for (int cs = 0; cs < nc; ++cs) {
+        DF_PTAP(0) DF_PTAP(1) DF_PTAP(2) DF_PTAP(3) DF_PTAP(4) DF_PTAP(5) DF_PTAP(6) DF_PTAP(7) DF_PTAP(8)
+      }
+#undef DF_PTAP
+      wait_vmcnt<0>();
+      if (PS > 1 && wid >= WGM * WGN) {      // surplus producers: the row-table barrier and epilogue_block's two, nothing else
+        __builtin_amdgcn_s_barrier();
+        epilogue_block_idle();
+        return;
+      }
+      for (int rr = etid; rr < BM; rr += NTE) srow[rr] = rowmap_calc(rr);
+      __syncthreads();
+      bool vec_ok = true;
+      if constexpr (EPI == EPI_ANY)
+        vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.ld_rowbias & 3) == 0 && (p.ld_aux & 3) == 0;
+      if (vec_ok) {
+        f32x16 none[TM][TN];
+        epilogue_block<BM, BN, NTE, TM, TN, EPI, false>(p, z, 0, reinterpret_cast<float*>(smem), none, 0, 0, n0, etid, rowmap, ev);
+      }
+      return;
+    }
+  }
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -1311,8 +1383,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
 #define DF_HALO_SYNC(T)                                                                           \
   {                                                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          \
-    if ((T) >= 1 && (T) <= NSTW - 1) wait_vmcnt_dyn((NSTW - 2) * WPASS + APASS);               \
-    else wait_vmcnt<(NSTW - 2) * WPASS>();                                                      \
+    if constexpr (PS == 0) {                                                                    \
+      if ((T) >= 1 && (T) <= NSTW - 1) wait_vmcnt_dyn((NSTW - 2) * WPASS + APASS);             \
+      else wait_vmcnt<(NSTW - 2) * WPASS>();                                                    \
+    }                                                                                           \
     __builtin_amdgcn_s_barrier();                                                               \
   }
 #define DF_HALO_READ(DA, DB, S)                                                                   \
@@ -1348,8 +1422,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
     DF_HALO_MMA(af0, bf0);                                                                      \
     DF_HALO_READ(af0, bf0, 3);                                                                  \
     __builtin_amdgcn_sched_barrier(0);   /* the last reads are ISSUED here: two MFMA groups of cover before the wait */ \
-    DF_HALO_W(it_ + NSTW - 1, (it_ + NSTW - 1) % NSTW);   /* refill requests interleave with the MFMA-only stretch */ \
-    if ((T) == 0) DF_HALO_A(c0 + cs + 1, (cs + 1) & 1);                                         \
+    if constexpr (PS == 0) {                                                                    \
+      DF_HALO_W(it_ + NSTW - 1, (it_ + NSTW - 1) % NSTW);   /* refill requests interleave with the MFMA-only stretch */ \
+      if ((T) == 0) DF_HALO_A(c0 + cs + 1, (cs + 1) & 1);                                       \
+    }                                                                                           \
     DF_HALO_MMA(af1, bf1);                                                                      \
     DF_HALO_MMA(af2, bf2);                                                                      \
     __builtin_amdgcn_sched_barrier(0);   /* ... and those MFMA groups stay in front of it */           \
@@ -1372,31 +1448,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv3x3_halo_kernel(GemmParams
     DF_TAP(8)
     stamp();
   }
-  wait_vmcnt<0>();
+  if constexpr (PS == 0) wait_vmcnt<0>();
   stamp();
 
-  // ---- epilogue: tile row -> NHWC pixel index of its output pixel.  Five integer divisions per row: computed once per
-  // row into a BM-entry LDS table behind the operand ring instead of once per 4-column chunk of the epilogue loop.
-  auto rowmap_calc = [&](int rr) {
-    const int pi = fd_ppx.div(rr), rem = rr - pi * PPX;
-    const int y = fd_tw.div(rem), x = rem - y * TW;
-    const int g = mt * PB + pi;
-    const int n = fd_pimg.div(g), gr = g - n * (npy * npx);
-    const int gy = fd_npx.div(gr), gx = gr - gy * npx;
-    return (g < npatch) ? (n * p.H + gy * TH + y) * p.Wd + gx * TW + x : p.M;
-  };
-  int* srow = reinterpret_cast<int*>(smem + p.halo_ring_bytes);
-  for (int rr = tid; rr < BM; rr += NT) srow[rr] = rowmap_calc(rr);
+  // ---- epilogue (row table: see rowmap_calc above)
+  for (int rr = etid; rr < BM; rr += NTE) srow[rr] = rowmap_calc(rr);
   __syncthreads();
-  auto rowmap = [&](int rr) { return srow[rr]; };
   if constexpr (EPI != EPI_ANY) {
-    epilogue_block<BM, BN, NT, TM, TN, EPI>(p, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap, ev);
+    epilogue_block<BM, BN, NTE, TM, TN, EPI>(p, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, etid, rowmap, ev);
     stamp();
   } else {
     const bool vec_ok = !p.store_nchw && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 &&
                         (p.ld_rowbias & 3) == 0 && (p.ld_aux & 3) == 0;
     if (vec_ok) {
-      epilogue_block<BM, BN, NT, TM, TN, EPI>(p, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, tid, rowmap, ev);
+      epilogue_block<BM, BN, NTE, TM, TN, EPI>(p, z, 0, reinterpret_cast<float*>(smem), acc, wm * WTM, wn * WTN, n0, etid, rowmap, ev);
       return;
     }
 #pragma unroll
@@ -1433,9 +1498,9 @@ hipError_t launch_cfg(const GemmParams& p, int zdim, hipStream_t stream) {
 }
 
 
-template <int BM, int BN, int WGM, int WGN, int NSTW, int EPI>
+template <int BM, int BN, int WGM, int WGN, int NSTW, int EPI, int PS = 0>
 hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
-  constexpr int NT = 64 * WGM * WGN, RPP = NT / 8;
+  constexpr int NT = 64 * WGM * WGN * (1 + PS), RPP = (PS ? 64 * WGM * WGN * PS : NT) / 8;
   GemmParams p = pin;
   if (!halo_patch(p.H, p.Wd, BM, &p.th, &p.tw)) return hipErrorInvalidValue;
   const int ppx = p.th * p.tw;
@@ -1446,12 +1511,12 @@ hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
   if (APASS > 12) return hipErrorInvalidValue;
   constexpr int WPASS = (BN + RPP - 1) / RPP;
   const size_t ring = ((size_t)2 * APASS * RPP + (size_t)NSTW * WPASS * RPP) * BK * 2;
-  const size_t lds = ring + (size_t)BM * 4;          // + the epilogue's row table
+  const size_t lds = ring + (size_t)std::max(BM, HR) * 4;          // + the prologue's halo-row table / the epilogue's row table
   p.halo_ring_bytes = (int)ring;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t attr = 0;
   if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WGM, WGN, NSTW, EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WGM, WGN, NSTW, EPI, PS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr = lds;
@@ -1459,7 +1524,7 @@ hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
   const int npatch = p.M / ppx;
   const int nbm = (npatch + PB - 1) / PB, nbn = (p.N + BN - 1) / BN;
   if ((long)nbm * PB >= (1 << 22)) return hipErrorInvalidValue;      // FastDiv range of the patch decomposition
-  hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WGM, WGN, NSTW, EPI>), dim3(nbm * nbn, 1, zdim), dim3(NT), lds, stream, p);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WGM, WGN, NSTW, EPI, PS>), dim3(nbm * nbn, 1, zdim), dim3(NT), lds, stream, p);
   return hipGetLastError();
 }
 

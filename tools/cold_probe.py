@@ -17,7 +17,7 @@ L = E.lib()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 only = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(TILES)
-HALO = (5, 6, 7, 15, 16, 17)
+HALO = (5, 6, 7, 15, 16, 17, 23, 24, 25)
 SHAPES = [("conv", 8, 2, 8, 1280, 1280), ("conv", 8, 2, 8, 2560, 1280), ("conv", 8, 4, 16, 1280, 1280), ("conv", 8, 4, 16, 2560, 1280),
           ("conv", 8, 8, 32, 640, 640), ("conv", 8, 16, 64, 320, 320),
           ("lin", 512, 10240, 1280), ("lin", 512, 1280, 6400), ("lin", 512, 3840, 1280), ("lin", 128, 10240, 1280),

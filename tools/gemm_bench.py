@@ -13,7 +13,8 @@ from diff_foley_amd import engine as E
 
 TILES = {0: "128x128", 1: "128x64", 2: "64x128", 3: "64x64", 4: "32x128", 5: "H128x64", 6: "H256x64", 7: "H128x128", 8: "128x256", 9: "256x128",
          10: "128x128s", 11: "128x64s", 12: "64x128s", 13: "64x64s", 14: "32x128s", 15: "H128x64d", 16: "H256x64d", 17: "H192x64",
-         18: "P256x128", 19: "P128x128", 20: "P2_128x128"}
+         18: "P256x128", 19: "P128x128", 20: "P2_128x128", 23: "HP192x64", 24: "HP128x64", 25: "HP128x128"}
+HALO = (5, 6, 7, 15, 16, 17, 23, 24, 25)
 # (name, kind, NB, H, W, Cin, Cout) for conv ; (name, 'lin', M, N, K)
 SHAPES = [
     ("conv 320->320 @16x64", "conv", 8, 16, 64, 320, 320),
@@ -74,10 +75,10 @@ def main():
             call = lambda t, sk: L.df_test_gemm(ptr(a), ptr(w), ptr(c), M, N, K, t, sk, st)
         res = []
         for t in TILES:
-            if t in (5, 6, 7, 15, 16, 17) and sh[1] != "conv":
+            if t in HALO and sh[1] != "conv":
                 continue
             for sk in (1, 2, 3, 4, 6, 8, 12, 16, 32):
-                if sk > 1 and (nk // sk < 4 or (t in (5, 6, 7, 15, 16, 17) and sh[5] // 64 // sk < 1)):
+                if sk > 1 and (nk // sk < 4 or (t in HALO and sh[5] // 64 // sk < 1)):
                     break
                 if call(t, sk) != 0:
                     continue
