@@ -235,9 +235,13 @@ def test_score_corrector_callback(P, tiny):
                                          corrector_kwargs=dict(gain=1.5), **kw)
     assert all(g == 1.5 for _, _, g in calls)
     from oracle import samplers as osamp, schedule as osch
-    eps = lambda x, t, cc: (tiny.model.diffusion_model(x.cuda(), t.cuda().float(), context=cc.cuda()).cpu())
-    zo, _ = osamp.ddim_sample(lambda x, t, cc: 0.75 * eps(x, t, cc), osch.ddpm_schedule()["alphas_cumprod"], 6, xT, c.cpu(), 4.5, uc.cpu())
-    assert rel_l2(z2.cpu(), zo) < 2e-3
+    # the oracle's loop driven by the product's own GUIDED eps * k, taken from the plan the sampler itself runs (the 2B-row CFG
+    # plan: the tiny random-weight bf16 model turns ANY rounding-level difference between two plans -- another tile, another
+    # split -- into ~1e-2 after 6 steps, tools/sens_probe.py; what is checked here is the callback, not plan-to-plan agreement)
+    tiny.engine.set_context(torch.cat([uc, c]))
+    eps = lambda x, t, cc: tiny.engine.unet_forward_cfg(x.cuda(), t.cuda().float(), 4.5).cpu()
+    zo, _ = osamp.ddim_sample(lambda x, t, cc: 0.75 * eps(x, t, cc), osch.ddpm_schedule()["alphas_cumprod"], 6, xT, c.cpu())
+    assert rel_l2(z2.cpu(), zo) < 5e-3        # (a wrong factor -- 0.5 or 1.0 for 0.75 -- is an O(1) difference)
 
     # a corrector that calls the model: apply_model and the module facades put THEIR context into the engine (B rows, another
     # conditioning); the next step's CFG forward needs the sampler's 2B-row context back
