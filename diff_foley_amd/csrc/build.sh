@@ -8,7 +8,7 @@ cd "$(dirname "$0")"
 # removes the v_accvgpr_read/write copies around every accumulator touched by VALU code (attention rescale, epilogues):
 # measured +5 % end to end, no spills in any kernel.
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -mllvm -amdgpu-mfma-vgpr-form"
-SRCS="gemm gemm_m0a gemm_m0b gemm_m1 gemm_m2 gemm_m3 gemm_halo gemm_ps ffn elementwise attention backward cavp vocoder diag engine"
+SRCS="gemm gemm_m0a gemm_m0b gemm_m1 gemm_m2 gemm_m3 gemm_halo gemm_ps gemm_ps2 ffn elementwise attention backward cavp vocoder diag engine"
 mkdir -p build/bf16 build/f16
 pids=()
 for v in bf16 f16; do

@@ -22,6 +22,7 @@ hipError_t launch_gemm_m2(int tile_cfg, int epi, const GemmParams& p, int zdim, 
 hipError_t launch_gemm_halo(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 hipError_t launch_gemm_m3(int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 hipError_t launch_gemm_ps(int mode, int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
+hipError_t launch_gemm_ps_small(int mode, int tile_cfg, int epi, const GemmParams& p, int zdim, hipStream_t stream);
 hipError_t launch_gemm_pgeglu(int tile_cfg, const GemmParams& p, hipStream_t stream);
 bool pgeglu_valid(const GemmParams& p, int tile, int batch, int splitk);
 
@@ -132,7 +133,7 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int nk = p.K / 64;
   if (p.taps == 4) {     // phase-decomposed upsample conv (MODE 3): a subset of the generic tiles, plain epilogues only
     static const bool ok3[TILE_ALL] = {false, false, false, true, false, false, false, false, true, true, true, true, true, true, false, false, false, false,
-                                       false, false, false, false, false, false, false, false};     // (no producer-specialised MODE 3 instantiation)
+                                       false, false, false, false, false, false, false, false, false, false, false, false};     // (no producer-specialised MODE 3 instantiation)
     if (tile < 0 || tile >= TILE_ALL || !ok3[tile] || batch > 1) return false;
     if (p.geglu || p.vt || p.ln_stats || p.stats || p.w_rows > 0 || p.sm_w > 0 || p.Cin2 > 0 || p.res || p.store_nchw) return false;
     if (splitk > 1 && (p.N & 3) != 0) return false;
@@ -216,7 +217,7 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
       return hipErrorInvalidValue;
     e = launch_gemm_m3(tile_cfg, epi, p, zdim, stream);
   } else if (gemm_tile_is_halo(tile_cfg)) e = launch_gemm_halo(tile_cfg, epi, p, zdim, stream);
-  else if (gemm_tile_is_ps(tile_cfg)) e = launch_gemm_ps(mode, tile_cfg, epi, p, zdim, stream);
+  else if (gemm_tile_is_ps(tile_cfg)) e = (tile_cfg >= TILE_PS_64x64) ? launch_gemm_ps_small(mode, tile_cfg, epi, p, zdim, stream) : launch_gemm_ps(mode, tile_cfg, epi, p, zdim, stream);
   else if (mode == 0) e = (tile_cfg <= TILE_256x128) ? launch_gemm_m0a(tile_cfg, epi, p, zdim, stream) : launch_gemm_m0b(tile_cfg, epi, p, zdim, stream);
   else if (mode == 1) e = launch_gemm_m1(tile_cfg, epi, p, zdim, stream);
   else e = launch_gemm_m2(tile_cfg, epi, p, zdim, stream);

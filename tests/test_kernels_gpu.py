@@ -44,7 +44,7 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-TILES = [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13, 14, 18, 19, 20]      # 18-20: producer-specialised blocks
+TILES = [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13, 14, 18, 19, 20, 26, 27, 28, 29]      # 18-20, 26-29: producer-specialised blocks
 HALO = (5, 6, 7, 15, 16, 17, 23, 24, 25)       # 23-25: producer-specialised (4 consumer + 4 producer wavefronts)
 _HALO_GEO = {5: (128, 64, 256, 4), 6: (256, 64, 512, 4), 7: (128, 128, 256, 4), 15: (128, 64, 256, 8), 16: (256, 64, 512, 8),
              17: (192, 64, 256, 4), 23: (192, 64, 256, 4), 24: (128, 64, 256, 4), 25: (128, 128, 256, 4)}      # (threads = those that issue the DMA requests)
@@ -101,7 +101,7 @@ def test_gemm_two_operand_tensors(tile, M, N, K1, K2, splitk):
     assert rel_l2(c.cpu(), ref.cpu()) < 2e-3
 
 
-@pytest.mark.parametrize("tile", [0, 3, 4, 8, 13, 18, 19, 20])
+@pytest.mark.parametrize("tile", [0, 3, 4, 8, 13, 18, 19, 20, 26, 27, 28, 29])
 @pytest.mark.parametrize("splitk", [1, 4])
 @pytest.mark.parametrize("act,res,out_operand", [(0, 0, 0), (1, 0, 0), (1, 0, 1), (2, 0, 0), (0, 1, 0), (1, 1, 1), (2, 1, 0)])
 def test_gemm_epilogue_times_splitk(tile, splitk, act, res, out_operand):
@@ -127,14 +127,14 @@ def test_gemm_epilogue_times_splitk(tile, splitk, act, res, out_operand):
     assert rel_l2(c.float().cpu(), ref.cpu()) < (6e-3 if out_operand else 2e-3)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 3, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 17, 18, 19, 20, 23, 24, 25])
+@pytest.mark.parametrize("tile", [0, 1, 3, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 17, 18, 19, 20, 23, 24, 25, 26, 27, 28, 29])
 @pytest.mark.parametrize("NB,H,W,Cin,Cout,stride,ups,splitk", [
     (2, 16, 64, 128, 96, 1, 0, 2), (8, 2, 8, 256, 64, 1, 0, 4), (3, 4, 16, 64, 192, 1, 0, 1), (1, 16, 16, 64, 64, 1, 0, 1),
     (2, 16, 64, 64, 64, 1, 0, 1), (2, 8, 32, 128, 192, 1, 0, 1), (1, 16, 64, 64, 64, 2, 0, 1),
     (2, 4, 16, 128, 64, 1, 1, 1), (2, 2, 8, 256, 320, 1, 0, 4), (3, 8, 16, 64, 4, 1, 0, 1)])
 def test_conv3x3(tile, NB, H, W, Cin, Cout, stride, ups, splitk):
     E = _eng()
-    if tile in HALO + (18, 19, 20) and (stride != 1 or ups):
+    if tile in HALO + (18, 19, 20, 26, 27, 28, 29) and (stride != 1 or ups):
         pytest.skip("halo and producer-specialised kernels cover stride-1 convs only")
     x = bf(rnd((NB, Cin, H, W), 3))
     w = bf(rnd((Cout, Cin, 3, 3), 4) / (3 * Cin ** 0.5))
@@ -158,7 +158,7 @@ def test_conv3x3(tile, NB, H, W, Cin, Cout, stride, ups, splitk):
     assert rel_l2(got, ref) < 2e-3
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 17, 18, 19, 20])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 17, 18, 19, 20, 26, 27, 28, 29])
 @pytest.mark.parametrize("NB,H,W,Cin,Cin2,Cout,splitk", [
     (2, 16, 64, 128, 192, 96, 1), (2, 16, 64, 64, 128, 320, 2), (4, 8, 32, 128, 64, 128, 1), (8, 4, 16, 128, 320, 192, 2),
     (8, 2, 8, 256, 128, 64, 4), (3, 4, 16, 64, 64, 64, 1)])
@@ -347,7 +347,8 @@ def _ln_chain_ref(A0, W0, b0, res, gamma, beta, W1, b1, mode):
     (8192, 320, 1024, 3, 1, 21, 1), (2048, 640, 256, 3, 1, 21, 1), (512, 1280, 64, 3, 1, 22, 1), (1024, 320, 256, 13, 1, 22, 1),
     (192, 128, 64, 0, 1, 21, 1), (4096, 640, 256, 3, 1, 22, 1),
     # 18-20: producer-specialised blocks as producer (PROD epilogue) and as LayerNorm-folded consumer (LNC / GEGLU / V^T epilogues)
-    (1024, 320, 256, 18, 1, 19, 1), (512, 1280, 64, 19, 1, 18, 1), (2048, 640, 256, 20, 2, 20, 1), (256, 640, 64, 19, 1, 19, 2)])
+    (1024, 320, 256, 18, 1, 19, 1), (512, 1280, 64, 19, 1, 18, 1), (2048, 640, 256, 20, 2, 20, 1), (256, 640, 64, 19, 1, 19, 2),
+    (1024, 320, 256, 26, 1, 27, 1), (512, 1280, 64, 27, 1, 28, 1), (2048, 640, 256, 28, 2, 29, 1), (256, 640, 64, 29, 1, 26, 2)])
 def test_ln_folded_gemm_chain(mode, M, C, T, tile0, sk0, tile1, sk1):
     """LayerNorm never runs as a kernel in the SpatialTransformer: statistics come out of the producer's epilogue and
     the consumer applies them (csrc/gemm.hip epilogue_block / splitk_reduce_vec_kernel)."""
@@ -355,7 +356,7 @@ def test_ln_folded_gemm_chain(mode, M, C, T, tile0, sk0, tile1, sk1):
     if sk1 > 1 and mode != 0:
         pytest.skip("split-K consumers exist only for the plain LN-folded projection")
     N1 = {0: C, 1: 8 * C if C <= 320 else 2 * C, 2: 3 * C}[mode]
-    bn = {0: 128, 1: 64, 2: 128, 3: 64, 4: 128, 8: 256, 9: 128, 10: 128, 11: 64, 12: 128, 13: 64, 14: 128, 18: 128, 19: 128, 20: 128,
+    bn = {0: 128, 1: 64, 2: 128, 3: 64, 4: 128, 8: 256, 9: 128, 10: 128, 11: 64, 12: 128, 13: 64, 14: 128, 18: 128, 19: 128, 20: 128, 26: 64, 27: 64, 28: 64, 29: 128,
           21: 128, 22: 128}
     if tile1 in (21, 22) and mode != 1:
         pytest.skip("the persistent kernel is the GEGLU projection only")

@@ -13,7 +13,7 @@ from diff_foley_amd import engine as E
 
 TILES = {0: "128x128", 1: "128x64", 2: "64x128", 3: "64x64", 4: "32x128", 5: "H128x64", 6: "H256x64", 7: "H128x128", 8: "128x256", 9: "256x128",
          10: "128x128s", 11: "128x64s", 12: "64x128s", 13: "64x64s", 14: "32x128s", 15: "H128x64d", 16: "H256x64d", 17: "H192x64",
-         18: "P256x128", 19: "P128x128", 20: "P2_128x128", 23: "HP192x64", 24: "HP128x64", 25: "HP128x128"}
+         18: "P256x128", 19: "P128x128", 20: "P2_128x128", 23: "HP192x64", 24: "HP128x64", 25: "HP128x128", 26: "P64x64", 27: "P2_64x64", 28: "P128x64", 29: "P64x128"}
 HALO = (5, 6, 7, 15, 16, 17, 23, 24, 25)
 # (name, kind, NB, H, W, Cin, Cout) for conv ; (name, 'lin', M, N, K)
 SHAPES = [
