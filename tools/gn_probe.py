@@ -31,4 +31,4 @@ for N, HW, Cc in [(8, 1024, 320), (8, 1024, 640), (8, 1024, 960), (8, 256, 640),
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 48 * 1e3
     mb = N * HW * Cc * 6 / 1e6
-    print(f"GN N={N} HW={HW:5d} C={Cc:5d}: {us:6.2f} us  ({mb:5.1f} MB, {mb / us / 1e3 * 1e3:6.0f} GB/s)")
+    print(f"GN N={N} HW={HW:5d} C={Cc:5d}: {us:6.2f} us  ({mb:5.1f} MB, {mb / us * 1e3:6.0f} GB/s)")
