@@ -3404,6 +3404,7 @@ int df_test_gemm(const uint16_t* A, const uint16_t* W, float* C, int M, int N, i
     g.dbg = getenv("DF_GEMM_DBG") ? atoi(getenv("DF_GEMM_DBG")) : 0;
     g.splitk = splitk;
     if (splitk > 1) g.partial = test_partial((size_t)splitk * M * N * 4);
+    else if (g.dbg & 64) g.partial = test_partial((size_t)4096 * 32 * 8);      // per-block clock stamps (tools/gemm_stamps.py)
     HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
   });
 }

@@ -601,6 +601,14 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void gemm_bf16_kernel(Ge
   const int wm = wid / WGN, wn = wid % WGN;
   const int l31 = lane & 31, lh = lane >> 5;
 
+  // tools (p.dbg bit 6, split-K 1): thread 0 stamps the shader clock at phase boundaries into p.partial[block][32] (uint64):
+  // entry, operand requests of the prologue issued, first tile landed, K loop done; the epilogue's stamps follow at slots 24..
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if ((p.dbg & 64) && p.splitk <= 1 && p.partial && threadIdx.x == 0 && blockIdx.z == 0 && n_stamp < 24)
+      reinterpret_cast<unsigned long long*>(p.partial)[(long)blockIdx.x * 32 + n_stamp++] = __builtin_amdgcn_s_memtime();
+  };
+  stamp();
   // ---- tile id with XCD-aware remap (block b runs on XCD b%8; give each XCD a contiguous range)
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   const int nblk = nbm * nbn;
@@ -830,6 +838,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void gemm_bf16_kernel(Ge
     if (NST > 4) DF_DMA(3, 3);
   }
   __builtin_amdgcn_sched_barrier(0);
+  stamp();
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -986,6 +995,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void gemm_bf16_kernel(Ge
   }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();           // tile 0 landed (the producers waited for it) and visible
+    stamp();
 #pragma unroll 1
     for (; it < nt; ++it) {
       bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
@@ -1007,6 +1017,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void gemm_bf16_kernel(Ge
 #undef DF_FRAGD
   } else {
   DF_RING_SYNC((NST - 2) * LPT + (WD > 0 ? BP : 0));       // tile 0 landed and visible
+  stamp();
   while (it < nt) {
     DF_ITER(0);
     if (it >= nt) break;
@@ -1026,6 +1037,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void gemm_bf16_kernel(Ge
   }
   }
   if constexpr (PS == 0) wait_vmcnt<0>();   // dead-slot requests of the last iterations must land before LDS is released
+  stamp();
 
   // ---- epilogue
   if (p.dbg & 2) {   // tools: keep the accumulators alive, store nothing
