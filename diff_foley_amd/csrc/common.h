@@ -29,6 +29,37 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define DF_WAVE 64
 
+// ---- Write-through stores of activations (round 4).  The 8 XCDs' L2s are not coherent with each other, so the release at the end
+// of every kernel writes back whatever the kernel left dirty in L2 -- AFTER the last block has finished: a tail proportional to the
+// output bytes (tools/gemm_bench.py, DF_GEMM_DBG=2: the 10.5 MB of a full-resolution fp32 output cost 2.7 of the 8.1 us of the
+// 8192 x 320 x 320 projection and 3.6 of the 22.4 us of the 320 -> 320 conv).  `sc1` (agent scope) sends the line on towards
+// memory when it is stored, under the blocks that are still computing, and the kernel-end write-back finds nothing to do:
+// 8.1 -> 6.8 us and 22.4 -> 20.9 us on those two.  Nothing is lost for the reader: the next kernel's acquire invalidates L2 anyway.
+// (`nt` gives half of that.)  -DDF_NO_WT_STORES compiles the plain stores back in (A/B).
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DF_NO_WT_STORES)
+__device__ __forceinline__ void st_wt(float4* p, const float4& v) {
+  const f32x4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void st_wt(uint4* p, const uint4& v) {
+  const u32x4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void st_wt(uint2* p, const uint2& v) {
+  const u32x2 t = {v.x, v.y};
+  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void st_wt(float2* p, const float2& v) {
+  const f32x2 t = {v.x, v.y};
+  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void st_wt(uint32_t* p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_wt(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+#else
+template <class T> __device__ __forceinline__ void st_wt(T* p, const T& v) { *p = v; }
+#endif
+
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   const f32x2 f = {op_clamp(lo), op_clamp(hi)};
   const op_x2 v = __builtin_convertvector(f, op_x2);

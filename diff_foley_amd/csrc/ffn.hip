@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void geglu_persistent_kernel(GemmParams p) 
         const int i = k * 64 + lane, rr = i / CPRW, ch = i % CPRW;
         const u32x4 v = *reinterpret_cast<const u32x4*>(scr + (rr / RPPC) * (RPP * BK * 2) + (rr % RPPC) * ROWB + ch * 16);
         const unsigned off = (m0 + wm * 32 + rr < p.M) ? (unsigned)((rr * p.ldc + ch * 8) * 2) : OOB;
-        if (!DBG || !(p.dbg & 2)) __builtin_amdgcn_raw_buffer_store_b128(v, rsC, off, off == OOB ? 0u : sbase, 0);
+        if (!DBG || !(p.dbg & 2)) __builtin_amdgcn_raw_buffer_store_b128(v, rsC, off, off == OOB ? 0u : sbase, 16 /* sc1: write-through, see common.h st_wt */);
         else asm volatile("" ::"v"(v), "v"(off));
       }
     }

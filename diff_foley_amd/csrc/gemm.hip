@@ -119,10 +119,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
       const long idx = orow * p.ldc + col;
       if (p.no_c_store) {       // producer whose fp32 value nobody reads (operand copy + statistics only)
       } else if (p.out_bf16)
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+        st_wt(reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx), make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)));
       else
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;
-      if (p.aux) *reinterpret_cast<uint2*>(p.aux + orow * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+        st_wt(reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx), v);
+      if (p.aux) st_wt(reinterpret_cast<uint2*>(p.aux + orow * p.ld_aux + col), make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)));
     }
   }
 }

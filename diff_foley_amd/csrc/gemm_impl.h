@@ -252,7 +252,7 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       const int r = e / CPR, c4 = (e - r * CPR) * 4;
       const int row = rowmap(r), col = n0 + c4;
       const float4 v = *reinterpret_cast<const float4*>(&sC[r * LDC + c4]);
-      if (row < p.M && col < p.N) *reinterpret_cast<float4*>(&part[(long)row * p.N + col]) = v;
+      if (row < p.M && col < p.N) st_wt(reinterpret_cast<float4*>(&part[(long)row * p.N + col]), v);
     }
     return;
   } else if constexpr (EPI == EPI_XS) {
@@ -321,9 +321,9 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       if (row < p.M && ocol < nout) {
         const long idx = (long)batch * p.c_bs + (long)row * p.ldc + ocol;
         if (p.out_bf16)
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+          st_wt(reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx), make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)));
         else
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;
+          st_wt(reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx), v);
       }
     }
     return;
@@ -364,10 +364,10 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       if (row < p.M && col < p.N) {           // M % 4 == 0 and vt_T % 4 == 0: the 4 rows belong to one sample
         const int smp = row / p.vt_T, t = row - smp * p.vt_T;
         bf16_t* dst = p.vt + ((long)smp * cv + (col - p.vt_col0)) * p.ldvt + t;
-        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf2(v[0].x, v[1].x), pack_bf2(v[2].x, v[3].x));
-        *reinterpret_cast<uint2*>(dst + p.ldvt) = make_uint2(pack_bf2(v[0].y, v[1].y), pack_bf2(v[2].y, v[3].y));
-        *reinterpret_cast<uint2*>(dst + 2 * p.ldvt) = make_uint2(pack_bf2(v[0].z, v[1].z), pack_bf2(v[2].z, v[3].z));
-        *reinterpret_cast<uint2*>(dst + 3 * p.ldvt) = make_uint2(pack_bf2(v[0].w, v[1].w), pack_bf2(v[2].w, v[3].w));
+        st_wt(reinterpret_cast<uint2*>(dst), make_uint2(pack_bf2(v[0].x, v[1].x), pack_bf2(v[2].x, v[3].x)));
+        st_wt(reinterpret_cast<uint2*>(dst + p.ldvt), make_uint2(pack_bf2(v[0].y, v[1].y), pack_bf2(v[2].y, v[3].y)));
+        st_wt(reinterpret_cast<uint2*>(dst + 2 * p.ldvt), make_uint2(pack_bf2(v[0].z, v[1].z), pack_bf2(v[2].z, v[3].z)));
+        st_wt(reinterpret_cast<uint2*>(dst + 3 * p.ldvt), make_uint2(pack_bf2(v[0].w, v[1].w), pack_bf2(v[2].w, v[3].w)));
       }
     }
     return;
@@ -414,28 +414,28 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       const float s1 = row16_sum(ok ? (v.x + v.y) + (v.z + v.w) : 0.f);                                             \
       const float s2 = row16_sum(ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f);                     \
       if (ok && (tid & 15) == 0) {                                                                                  \
-        p.stats[(long)row * p.stats_slots + (col >> 6)] = make_float2(s1, s2);                                      \
-        if (p.dup_rows) p.stats[(long)(row + p.dup_rows) * p.stats_slots + (col >> 6)] = make_float2(s1, s2);       \
+        st_wt(&p.stats[(long)row * p.stats_slots + (col >> 6)], make_float2(s1, s2));                                      \
+        if (p.dup_rows) st_wt(&p.stats[(long)(row + p.dup_rows) * p.stats_slots + (col >> 6)], make_float2(s1, s2));       \
       }                                                                                                             \
     }                                                                                                               \
     if (ok) {                                                                                                       \
       const long idx = (long)batch * p.c_bs + (long)row * p.ldc + col;                                              \
       if (((FL) & 4) && p.no_c_store) { /* producer whose fp32 value nobody reads: operand copy + statistics only */ \
       } else if (p.out_bf16)                                                                                        \
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
+        st_wt(reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx), make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w))); \
       else                                                                                                          \
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx) = v;                                        \
+        st_wt(reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx), v);                                        \
       if (((FL) & 1) && p.aux)                                                                                      \
-        *reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
+        st_wt(reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col), make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w))); \
       if (p.dup_rows) {       /* CFG prefix: the other half of the batch gets the same row */                       \
         const long idx2 = idx + (long)p.dup_rows * p.ldc;                                                           \
         if (((FL) & 4) && p.no_c_store) {                                                                            \
         } else if (p.out_bf16)                                                                                      \
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx2) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
+          st_wt(reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx2), make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w))); \
         else                                                                                                        \
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx2) = v;                                     \
+          st_wt(reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + idx2), v);                                     \
         if (((FL) & 1) && p.aux)                                                                                    \
-          *reinterpret_cast<uint2*>(p.aux + (long)(row + p.dup_rows) * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); \
+          st_wt(reinterpret_cast<uint2*>(p.aux + (long)(row + p.dup_rows) * p.ld_aux + col), make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w))); \
       }                                                                                                             \
     }                                                                                                               \
   }
@@ -503,17 +503,17 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
           const float s1 = row16_sum(ok ? (v.x + v.y) + (v.z + v.w) : 0.f);
           const float s2 = row16_sum(ok ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f);
           if (ok) {
-            if ((tid & 15) == 0) p.stats[(long)row * p.stats_slots + (col >> 6)] = make_float2(s1, s2);
+            if ((tid & 15) == 0) st_wt(&p.stats[(long)row * p.stats_slots + (col >> 6)], make_float2(s1, s2));
             if (!p.no_c_store) {
               if (p.out_bf16)
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + cbase + (long)row * p.ldc) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+                st_wt(reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + cbase + (long)row * p.ldc), make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)));
               else
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + cbase + (long)row * p.ldc) = v;
+                st_wt(reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + cbase + (long)row * p.ldc), v);
             }
-            if (p.aux) *reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+            if (p.aux) st_wt(reinterpret_cast<uint2*>(p.aux + (long)row * p.ld_aux + col), make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)));
           }
         } else {
-          if (ok) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + cbase + (long)row * p.ldc) = v;
+          if (ok) st_wt(reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + cbase + (long)row * p.ldc), v);
         }
       }
       return;
@@ -1349,19 +1349,40 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel
       // the next tap's operands -- DF_HALO_SYNC's rule, the issue order is the symmetric kernel's -- and the tap barrier
       wait_vmcnt<(NSTW - 2) * WPASS>();
       __builtin_amdgcn_s_barrier();
+      // The next slice's halo is requested in pieces, pass i with tap i % 8, IN FRONT of that tap's weight request (round 4,
+      // tools/halo_stamps.py: issued whole at tap 0, its <= 12 requests per wavefront at ~130 cycles each made tap 0 cost 1.7 k
+      // cycles while taps 1-8 ran at ~480 -- the consumers sat at tap 0's barrier).  Loads retire in issue order, so with a(T) halo
+      // requests at tap T the operands of tap T + 1 (weights requested NSTW - 2 = 2 taps earlier) have landed once at most
+      // 2 * WPASS + a(T - 1) + a(T) younger requests are outstanding; the wait in front of the next slice's tap 0 allows the two
+      // youngest weight tiles only, which covers the whole halo (a(8) = 0 and a(7) sits in front of tap 7's weight request).
+      static_assert(NSTW == 4, "the spread halo schedule counts on weights requested 3 taps ahead");
+      int acnt[10];
+#pragma unroll
+      for (int t = 0; t < 10; ++t) acnt[t] = (t >= 1 && t <= 8) ? (APASS > t - 1) + (APASS > t + 7) : 0;      // acnt[T + 1] = a(T)
+#define DF_HALO_A_PART(C, BUF, T)                                                                 \
+  {                                                                                             \
+    bf16_t* a_ = sA + (BUF) * HRP * BK + wid * (8 * BK);                                        \
+    const bool live = (C) < c1;                                                                 \
+    const unsigned cb = (unsigned)(C) * (BK * 2);                                               \
+    _Pragma("unroll") for (int i = (T); i < MAXAP; i += 8)                                      \
+      if ((T) < 8 && i < APASS)                                                                 \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a_ + i * RPP * BK), 16,         \
+                                                 (live && a_off[i] != OOB) ? a_off[i] + cb : OOB, 0, 0, 0); \
+  }
 #define DF_PTAP(T)                                                                                \
   {                                                                                             \
     const int it_ = cs * 9 + (T);                                                               \
+    DF_HALO_A_PART(c0 + cs + 1, (cs + 1) & 1, T);                                               \
     DF_HALO_W(it_ + NSTW - 1, (it_ + NSTW - 1) % NSTW);                                         \
-    if ((T) == 0) DF_HALO_A(c0 + cs + 1, (cs + 1) & 1);                                         \
-    if (((T) + 1) % 9 >= 1 && ((T) + 1) % 9 <= NSTW - 1) wait_vmcnt_dyn((NSTW - 2) * WPASS + APASS); \
-    else wait_vmcnt<(NSTW - 2) * WPASS>();                                                      \
+    if ((T) == 8) wait_vmcnt<(NSTW - 2) * WPASS>();                                             \
+    else wait_vmcnt_dyn((NSTW - 2) * WPASS + acnt[(T)] + acnt[(T) + 1]);                        \
     __builtin_amdgcn_s_barrier();                                                               \
   }
       for (int cs = 0; cs < nc; ++cs) {
         DF_PTAP(0) DF_PTAP(1) DF_PTAP(2) DF_PTAP(3) DF_PTAP(4) DF_PTAP(5) DF_PTAP(6) DF_PTAP(7) DF_PTAP(8)
       }
 #undef DF_PTAP
+#undef DF_HALO_A_PART
       wait_vmcnt<0>();
       if (PS > 1 && wid >= WGM * WGN) {      // surplus producers: the row-table barrier and epilogue_block's two, nothing else
         __builtin_amdgcn_s_barrier();

@@ -28,6 +28,12 @@ assert L.df_test_scratch_read(buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
 buf = buf.reshape(4096, 32)
 nb = int((buf[:, 0] > 0).sum())
 print("blocks:", nb)
+# (the clocks of different XCDs are not aligned: only differences inside one block mean anything)
+tot = np.array([buf[i, :24][buf[i, :24] > 0][-1] - buf[i, 0] for i in range(nb)], dtype=np.int64)
+from gemm_bench import timeit
+us = timeit(lambda: L.df_test_conv3x3(ptr(a), ptr(w), ptr(b), ptr(c), NB, H, W, Cin, Cout, 1, 0, tile, 1, st))
+print(f"block totals min / median / max {int(tot.min())} / {int(np.median(tot))} / {int(tot.max())} cycles; {us:.1f} us per launch back to back "
+      f"(stamps on)")
 for blk in (0, 1, 8, 100, nb - 1):
     row = buf[blk].astype(np.int64)
     n = int((row[:24] > 0).sum())
