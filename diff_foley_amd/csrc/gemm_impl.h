@@ -292,8 +292,8 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       sm += __shfl_xor(sm, 4);
       const float inv = 1.0f / sm;
       if (row < p.M && col < p.N)
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (long)row * p.ldc + col) =
-            make_uint2(pack_bf2(v.x * inv, v.y * inv), pack_bf2(v.z * inv, v.w * inv));
+        st_wt(reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (long)row * p.ldc + col),
+              make_uint2(pack_bf2(v.x * inv, v.y * inv), pack_bf2(v.z * inv, v.w * inv)));
     }
     return;
   } else if constexpr (EPI == EPI_GEGLU) {
@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel
   for (int i = 0; i < MAXAP; ++i) {
     const int hr = r0 + RPP * i;                 // halo row
     unsigned off = OOB;
-    if (i < APASS && hr < HR && (!PS || producer)) {
+    if (i < APASS && hr < HR) {      // (PS: the consumers take the odd passes of the FIRST halo, see the prologue)
       const unsigned e = atab[hr];
       if (e != 0xffffffffu) off = (e & ~7u) + ((((unsigned)tid & 7u) ^ (e & 7u)) << 4);     // lda % 8 == 0: the low 4 bits of a pixel offset are free
     }
@@ -1302,11 +1302,31 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel
 
   // ---- prologue: A(0), W(0 .. NSTW-2) -- requested as soon as the offsets exist; fragment coordinates, accumulator init and
   // the epilogue prefetch below run while these are in flight
-  if (!PS || producer) {
+  // PS: the first halo is the longest request burst of the block (<= 12 per wavefront in front of the first MFMA) and the consumers
+  // have nothing to do yet: they take its odd passes (own vmcnt(0) in front of the first tap barrier), the producers the even ones.
+#define DF_HALO_A_PAR(C, BUF, PAR)                                                                \
+  {                                                                                             \
+    bf16_t* a_ = sA + (BUF) * HRP * BK + wid * (8 * BK);                                        \
+    const unsigned cb = (unsigned)(C) * (BK * 2);                                               \
+    _Pragma("unroll") for (int i = (PAR); i < MAXAP; i += 2)                                    \
+      if (i < APASS)                                                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(a_ + i * RPP * BK), 16,         \
+                                                 ((C) < c1 && a_off[i] != OOB) ? a_off[i] + cb : OOB, 0, 0, 0); \
+  }
+  if constexpr (PS != 0) {
+    if (producer) {
+      DF_HALO_A_PAR(c0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NSTW - 1; ++t) DF_HALO_W(t, t);
+    } else {
+      DF_HALO_A_PAR(c0, 0, 1);
+    }
+  } else {
     DF_HALO_A(c0, 0);
 #pragma unroll
     for (int t = 0; t < NSTW - 1; ++t) DF_HALO_W(t, t);
   }
+#undef DF_HALO_A_PAR
   __builtin_amdgcn_sched_barrier(0);
   stamp();
 
@@ -1467,6 +1487,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel
   }
 
   stamp();
+  if constexpr (PS != 0) wait_vmcnt<0>();      // this consumer's share of the first halo
   DF_HALO_SYNC(0);
   stamp();
   for (int cs = 0; cs < nc; ++cs) {
