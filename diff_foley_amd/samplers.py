@@ -129,9 +129,9 @@ class DDIMSampler(object):
         self.schedule = schedule
 
     def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0.0, verbose=True):
-        if ddim_discretize != "uniform":
-            raise NotImplementedError("only the 'uniform' DDIM discretisation is on the path")
-        self.tables = DDIMTables(self.model.alphas_cumprod, ddim_num_steps, ddim_eta)
+        # "uniform" | "quad" (util.py:46-60).  As in the reference, sample() re-makes the schedule with the default ("uniform",
+        # ddim.py:90): a "quad" schedule serves callers that drive the step loop from the tables themselves.
+        self.tables = DDIMTables(self.model.alphas_cumprod, ddim_num_steps, ddim_eta, ddim_discretize)
         self.ddim_timesteps = self.tables.timesteps
         self.ddim_alphas = self.tables.alphas
         self.ddim_alphas_prev = self.tables.alphas_prev

@@ -46,11 +46,16 @@ def register_schedule(linear_start, linear_end, timesteps, v_posterior=0.0, beta
 class DDIMTables:
     """Per-step scalars of DDIMSampler.make_schedule (ddim.py:27-56) as python floats (fp32-rounded)."""
 
-    def __init__(self, alphas_cumprod, S, eta=0.0):
+    def __init__(self, alphas_cumprod, S, eta=0.0, discretize="uniform"):
         ac = alphas_cumprod.detach().cpu().float().numpy()        # fp32 buffer values
         T = ac.shape[0]
-        c = T // S
-        self.timesteps = np.arange(0, T, c) + 1                   # util.py:48-57: S=25 -> [1, 41, ..., 961]
+        if discretize == "uniform":
+            c = T // S
+            self.timesteps = np.arange(0, T, c) + 1               # util.py:48-57: S=25 -> [1, 41, ..., 961]
+        elif discretize == "quad":                                # util.py:50-51: squares of an even grid up to sqrt(0.8 T)
+            self.timesteps = ((np.linspace(0, np.sqrt(T * .8), S)) ** 2).astype(int) + 1
+        else:
+            raise NotImplementedError(f'There is no ddim discretization method called "{discretize}"')
         if self.timesteps.max() >= T:
             raise IndexError(f"ddim_steps={S}: timestep {self.timesteps.max()} out of range "
                              f"(same failure as the reference, util.py:48-57)")

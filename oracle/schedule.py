@@ -37,15 +37,20 @@ def ddpm_schedule(linear_start=0.00085, linear_end=0.012, timesteps=1000, v_post
     }
 
 
-def ddim_schedule(alphas_cumprod, S, eta=0.0, T=1000):
+def ddim_schedule(alphas_cumprod, S, eta=0.0, T=1000, discretize="uniform"):
     """DDIMSampler.make_schedule (ddim.py:27-56): returns dict with numpy tables.
 
     ``alphas_cumprod`` is the fp32 torch buffer; the DDIM alphas are gathered from
     it (fp32 values) and kept as numpy float32 arrays exactly as the reference
     does (util.py:63-74 operates on ``alphacums.cpu()`` = a fp32 tensor indexed
     with a numpy int array)."""
-    c = T // S
-    steps = np.asarray(list(range(0, T, c))) + 1                  # util.py:48-57 (quirk kept)
+    if discretize == "uniform":
+        c = T // S
+        steps = np.asarray(list(range(0, T, c))) + 1              # util.py:48-57 (quirk kept)
+    elif discretize == "quad":
+        steps = ((np.linspace(0, np.sqrt(T * .8), S)) ** 2).astype(int) + 1      # util.py:50-51
+    else:
+        raise NotImplementedError(discretize)
     ac = alphas_cumprod
     alphas = ac[steps]                                            # fp32 tensor
     alphas_prev = np.asarray([ac[0]] + ac[steps[:-1]].tolist())   # float64 numpy of fp32 values

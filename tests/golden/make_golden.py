@@ -420,6 +420,27 @@ def full_extra(seed=0):
     save("g5_full_samplers_extra.npz", **out)
 
 
+def quad():
+    """G11: DDIMSampler.make_schedule(ddim_discretize="quad") of the reference (tiny model: the schedule only needs its buffers),
+    S in {10, 25, 50}, eta 0 and 1."""
+    spec = synth.state_dict_spec(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
+    sd = synth.make_state_dict(spec, 0)
+    cfg = ref_import.load_ldm_config(unet=synth.UNET_TINY, vae=synth.VAE_TINY, cond=synth.COND_TINY)
+    model, ns = ref_import.build_reference_ldm(cfg, sd)
+    out = {}
+    for S in (10, 25, 50):
+        for eta in (0.0, 1.0):
+            s = ns.DDIMSampler(model)
+            s.make_schedule(S, ddim_discretize="quad", ddim_eta=eta, verbose=False)
+            tag = f"quad{S}_eta{int(eta)}"
+            out[f"{tag}_timesteps"] = s.ddim_timesteps
+            out[f"{tag}_alphas"] = np.asarray(s.ddim_alphas, dtype=np.float64)
+            out[f"{tag}_alphas_prev"] = np.asarray(s.ddim_alphas_prev, dtype=np.float64)
+            out[f"{tag}_sqrt_one_minus_alphas"] = np.asarray(s.ddim_sqrt_one_minus_alphas, dtype=np.float64)
+            out[f"{tag}_sigmas"] = np.asarray(s.ddim_sigmas, dtype=np.float64)
+    save("g11_ddim_quad.npz", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiny", action="store_true")
@@ -428,6 +449,7 @@ if __name__ == "__main__":
     ap.add_argument("--video", action="store_true", help="G9: frame pre-processing vectors (Pillow's own resize outputs)")
     ap.add_argument("--configs", action="store_true", help="G8: BASELINE configs[2] / configs[4] at full size (~8 min)")
     ap.add_argument("--inpaint", action="store_true", help="G10: mask / x0 inpainting through DDIM, PLMS and the ancestral sampler (tiny)")
+    ap.add_argument("--quad", action="store_true", help="G11: the 'quad' DDIM discretisation tables (seconds)")
     ap.add_argument("--full-extra", action="store_true", help="G5 extension: DDIM-25 reference runs for seeds 23 / 24 (~4 min)")
     a = ap.parse_args()
     torch.set_num_threads(8)
@@ -445,3 +467,5 @@ if __name__ == "__main__":
         full_extra()
     if a.inpaint:
         inpaint()
+    if a.quad:
+        quad()

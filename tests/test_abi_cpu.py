@@ -66,6 +66,24 @@ def test_product_schedule_matches_reference_golden():
     assert np.allclose(got, g["interp_log_alpha"].numpy(), rtol=2e-6, atol=1e-7)
 
 
+def test_product_quad_discretisation_matches_reference_golden():
+    """DDIMSampler.make_schedule(ddim_discretize="quad"): tables bit-equal to the reference's (sigmas to fp32 rounding)."""
+    g = gold("g11_ddim_quad.npz")
+    m = P.LatentDiffusion(**P.stage2_config())
+    for s in (10, 25, 50):
+        for eta in (0, 1):
+            smp = P.DDIMSampler(m)
+            smp.make_schedule(s, ddim_discretize="quad", ddim_eta=float(eta), verbose=False)
+            tag = f"quad{s}_eta{eta}"
+            assert np.array_equal(smp.ddim_timesteps, g[f"{tag}_timesteps"].numpy())
+            assert np.array_equal(smp.ddim_alphas.astype(np.float64), g[f"{tag}_alphas"].numpy())
+            assert np.array_equal(smp.ddim_alphas_prev.astype(np.float64), g[f"{tag}_alphas_prev"].numpy())
+            assert np.array_equal(smp.ddim_sqrt_one_minus_alphas.astype(np.float64), g[f"{tag}_sqrt_one_minus_alphas"].numpy())
+            assert np.allclose(smp.ddim_sigmas.astype(np.float64), g[f"{tag}_sigmas"].numpy(), rtol=2e-6, atol=0)
+    with pytest.raises(NotImplementedError):
+        P.DDIMSampler(m).make_schedule(25, ddim_discretize="cosine")
+
+
 def test_ddim_step_count_quirk():
     m = P.LatentDiffusion(**P.stage2_config())
     with pytest.raises(IndexError):

@@ -37,6 +37,20 @@ def test_g1_ddim_tables(S):
     assert np.all(np.asarray(sch["sigmas"], dtype=np.float64) == 0)
 
 
+@pytest.mark.parametrize("S", [10, 25, 50])
+@pytest.mark.parametrize("eta", [0, 1])
+def test_g11_ddim_quad_tables(S, eta):
+    """ddim_discretize="quad" (util.py:50-51) against the reference's own make_schedule output."""
+    g = gold("g11_ddim_quad.npz")
+    sch = osch.ddim_schedule(osch.ddpm_schedule()["alphas_cumprod"], S, eta=float(eta), discretize="quad")
+    tag = f"quad{S}_eta{eta}"
+    assert np.array_equal(sch["timesteps"], g[f"{tag}_timesteps"].numpy())
+    assert np.array_equal(np.asarray(sch["alphas"], dtype=np.float64), g[f"{tag}_alphas"].numpy())
+    assert np.array_equal(np.asarray(sch["alphas_prev"], dtype=np.float64), g[f"{tag}_alphas_prev"].numpy())
+    assert np.array_equal(np.asarray(sch["sqrt_one_minus_alphas"], dtype=np.float64), g[f"{tag}_sqrt_one_minus_alphas"].numpy())
+    assert np.allclose(np.asarray(sch["sigmas"], dtype=np.float64), g[f"{tag}_sigmas"].numpy(), rtol=1e-6, atol=0)
+
+
 @pytest.mark.parametrize("S", [25, 50])
 def test_g1_dpm_tables(S):
     g = gold("g1_schedules.npz")
