@@ -25,9 +25,10 @@ constexpr int VROW = 36;        // V^T LDS row stride in bf16 (72 B: conflict-fr
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __restrict__ Q, int ldq,
                                                             const bf16_t* __restrict__ K, int ldk,
-                                                            const bf16_t* __restrict__ Vt, int ldvt,
-                                                            bf16_t* __restrict__ O, int ldo, int heads, int Tq,
-                                                            int Tk, float scale_log2e) {
+                                                            const bf16_t* __restrict__ Vt, int ldvt, int heads, int Tq,
+                                                            int Tk, float scale_log2e, bf16_t* __restrict__ O, int ldo) {
+  // (argument order: everything the Q / K / V fetches need sits inside the 16 dwords preloaded into SGPRs at wavefront launch,
+  // build.sh; the output pointer, needed last, arrives by s_load)
   constexpr int DKC = (D + 15) / 16;      // 16-wide contraction chunks for Q K^T
   constexpr int DKP = DKC * 16;           // padded head dim
   constexpr int DT = (D + 31) / 32;       // 32-row tiles of O^T
@@ -243,16 +244,16 @@ hipError_t launch_d(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, cons
   const float sl2 = scale * 1.4426950408889634f;
   if (Tq >= 128) {
     dim3 grid((Tq + 127) / 128, heads, N);
-    hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, heads, Tq,
-                       Tk, sl2);
+    hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), 0, s, Q, ldq, K, ldk, Vt, ldvt, heads, Tq, Tk, sl2,
+                       O, ldo);
   } else if (Tq >= 64) {
     dim3 grid((Tq + 63) / 64, heads, N);
-    hipLaunchKernelGGL((attention_kernel<D, 2>), grid, dim3(128), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, heads, Tq,
-                       Tk, sl2);
+    hipLaunchKernelGGL((attention_kernel<D, 2>), grid, dim3(128), 0, s, Q, ldq, K, ldk, Vt, ldvt, heads, Tq, Tk, sl2,
+                       O, ldo);
   } else {
     dim3 grid((Tq + 31) / 32, heads, N);
-    hipLaunchKernelGGL((attention_kernel<D, 1>), grid, dim3(64), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, heads, Tq,
-                       Tk, sl2);
+    hipLaunchKernelGGL((attention_kernel<D, 1>), grid, dim3(64), 0, s, Q, ldq, K, ldk, Vt, ldvt, heads, Tq, Tk, sl2,
+                       O, ldo);
   }
   return hipGetLastError();
 }

@@ -34,10 +34,15 @@ struct GnSlabs {
 // pair for all of its PER items (rows ty + k * R), so gamma / beta / bias are loaded once, addresses are affine in k and no
 // per-item division or index array exists (the round-2 kernel indexed items linearly: 25 VALU instructions of integer division
 // per item and, at PER = 16, scratch spills -- the norm was VALU-bound, its time proportional to the element count).
+// Argument order (round 4): what the first loads need -- x, ld, HW, cpg, R and the slab switch (n, own, c_own, stride) -- comes
+// first, inside the 16 dwords that are preloaded into SGPRs at wavefront launch (build.sh); everything behind them arrives by
+// s_load while the loads are already in flight.  `sl` carries the same four values again; the kernel reads the scalars.
 template <int PER>
-__global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
+__global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW, int cpg, int R, int sl_n,
+                                     const float* __restrict__ sl_own, int sl_c_own, long sl_stride,
+                                     bf16_t* __restrict__ out, int ldo, int silu, int C,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                     int silu, bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw, GnSlabs sl, int R) {
+                                     bf16_t* __restrict__ raw, GnSlabs sl) {
   __shared__ float red[16];
   // block b runs on XCD b%8: put the 4 neighbouring groups that share 128-B lines of every pixel row on one XCD
   const int g = (blockIdx.x & 7) * 4 + (blockIdx.x >> 3), n = blockIdx.y;
@@ -49,26 +54,26 @@ __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW
   float2 v[PER];
   // clamped row of item k (loads are unconditional); element offsets fit 32 bits (one tensor / slab < 2^31 elements)
 #define DF_ROW(k) min(ty + (k) * R, HW - 1)
-  const bool from_slabs = sl.n > 0 && (!sl.own || c < sl.c_own);
+  const bool from_slabs = sl_n > 0 && (!sl_own || c < sl_c_own);
   if (from_slabs) {
     // split-K input: the slab loads are issued U slabs at a time (16 independent loads per thread in flight) and added in slab
     // order, so the sum is bit-identical to the reduce kernel's and the latency chain is n / U long, not n
-    const int sld = sl.own ? sl.c_own : ld;
-    const float* p0 = (sl.own ? sl.own : x) + row0 * sld + c;
+    const int sld = sl_own ? sl_c_own : ld;
+    const float* p0 = (sl_own ? sl_own : x) + row0 * sld + c;
 #pragma unroll
     for (int k = 0; k < PER; ++k) v[k] = *reinterpret_cast<const float2*>(p0 + DF_ROW(k) * sld);
     constexpr int U = PER >= 16 ? 1 : 16 / PER;
-    for (int s0 = 1; s0 < sl.n; s0 += U) {
+    for (int s0 = 1; s0 < sl_n; s0 += U) {
       float2 t[U][PER];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const float* sp = p0 + (long)min(s0 + u, sl.n - 1) * sl.stride;
+        const float* sp = p0 + (long)min(s0 + u, sl_n - 1) * sl_stride;
 #pragma unroll
         for (int k = 0; k < PER; ++k) t[u][k] = *reinterpret_cast<const float2*>(sp + DF_ROW(k) * sld);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (s0 + u < sl.n) {
+        if (s0 + u < sl_n) {
 #pragma unroll
           for (int k = 0; k < PER; ++k) {
             v[k].x += t[u][k].x;
@@ -85,7 +90,7 @@ __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW
       v[k].x += bx;
       v[k].y += by;
     }
-    if (sl.own) {       // the producer's epilogue in the reduce kernel's order (bias, then residual); x is written back
+    if (sl_own) {       // the producer's epilogue in the reduce kernel's order (bias, then residual); x is written back
       if (sl.res) {
         float2 r[PER];
 #pragma unroll
@@ -766,8 +771,8 @@ static hipError_t launch_groupnorm_sl(const float* x, int ld, int N, int HW, int
   {                                                                                                                   \
     const int R = (HW + (PER) - 1) / (PER);                                                                           \
     const int threads = (half * R + 63) & ~63;                                                                        \
-    hipLaunchKernelGGL(groupnorm_reg_kernel<PER>, dim3(32, N), dim3(threads), 0, s, x, ld, HW, C, cpg, gamma, beta, eps, \
-                       silu, out, ldo, raw_out, sl, R);                                                               \
+    hipLaunchKernelGGL(groupnorm_reg_kernel<PER>, dim3(32, N), dim3(threads), 0, s, x, ld, HW, cpg, R, sl.n, sl.own,  \
+                       sl.c_own, sl.stride, out, ldo, silu, C, gamma, beta, eps, raw_out, sl);                        \
   }
   if (items > 16384 || need > 20 || half < 1) {
     if (nslab > 0) return hipErrorInvalidValue;
