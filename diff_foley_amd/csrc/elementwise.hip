@@ -38,14 +38,24 @@ struct GnSlabs {
 // first, inside the 16 dwords that are preloaded into SGPRs at wavefront launch (build.sh); everything behind them arrives by
 // s_load while the loads are already in flight.  `sl` carries the same four values again; the kernel reads the scalars.
 template <int PER>
-__global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW, int cpg, int R, int sl_n,
+__global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW, int cpg, int R, int sl_n, int nsamp,
                                      const float* __restrict__ sl_own, int sl_c_own, long sl_stride,
                                      bf16_t* __restrict__ out, int ldo, int silu, int C,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                      bf16_t* __restrict__ raw, GnSlabs sl) {
   __shared__ float red[16];
-  // block b runs on XCD b%8: put the 4 neighbouring groups that share 128-B lines of every pixel row on one XCD
-  const int g = (blockIdx.x & 7) * 4 + (blockIdx.x >> 3), n = blockIdx.y;
+  // block b runs on XCD b%8.  Samples in multiples of 8 (the UNet's CFG batch): ALL groups of a sample on one XCD (b = g * nsamp +
+  // n), so every 128-B line of the sample's rows is read into, and written back from, exactly one L2.  Otherwise: the 4
+  // neighbouring groups that share lines on one XCD (b = n * 32 + (XCD-major group index)).
+  int g, n;
+  if ((nsamp & 7) == 0) {
+    n = blockIdx.x % nsamp;
+    g = blockIdx.x / nsamp;
+  } else {
+    const int bx = blockIdx.x & 31;
+    n = blockIdx.x >> 5;
+    g = (bx & 7) * 4 + (bx >> 3);
+  }
   const int half = cpg >> 1;
   const int ty = threadIdx.x / half, tx = threadIdx.x - ty * half;
   const bool act = ty < R;                       // the last wavefront may carry idle threads
@@ -771,7 +781,7 @@ static hipError_t launch_groupnorm_sl(const float* x, int ld, int N, int HW, int
   {                                                                                                                   \
     const int R = (HW + (PER) - 1) / (PER);                                                                           \
     const int threads = (half * R + 63) & ~63;                                                                        \
-    hipLaunchKernelGGL(groupnorm_reg_kernel<PER>, dim3(32, N), dim3(threads), 0, s, x, ld, HW, cpg, R, sl.n, sl.own,  \
+    hipLaunchKernelGGL(groupnorm_reg_kernel<PER>, dim3(32 * N), dim3(threads), 0, s, x, ld, HW, cpg, R, sl.n, N, sl.own, \
                        sl.c_own, sl.stride, out, ldo, silu, C, gamma, beta, eps, raw_out, sl);                        \
   }
   if (items > 16384 || need > 20 || half < 1) {
