@@ -32,7 +32,8 @@ def _warn_batch(conditioning, batch_size):
 # Reference sampler features that are NOT on this path.  The reference classes accept them (ddim.py:58-113, 179-273;
 # plms.py:60-110; dpm_solver/sampler.py:24-56); silently dropping one would return a plausible but wrong sample, so a
 # non-default value raises.  Anything not listed is ignored exactly like the reference's own **kwargs.
-_UNSUPPORTED_DEFAULTS = dict(quantize_x0=False, noise_dropout=0.0, normals_sequence=None)
+# (`normals_sequence` is accepted and never read by the reference's samplers -- ddim.py:65,123, plms.py:64 -- so it is ignored here too.)
+_UNSUPPORTED_DEFAULTS = dict(quantize_x0=False, noise_dropout=0.0)
 
 
 def reject_unsupported(sampler, kwargs, extra=None):
