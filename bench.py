@@ -231,8 +231,17 @@ def run_mode(precision, sd_dev, a, dev, rank, world, lo, hi, barrier, dump_ops="
                 "what": "LatentDiffusion.sample_log_diff_sampler('DDIM', 25 steps, CFG 4.5) x 4 calls incl. set_context per call"}
     if world > 1:       # every rank's pack / broadcast / import seconds in the one JSON line (first real SCALE run shows them)
         infos = [None] * world
-        torch.distributed.all_gather_object(infos, dict(rank=rank, **{k: (round(v, 4) if isinstance(v, float) else v)
-                                                                   for k, v in (dist_info or {}).items()}))
+        # what each rank saw of the job: the world size of its process group on its backend ("nccl" = RCCL), the device it
+        # computes on and that device's PCI bus id -- a SCALE run with two ranks on one GPU, or a rank that fell back to gloo,
+        # shows in the line itself
+        try:
+            bus = torch.cuda.get_device_properties(dev).pci_bus_id
+        except Exception:
+            bus = None
+        seen = dict(rccl_world_seen=torch.distributed.get_world_size(), backend=torch.distributed.get_backend(),
+                    cuda_device=torch.cuda.current_device(), pci_bus_id=bus, gpu_name=torch.cuda.get_device_name(dev))
+        torch.distributed.all_gather_object(infos, dict(rank=rank, **seen, **{k: (round(v, 4) if isinstance(v, float) else v)
+                                                                             for k, v in (dist_info or {}).items()}))
         dist_info = {"per_rank": infos}
     return dict(model=model, dt=dt, prof=prof, sub=sub, stats=eng.plan_stats(), t_setup=t_setup, dist=dist_info, loop=loop)
 

@@ -36,23 +36,26 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // memory when it is stored, under the blocks that are still computing, and the kernel-end write-back finds nothing to do:
 // 8.1 -> 6.8 us and 22.4 -> 20.9 us on those two.  Nothing is lost for the reader: the next kernel's acquire invalidates L2 anyway.
 // (`nt` gives half of that.)  -DDF_NO_WT_STORES compiles the plain stores back in (A/B).
+// Hazard: gfx950 needs 2 wait states between a VMEM store of more than 64 bits and a VALU write of its data VGPRs, and the
+// hazard recogniser does not see into inline asm -- the dwordx4 forms carry their own `s_nop 1` (= 2 wait states); the <= 64-bit
+// forms need none.  tools/check_store_hazard.py scans the built libraries for a dwordx4 sc1 store without it.
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(DF_NO_WT_STORES)
 __device__ __forceinline__ void st_wt(float4* p, const float4& v) {
   const f32x4 t = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(t) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
 __device__ __forceinline__ void st_wt(uint4* p, const uint4& v) {
   const u32x4 t = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(t) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
 __device__ __forceinline__ void st_wt(uint2* p, const uint2& v) {
   const u32x2 t = {v.x, v.y};
-  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(t) : "memory");
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
 }
 __device__ __forceinline__ void st_wt(float2* p, const float2& v) {
   const f32x2 t = {v.x, v.y};
-  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(t) : "memory");
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
 }
 __device__ __forceinline__ void st_wt(uint32_t* p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void st_wt(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }

@@ -21,6 +21,7 @@
 // MFMA: v_mfma_f32_32x32x16_{bf16,f16}; operands HBM/L2 -> LDS by buffer_load ... lds (no VGPR round trip), XOR-swizzled through
 // the source address like gemm_impl.h; counted vmcnt, one raw s_barrier per K step, lgkmcnt(0) in front of it (ring hand-back).
 #include "gemm_impl.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -117,6 +118,15 @@ __global__ __launch_bounds__(256, 2) void geglu_persistent_kernel(GemmParams p) 
   for (int s = 0; s < NST - 1; ++s) dma_step();
   __builtin_amdgcn_sched_barrier(0);
   stamp();
+  // ---- anti-phase start (round 5).  The two resident blocks of a CU start within ~20 cycles of each other and walk identical
+  // tile sequences, so they stay in LOCKSTEP: both in the K loop (two wavefronts per SIMD contending for the matrix pipe and the
+  // request issue: ~2 k cycles per K step against ~1 k alone), then both in the epilogue (two wavefronts contending for the VALU:
+  // 6.5 k cycles for ~2.5 k of arithmetic) -- profiles/r4_pgeglu_stamps.txt, blocks 0 / 256.  The second block of every CU
+  // (block b + 256 lands beside block b: dispatch fills one block per CU first) sleeps p.th x ~1 k cycles behind its prologue
+  // requests, so that one block's K loop runs beside the other's epilogue; the symmetry that kept them in phase keeps them apart.
+  if (p.th > 0 && (int)gridDim.x > 256 && bid >= 256)
+    for (int i = 0; i < p.th; ++i) __builtin_amdgcn_s_sleep(16);
+  __builtin_amdgcn_sched_barrier(0);
 
   // LDS fragment byte offsets inside a stage for the 4 k-steps of a tile
   int fA[4], fB[TN][4];
@@ -323,7 +333,14 @@ hipError_t launch_pgeglu(const GemmParams& p, hipStream_t stream) {
   }
   const int nblk = ((p.M + BM - 1) / BM) * (p.N / 128);
   const int grid = std::min(nblk, 512);                  // 2 resident blocks on each of the 256 CUs
-  hipLaunchKernelGGL((geglu_persistent_kernel<BM, WGM, WGN, NST, LNS, DBG>), dim3(grid), dim3(256), lds, stream, p);
+  static int stagger = -1;                               // anti-phase start of a CU's second block, in ~1 k-cycle units (DF_PG_STAGGER)
+  if (stagger < 0) {
+    const char* e = getenv("DF_PG_STAGGER");
+    stagger = e ? atoi(e) : 0;
+  }
+  GemmParams q = p;
+  q.th = stagger;
+  hipLaunchKernelGGL((geglu_persistent_kernel<BM, WGM, WGN, NST, LNS, DBG>), dim3(grid), dim3(256), lds, stream, q);
   return hipGetLastError();
 }
 

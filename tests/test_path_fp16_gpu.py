@@ -86,6 +86,49 @@ def test_fp16_default_and_saturation_counter(P, tiny):
     assert torch.isfinite(y0).all()
 
 
+def test_fp16_range_guard_on_plain_cuda(P):
+    """The product's own guard (ldm.py:_range_check): load_state_dict + .cuda() runs one saturation-counted probe forward at
+    t = 999 / 1.  Procedural weights: silent.  The scaled-GEGLU state dict of the test above through the PLAIN m.cuda() path:
+    RuntimeWarning naming st.ff1 and the bf16 fallback; the bf16 build has no range to guard and stays silent;
+    DF_RANGE_CHECK=0 switches the probe off."""
+    import os
+    import warnings
+    from diff_foley_amd import synth
+    cfg = P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        m = P.LatentDiffusion(precision="fp16", **cfg)
+        m.load_state_dict(tiny_state_dict())
+        m.cuda()
+        assert m._range_check() == []
+    sd = dict(tiny_state_dict())
+    key = [k for k in sd if k.endswith("input_blocks.2.1.transformer_blocks.0.ff.net.0.proj.weight")]
+    sd[key[0]] = sd[key[0]] * 3.0e4
+    m = P.LatentDiffusion(precision="fp16", **cfg)
+    m.load_state_dict(sd)
+    with pytest.warns(RuntimeWarning, match=r"fp16 operands saturated.*st\.ff1.*precision='bf16'"):
+        m.cuda()
+    with pytest.warns(RuntimeWarning, match="saturated"):      # re-loading weights into a live engine probes again
+        m.load_state_dict(sd)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        mb = P.LatentDiffusion(precision="bf16", **cfg)
+        mb.load_state_dict(sd)
+        mb.cuda()
+        os.environ["DF_RANGE_CHECK"] = "0"
+        try:
+            m2 = P.LatentDiffusion(precision="fp16", **cfg)
+            m2.load_state_dict(sd)
+            m2.cuda()
+        finally:
+            del os.environ["DF_RANGE_CHECK"]
+    # the probe leaves no state behind: the saturation counters are off and a normal forward still runs
+    x = synth.synthetic_xT(2, seed=3).cuda()
+    c = m.get_learned_conditioning(synth.synthetic_cavp(2, 32, 64, seed=1234).cuda())
+    assert torch.isfinite(m.apply_model(x, torch.tensor([500.0, 37.0]).cuda(), c)).all()
+    assert m.engine.debug_saturations_read() == []
+
+
 def test_fp16_tiny_forward_and_samplers(tiny):
     from diff_foley_amd import synth
     g = gold("g3_tiny_unet.npz")
