@@ -21,23 +21,23 @@
 // MFMA: v_mfma_f32_32x32x16_{bf16,f16}; operands HBM/L2 -> LDS by buffer_load ... lds (no VGPR round trip), XOR-swizzled through
 // the source address like gemm_impl.h; counted vmcnt, one raw s_barrier per K step, lgkmcnt(0) in front of it (ring hand-back).
 #include "gemm_impl.h"
-#include <stdlib.h>
 
 namespace {
 
-// BM x 128 tile, 256 threads = 4 wavefronts as WGM x WGN; every wavefront owns 32 rows x (128 / WGN) columns.
+// BM x 128 tile, WGM x WGN wavefronts (4 or 8); every wavefront owns 32 rows x (128 / WGN) columns.  Two resident blocks per CU.
 template <int BM, int WGM, int WGN, int NST, int LNS, bool DBG>
-__global__ __launch_bounds__(256, 2) void geglu_persistent_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void geglu_persistent_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BN = 128, NT = 256, RPP = NT / 8;
+  constexpr int BN = 128, NT = 64 * WGM * WGN, RPP = NT / 8;
   constexpr int WTN = BN / WGN, TN = WTN / 32, NG = TN / 2;     // NG (x | gate) group pairs per wavefront
   constexpr int AP = BM / RPP, BP = BN / RPP, LPT = AP + BP;
   constexpr int STAGE = (BM + BN) * BK * 2;                      // bytes of one ring stage: [A tile | W tile]
-  static_assert(BM == 32 * WGM && TN % 2 == 0 && WGM * WGN == 4, "tile shape");
+  static_assert(BM == 32 * WGM && TN % 2 == 0 && (WGM * WGN == 4 || WGM * WGN == 8) && BM % RPP == 0 && BN % RPP == 0, "tile shape");
+  static_assert(32 * (32 * NG * 2) <= LPT * 1024, "the epilogue's transposition patch fits this wavefront's own request pieces of a stage");
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  float2* sRow = reinterpret_cast<float2*>(smem + NST * STAGE);     // [2][BM] (mean, rstd) of the current / next tile's rows
+  float2* sRow = reinterpret_cast<float2*>(smem + NST * STAGE);     // [2][BM] (rstd, -rstd * mean) of the current / next tile's rows
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WGN, wn = wid % WGN;
@@ -118,15 +118,6 @@ __global__ __launch_bounds__(256, 2) void geglu_persistent_kernel(GemmParams p) 
   for (int s = 0; s < NST - 1; ++s) dma_step();
   __builtin_amdgcn_sched_barrier(0);
   stamp();
-  // ---- anti-phase start (round 5).  The two resident blocks of a CU start within ~20 cycles of each other and walk identical
-  // tile sequences, so they stay in LOCKSTEP: both in the K loop (two wavefronts per SIMD contending for the matrix pipe and the
-  // request issue: ~2 k cycles per K step against ~1 k alone), then both in the epilogue (two wavefronts contending for the VALU:
-  // 6.5 k cycles for ~2.5 k of arithmetic) -- profiles/r4_pgeglu_stamps.txt, blocks 0 / 256.  The second block of every CU
-  // (block b + 256 lands beside block b: dispatch fills one block per CU first) sleeps p.th x ~1 k cycles behind its prologue
-  // requests, so that one block's K loop runs beside the other's epilogue; the symmetry that kept them in phase keeps them apart.
-  if (p.th > 0 && (int)gridDim.x > 256 && bid >= 256)
-    for (int i = 0; i < p.th; ++i) __builtin_amdgcn_s_sleep(16);
-  __builtin_amdgcn_sched_barrier(0);
 
   // LDS fragment byte offsets inside a stage for the 4 k-steps of a tile
   int fA[4], fB[TN][4];
@@ -144,17 +135,24 @@ __global__ __launch_bounds__(256, 2) void geglu_persistent_kernel(GemmParams p) 
 
   // per-tile epilogue operands: LayerNorm row statistics of tile row `tid` (threads < BM) and this lane's column vectors.
   // request(i) issues the loads for tile ordinal i, fold(i) turns them into sRow[i & 1][] / keeps the column vectors.
-  float2 lnv[LNS];
+  // Row statistics: TPR = NT / BM neighbouring lanes share a tile row, lane `sub` takes slots sub, sub + TPR, ... (<= LPS per lane:
+  // 3-5 registers pairs ride through the K loop instead of 10-20) and the lanes' sums meet in a quad exchange.
+  constexpr int TPR = NT / BM, LPS = (LNS + TPR - 1) / TPR;
+  static_assert(TPR == 2 || TPR == 4, "lanes per tile row");
+  const int srow_ = tid / TPR, ssub = tid % TPR;
+  float2 lnv[LPS];
   float ccs[TN], cbb[TN];
   auto request = [&](int i) {
     if (DBG && (p.dbg & 32)) return;
     int m0, n0;
     tile_mn(min(i, mine - 1), m0, n0);
-    if (tid < BM) {
-      const float2* sp = p.ln_stats + (long)min(m0 + tid, p.M - 1) * p.ln_slots;
+    {
+      const float2* sp = p.ln_stats + (long)min(m0 + srow_, p.M - 1) * p.ln_slots;
 #pragma unroll
-      for (int s = 0; s < LNS; ++s)
-        if (s < p.ln_slots) lnv[s] = sp[s];
+      for (int s = 0; s < LPS; ++s) {
+        const int slot = ssub + s * TPR;
+        lnv[s] = slot < p.ln_slots ? sp[slot] : make_float2(0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -166,17 +164,23 @@ __global__ __launch_bounds__(256, 2) void geglu_persistent_kernel(GemmParams p) 
   float ecs[TN], ebb[TN];        // column vectors of the tile being computed (ccs / cbb hold the next tile's)
   auto fold = [&](int i) {
     if (DBG && (p.dbg & 32)) return;
-    if (tid < BM) {
+    {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int s = 0; s < LNS; ++s)
-        if (s < p.ln_slots) {
-          s1 += lnv[s].x;
-          s2 += lnv[s].y;
-        }
+      for (int s = 0; s < LPS; ++s) {
+        s1 += lnv[s].x;
+        s2 += lnv[s].y;
+      }
+      s1 += __shfl_xor(s1, 1);
+      s2 += __shfl_xor(s2, 1);
+      if (TPR == 4) {
+        s1 += __shfl_xor(s1, 2);
+        s2 += __shfl_xor(s2, 2);
+      }
       const float inv = 1.0f / (float)p.ln_C;
       const float mean = s1 * inv;
-      sRow[(i & 1) * BM + tid] = make_float2(mean, rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps));
+      const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + p.ln_eps);
+      if (ssub == 0) sRow[(i & 1) * BM + srow_] = make_float2(rstd, -rstd * mean);     // the epilogue's FMA operands
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -257,29 +261,35 @@ __global__ __launch_bounds__(256, 2) void geglu_persistent_kernel(GemmParams p) 
     stamp();
     // LayerNorm fold:  v = acc * rstd + (b - rstd * mean * cs).  Plain fp32 FMAs: the packed forms (v_pk_fma_f32) measured slower
     // here (5.1 k vs ~3.5 k cycles for this block of arithmetic) -- fp32 VALU work is bound by lanes per clock, not by issue slots
+    // (Two halves of 8 accumulator rows: only 8 rows' (rstd, -rstd * mean) pairs are live at a time -- the 8-wavefront form runs at
+    // 4 wavefronts per SIMD, 128 registers.)
     const float2* sR = sRow + (ti & 1) * BM + wm * 32;
-    float rs[16], rm[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float2 m_ = sR[(r & 3) + 8 * (r >> 2) + 4 * lh];
-      rs[r] = m_.y;
-      rm[r] = -m_.y * m_.x;
-    }
     uint32_t o32[NG][8];           // outputs of accumulator rows (2q, 2q+1) as operand-type pairs
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float o[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int r = 2 * q + h;
-          const float xv = acc[2 * g][r] * rs[r] + (rm[r] * xcs[2 * g] + xbb[2 * g]);
-          const float gv = acc[2 * g + 1][r] * rs[r] + (rm[r] * xcs[2 * g + 1] + xbb[2 * g + 1]);
-          o[h] = (DBG && (p.dbg & 4)) ? xv + gv : xv * gelu_erf(gv);
-        }
-        o32[g][q] = pack_bf2(o[0], o[1]);
-      }
+#define PG_HALF(H)                                                                                \
+    {                                                                                           \
+      float rs[8], rm[8];                                                                       \
+      _Pragma("unroll") for (int r8 = 0; r8 < 8; ++r8) {                                        \
+        const int r = 8 * (H) + r8;                                                             \
+        const float2 m_ = sR[(r & 3) + 8 * (r >> 2) + 4 * lh];                                  \
+        rs[r8] = m_.x;                                                                          \
+        rm[r8] = m_.y;                                                                          \
+      }                                                                                         \
+      _Pragma("unroll") for (int g = 0; g < NG; ++g)                                            \
+        _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                      \
+          float o[2];                                                                           \
+          _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                       \
+            const int r8 = 2 * q4 + h, r = 8 * (H) + r8;                                        \
+            const float xv = acc[2 * g][r] * rs[r8] + (rm[r8] * xcs[2 * g] + xbb[2 * g]);       \
+            const float gv = acc[2 * g + 1][r] * rs[r8] + (rm[r8] * xcs[2 * g + 1] + xbb[2 * g + 1]); \
+            o[h] = (DBG && (p.dbg & 4)) ? xv + gv : xv * gelu_erf(gv);                          \
+          }                                                                                     \
+          o32[g][4 * (H) + q4] = pack_bf2(o[0], o[1]);                                          \
+        }                                                                                       \
+    }
+    PG_HALF(0)
+    __builtin_amdgcn_sched_barrier(0);
+    PG_HALF(1)
+#undef PG_HALF
     stamp();
     // ---- stores.  The 32 x (32 NG) output patch of this wavefront is transposed through LDS so that it leaves as 16-byte stores of
     // whole rows (2-byte stores straight out of the accumulator layout cost ~130 cycles each, 4 k cycles per tile: tools/
@@ -333,21 +343,14 @@ hipError_t launch_pgeglu(const GemmParams& p, hipStream_t stream) {
   }
   const int nblk = ((p.M + BM - 1) / BM) * (p.N / 128);
   const int grid = std::min(nblk, 512);                  // 2 resident blocks on each of the 256 CUs
-  static int stagger = -1;                               // anti-phase start of a CU's second block, in ~1 k-cycle units (DF_PG_STAGGER)
-  if (stagger < 0) {
-    const char* e = getenv("DF_PG_STAGGER");
-    stagger = e ? atoi(e) : 0;
-  }
-  GemmParams q = p;
-  q.th = stagger;
-  hipLaunchKernelGGL((geglu_persistent_kernel<BM, WGM, WGN, NST, LNS, DBG>), dim3(grid), dim3(256), lds, stream, q);
+  hipLaunchKernelGGL((geglu_persistent_kernel<BM, WGM, WGN, NST, LNS, DBG>), dim3(grid), dim3(64 * WGM * WGN), lds, stream, p);
   return hipGetLastError();
 }
 
 }  // namespace
 
 bool pgeglu_valid(const GemmParams& p, int tile, int batch, int splitk) {
-  if (tile == TILE_PGEGLU_128 && p.ln_slots > 10) return false;     // its row-statistics registers hold 10 slots (C <= 640)
+  if ((tile == TILE_PGEGLU_128 || tile == TILE_PGEGLU_128_W8) && p.ln_slots > 10) return false;     // their row-statistics registers hold 10 slots (C <= 640)
   return p.geglu && p.ln_stats && p.ln_cs && p.bias && splitk <= 1 && batch <= 1 && p.taps == 1 && p.out_bf16 && !p.res &&
          !p.rowbias && !p.aux && !p.stats && !p.vt && p.w_rows == 0 && p.Cin2 == 0 && p.dup_rows == 0 && p.sm_w == 0 &&
          !p.relu && !p.silu && !p.store_nchw && p.alpha == 1.f && (p.N % 128) == 0 && (p.K % 64) == 0 && p.K >= 128 &&
@@ -358,6 +361,8 @@ hipError_t launch_gemm_pgeglu(int tile_cfg, const GemmParams& p, hipStream_t str
   switch (tile_cfg) {
     case TILE_PGEGLU_128: return p.dbg ? launch_pgeglu<128, 4, 1, 2, 10, true>(p, stream) : launch_pgeglu<128, 4, 1, 2, 10, false>(p, stream);
     case TILE_PGEGLU_64: return p.dbg ? launch_pgeglu<64, 2, 2, 3, 20, true>(p, stream) : launch_pgeglu<64, 2, 2, 3, 20, false>(p, stream);
+    case TILE_PGEGLU_128_W8: return p.dbg ? launch_pgeglu<128, 4, 2, 2, 10, true>(p, stream) : launch_pgeglu<128, 4, 2, 2, 10, false>(p, stream);
+    case TILE_PGEGLU_128_W8L: return p.dbg ? launch_pgeglu<128, 4, 2, 2, 20, true>(p, stream) : launch_pgeglu<128, 4, 2, 2, 20, false>(p, stream);
     default: return hipErrorInvalidValue;
   }
 }

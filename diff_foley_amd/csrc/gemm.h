@@ -96,14 +96,19 @@ enum GemmTile {
   TILE_HALO_PS_192x64 = 23, TILE_HALO_PS_128x64 = 24, TILE_HALO_PS_128x128 = 25,
   // producer-specialised small generic tiles (the transformer's K = 320 .. 1280 projections: 160 blocks on 256 CUs, one block per
   // CU, no second block to overlap with): 4 + 4 and 4 + 8 wavefronts
-  TILE_PS_64x64 = 26, TILE_PS2_64x64 = 27, TILE_PS_128x64 = 28, TILE_PS_64x128 = 29, TILE_ALL = 30
+  TILE_PS_64x64 = 26, TILE_PS2_64x64 = 27, TILE_PS_128x64 = 28, TILE_PS_64x128 = 29,
+  // persistent GEGLU projection with EIGHT wavefronts per block (4 x 2, each 32 rows x 64 columns; round 5): a wavefront issues
+  // in order -- its LDS-DMA requests (~130 cycles each), its MFMAs and its GELU arithmetic are one serial stream (1.8 k cycles per
+  // K step for 512 of MFMA, 6.5 k of epilogue arithmetic per tile in the 4-wavefront form, whatever the co-resident block does:
+  // the DF_PG_STAGGER experiment).  Twice the wavefronts halve every one of those streams.  31: 20 row-statistics slots (C = 1280)
+  TILE_PGEGLU_128_W8 = 30, TILE_PGEGLU_128_W8L = 31, TILE_ALL = 32
 };
-static inline bool gemm_tile_is_pgeglu(int cfg) { return cfg == TILE_PGEGLU_128 || cfg == TILE_PGEGLU_64; }
+static inline bool gemm_tile_is_pgeglu(int cfg) { return cfg == TILE_PGEGLU_128 || cfg == TILE_PGEGLU_64 || cfg == TILE_PGEGLU_128_W8 || cfg == TILE_PGEGLU_128_W8L; }
 static inline bool gemm_tile_is_ps(int cfg) { return (cfg >= TILE_PS_256x128 && cfg <= TILE_PS2_128x128) || (cfg >= TILE_PS_64x64 && cfg <= TILE_PS_64x128); }
 // ring depths (activation ring, weight ring) of the generic tiles; 0 for halo tiles
 static inline void gemm_tile_rings(int cfg, int* nsta, int* nstb) {
-  static const int a[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3, 0, 0, 0, 4, 4, 4, 4};
-  static const int b[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3, 0, 0, 0, 4, 4, 4, 4};
+  static const int a[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3, 0, 0, 0, 4, 4, 4, 4, 2, 2};
+  static const int b[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3, 0, 0, 0, 4, 4, 4, 4, 2, 2};
   *nsta = a[cfg];
   *nstb = b[cfg];
 }
@@ -125,7 +130,7 @@ static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
                                      {128, 64},  {256, 64}, {128, 128}, {128, 256}, {256, 128},
                                      {128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
                                      {128, 64}, {256, 64}, {192, 64}, {256, 128}, {128, 128}, {128, 128}, {128, 128}, {64, 128},
-                                     {192, 64}, {128, 64}, {128, 128}, {64, 64}, {64, 64}, {128, 64}, {64, 128}};
+                                     {192, 64}, {128, 64}, {128, 128}, {64, 64}, {64, 64}, {128, 64}, {64, 128}, {128, 128}, {128, 128}};
   *bm = d[cfg][0];
   *bn = d[cfg][1];
 }

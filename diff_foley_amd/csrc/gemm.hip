@@ -133,7 +133,7 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int nk = p.K / 64;
   if (p.taps == 4) {     // phase-decomposed upsample conv (MODE 3): a subset of the generic tiles, plain epilogues only
     static const bool ok3[TILE_ALL] = {false, false, false, true, false, false, false, false, true, true, true, true, true, true, false, false, false, false,
-                                       false, false, false, false, false, false, false, false, false, false, false, false};     // (no producer-specialised MODE 3 instantiation)
+                                       false, false, false, false, false, false, false, false, false, false, false, false, false, false};     // (no producer-specialised MODE 3 instantiation)
     if (tile < 0 || tile >= TILE_ALL || !ok3[tile] || batch > 1) return false;
     if (p.geglu || p.vt || p.ln_stats || p.stats || p.w_rows > 0 || p.sm_w > 0 || p.Cin2 > 0 || p.res || p.store_nchw) return false;
     if (splitk > 1 && (p.N & 3) != 0) return false;
@@ -166,7 +166,9 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   if (splitk > 1 && (p.N & 3) != 0) return false;
   if (p.dup_rows > 0 && (p.store_nchw || (p.N & 3) != 0 || (p.ldc & 3) != 0 || (p.ldr & 3) != 0 || (p.ld_rowbias & 3) != 0 || (p.ld_aux & 3) != 0))
     return false;
-  if (p.Cin2 > 0) return false;                 // the folded skip connection exists in the generic stride-1 kernel only (a halo-kernel tail was measured slower: DESIGN.md section 7)
+  // the folded skip connection: generic stride-1 kernel, and (round 5) a one-tap K tail of the producer-specialised halo tiles
+  const bool halo_ps = tile >= TILE_HALO_PS_192x64 && tile <= TILE_HALO_PS_128x128;
+  if (p.Cin2 > 0 && (!halo_ps || (p.Cin2 & 63) != 0 || !p.A2 || (p.lda2 & 7) != 0)) return false;
   if (p.taps != 9 || p.stride != 1 || p.ups != 0 || p.geglu || batch > 1) return false;
   int bm, bn, th, tw;
   gemm_tile_dims(tile, &bm, &bn);
@@ -175,6 +177,7 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
   const int hr = (bm / (th * tw)) * (th + 2) * (tw + 2);
   const int apass = (hr + rpp - 1) / rpp, wpass = (bn + rpp - 1) / rpp;
   if (apass > 12) return false;
+  if (p.Cin2 > 0 && 3 * bm > 2 * apass * rpp) return false;      // the tail's three activation slots live in the two halo buffers
   const int nstw = gemm_halo_ring(tile);   // weight ring depth (4; 8 for the weight-streaming variants)
   if (((size_t)2 * apass * rpp + (size_t)nstw * wpass * rpp) * 128 + (size_t)std::max(bm, hr) * 4 > 160 * 1024) return false;
   if ((p.lda & 7) != 0) return false;           // the halo-row table keeps a 3-bit key in the low bits of a pixel's byte offset

@@ -1170,7 +1170,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int WPASS = (BN + RPP - 1) / RPP; // weight passes per tap
+  constexpr int A2P = BM / RPP;               // passes of one folded-skip tail slice (BM centre pixels)
   static_assert(NSTW >= 3 && NSTW <= 8, "weight ring depth");
+  static_assert(PS == 0 || (BM % RPP == 0 && A2P <= 8), "tail slice passes");
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -1221,9 +1223,27 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel
     c1 = min(nchunk, c0 + per);
   }
   const int nc = max(c1 - c0, 0);
+  // ResBlock skip connection folded into conv2 (openai_unetmodel.py:234-241, 275: skip(x) + h): a TAIL of n2 one-tap K steps after
+  // the nine-tap slices, reading 64-channel slices [s0, s0 + n2) of the second tensor at the centre pixel (producer-specialised
+  // tiles only, round 5).  With split-K the skip slices are dealt to the splits that own conv slices, in the same order.
+  int s0 = 0, n2 = 0;
+  if (PS != 0 && p.Cin2 > 0) {
+    const int n2tot = p.Cin2 / BK;
+    if (p.splitk > 1) {
+      const int per = (nchunk + p.splitk - 1) / p.splitk, used = (nchunk + per - 1) / per;
+      const int per2 = (n2tot + used - 1) / used;
+      s0 = z * per2;
+      n2 = (z < used) ? max(min(n2tot, s0 + per2) - s0, 0) : 0;
+    } else {
+      n2 = n2tot;
+    }
+  }
+  const int nc9 = nc * 9;
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(PS != 0 && p.A2 ? p.A2 : p.A), 0,
+                                                                          (int)(PS != 0 && p.A2 ? p.a2_bytes : 0u), 0x00020000);
 
   // ---- staging coordinates.  Thread (r0 = tid>>3, slot = tid&7) fills LDS slot `slot` of rows r0 + RPP*i with the
   // source chunk slot ^ ((row>>1)&7)   (RPP is a multiple of 16, so the swizzle term is the same for every pass).
@@ -1293,8 +1313,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel
   {                                                                                             \
     bf16_t* w_ = sW + (ST) * WROWS * BK + wid * (8 * BK);                                       \
     const int cs_ = (IT) / 9, tp_ = (IT) - cs_ * 9;                                             \
-    const bool live = cs_ < nc;                                                                 \
-    const unsigned kb = (unsigned)(tp_ * p.Cin + (c0 + cs_) * BK) * 2u;                         \
+    const bool live = (IT) < nc9 + n2;          /* (IT) >= nc9: weight tile of step (IT) - nc9 of the folded-skip tail */ \
+    const unsigned kb = (IT) < nc9 ? (unsigned)(tp_ * p.Cin + (c0 + cs_) * BK) * 2u             \
+                                   : (unsigned)(9 * p.Cin + (s0 + (IT) - nc9) * BK) * 2u;      \
     _Pragma("unroll") for (int i = 0; i < WPASS; ++i)                                           \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(w_ + i * RPP * BK), 16,           \
                                                (live && w_off[i] != OOB) ? w_off[i] + kb : OOB, 0, 0, 0); \
@@ -1376,9 +1397,36 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel
       // 2 * WPASS + a(T - 1) + a(T) younger requests are outstanding; the wait in front of the next slice's tap 0 allows the two
       // youngest weight tiles only, which covers the whole halo (a(8) = 0 and a(7) sits in front of tap 7's weight request).
       static_assert(NSTW == 4, "the spread halo schedule counts on weights requested 3 taps ahead");
-      int acnt[10];
+      int acnt[10], acnt2[10];
 #pragma unroll
-      for (int t = 0; t < 10; ++t) acnt[t] = (t >= 1 && t <= 8) ? (APASS > t - 1) + (APASS > t + 7) : 0;      // acnt[T + 1] = a(T)
+      for (int t = 0; t < 10; ++t) {
+        acnt[t] = (t >= 1 && t <= 8) ? (APASS > t - 1) + (APASS > t + 7) : 0;      // acnt[T + 1] = a(T)
+        acnt2[t] = (t >= 1 && t <= 8) ? (A2P > t - 1) : 0;                         // the same for the first tail slice (A2P <= 8 passes)
+      }
+      // Folded-skip tail (round 5).  Tail step j multiplies the BM centre pixels of slice s0 + j of the second tensor (LDS rows =
+      // tile rows, 128 B each, swizzled like the generic kernel's A tiles) with weight tile nc9 + j of the ring.  The tail's
+      // activation slots are three BM-row windows of the two halo buffers (3 BM <= 2 HRP, checked by the launcher); slot 0 lies
+      // inside the buffer that is FREE during the last nine-tap slice and is requested in that slice's spread schedule in place
+      // of the (dead) next halo; slots 1 / 2 reach into the buffer the last slice reads and are requested by tail step 0, after
+      // its barrier.  From then on step j requests slice j + 2 into the slot step j - 1 read; the wait in front of step j + 1
+      // allows slice j + 2 and the two youngest weight tiles.
+      unsigned a2_off[A2P];
+#pragma unroll
+      for (int i = 0; i < A2P; ++i) {
+        const int px = rowmap_calc(r0 + RPP * i);
+        a2_off[i] = (n2 > 0 && px < p.M) ? (unsigned)(((long)px * p.lda2 + c8) * 2) : OOB;
+      }
+      const int tfree = nc & 1;                // halo buffer that is free during the last nine-tap slice
+      auto tslot = [&](int k) { return (tfree == 0 ? k * BM : 2 * HRP - (k + 1) * BM) * (BK * 2); };   // byte offset of tail slot k in sA
+#define DF_TAIL_A(J, SLOT)                                                                        \
+  {                                                                                             \
+    char* a_ = reinterpret_cast<char*>(sA) + tslot(SLOT) + wid * (8 * BK * 2);                  \
+    const bool live = (J) < n2;                                                                 \
+    const unsigned cb = (unsigned)(s0 + (J)) * (BK * 2);                                        \
+    _Pragma("unroll") for (int i = 0; i < A2P; ++i)                                             \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a_ + i * RPP * BK * 2), 16,      \
+                                               (live && a2_off[i] != OOB) ? a2_off[i] + cb : OOB, 0, 0, 0); \
+  }
 #define DF_HALO_A_PART(C, BUF, T)                                                                 \
   {                                                                                             \
     bf16_t* a_ = sA + (BUF) * HRP * BK + wid * (8 * BK);                                        \
@@ -1392,15 +1440,43 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel
 #define DF_PTAP(T)                                                                                \
   {                                                                                             \
     const int it_ = cs * 9 + (T);                                                               \
-    DF_HALO_A_PART(c0 + cs + 1, (cs + 1) & 1, T);                                               \
+    if (tail0) {              /* pass T of the first tail slice into tail slot 0 */              \
+      if ((T) < A2P) {                                                                          \
+        char* a_ = reinterpret_cast<char*>(sA) + tslot(0) + wid * (8 * BK * 2);                 \
+        const unsigned o_ = a2_off[(T) < A2P ? (T) : 0];                                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(a_ + (T) * RPP * BK * 2), 16,  \
+                                                 o_ != OOB ? o_ + (unsigned)s0 * (BK * 2) : OOB, 0, 0, 0); \
+      }                                                                                         \
+    } else {                                                                                    \
+      DF_HALO_A_PART(c0 + cs + 1, (cs + 1) & 1, T);                                             \
+    }                                                                                           \
     DF_HALO_W(it_ + NSTW - 1, (it_ + NSTW - 1) % NSTW);                                         \
     if ((T) == 8) wait_vmcnt<(NSTW - 2) * WPASS>();                                             \
-    else wait_vmcnt_dyn((NSTW - 2) * WPASS + acnt[(T)] + acnt[(T) + 1]);                        \
+    else wait_vmcnt_dyn((NSTW - 2) * WPASS + (tail0 ? acnt2[(T)] + acnt2[(T) + 1] : acnt[(T)] + acnt[(T) + 1])); \
     __builtin_amdgcn_s_barrier();                                                               \
   }
       for (int cs = 0; cs < nc; ++cs) {
+        const bool tail0 = n2 > 0 && cs == nc - 1;
         DF_PTAP(0) DF_PTAP(1) DF_PTAP(2) DF_PTAP(3) DF_PTAP(4) DF_PTAP(5) DF_PTAP(6) DF_PTAP(7) DF_PTAP(8)
       }
+      if (n2 > 0) {
+        // tail step 0: slices 1 and 2 (their slots were under the last nine-tap slice until its last barrier) + weight tile nc9 + 3;
+        // step 1 needs slice 1: slice 2 and that weight tile may still be in flight
+        DF_TAIL_A(1, 1);
+        DF_TAIL_A(2, 2);
+        DF_HALO_W(nc9 + NSTW - 1, (nc9 + NSTW - 1) % NSTW);
+        wait_vmcnt<A2P + WPASS>();
+        __builtin_amdgcn_s_barrier();
+        int ts = 0;                            // slot of slice j + 2 = (j + 2) % 3
+        for (int j = 1; j < n2; ++j) {
+          DF_TAIL_A(j + 2, ts);
+          DF_HALO_W(nc9 + j + NSTW - 1, (nc9 + j + NSTW - 1) % NSTW);
+          wait_vmcnt<(NSTW - 2) * WPASS + A2P>();
+          __builtin_amdgcn_s_barrier();
+          ts = (ts == 2) ? 0 : ts + 1;
+        }
+      }
+#undef DF_TAIL_A
 #undef DF_PTAP
 #undef DF_HALO_A_PART
       wait_vmcnt<0>();
@@ -1502,6 +1578,42 @@ __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel
     DF_TAP(8)
     stamp();
   }
+  if constexpr (PS != 0) {
+    // folded-skip tail (see the producer's side): one K step per 64-channel slice of the second tensor, centre pixels only
+    if (n2 > 0) {
+      const int tfree = nc & 1;
+      const int sat = (l31 >> 1) & 7;
+      int ts = 0;
+      for (int j = 0; j < n2; ++j) {
+        const char* a = reinterpret_cast<const char*>(sA) + (tfree == 0 ? ts * BM : 2 * HRP - (ts + 1) * BM) * (BK * 2) +
+                        (wm * WTM + l31) * (BK * 2);
+        const bf16_t* b = sW + ((nc9 + j) % NSTW) * WROWS * BK;
+#define DF_TAIL_READ(DA, DB, S)                                                                   \
+  {                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+      DA[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * (BK * 2) + (((2 * (S) + lh) ^ sat) << 4)); \
+    _Pragma("unroll") for (int jj = 0; jj < TN; ++jj)                                           \
+      DB[jj] = *reinterpret_cast<const bf16x8*>(b + fb[jj] + (((2 * (S) + lh) ^ sb[jj]) << 3)); \
+  }
+        bf16x8 af0[TM], bf0[TN], af1[TM], bf1[TN], af2[TM], bf2[TN];
+        DF_TAIL_READ(af0, bf0, 0);
+        DF_TAIL_READ(af1, bf1, 1);
+        DF_TAIL_READ(af2, bf2, 2);
+        DF_HALO_MMA(af0, bf0);
+        DF_TAIL_READ(af0, bf0, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        DF_HALO_MMA(af1, bf1);
+        DF_HALO_MMA(af2, bf2);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        DF_HALO_MMA(af0, bf0);
+#undef DF_TAIL_READ
+        ts = (ts == 2) ? 0 : ts + 1;
+      }
+      stamp();
+    }
+  }
   if constexpr (PS == 0) wait_vmcnt<0>();
   stamp();
 
@@ -1563,6 +1675,7 @@ hipError_t launch_halo(const GemmParams& pin, int zdim, hipStream_t stream) {
   const int PB = BM / ppx, HR = PB * (p.th + 2) * (p.tw + 2);
   const int APASS = (HR + RPP - 1) / RPP;
   if (APASS > 12) return hipErrorInvalidValue;
+  if (p.Cin2 > 0 && (PS == 0 || 3 * BM > 2 * APASS * RPP || (p.Cin2 % BK) != 0 || !p.A2)) return hipErrorInvalidValue;   // folded-skip tail
   constexpr int WPASS = (BN + RPP - 1) / RPP;
   const size_t ring = ((size_t)2 * APASS * RPP + (size_t)NSTW * WPASS * RPP) * BK * 2;
   const size_t lds = ring + (size_t)std::max(BM, HR) * 4;          // + the prologue's halo-row table / the epilogue's row table

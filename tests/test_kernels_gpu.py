@@ -161,10 +161,12 @@ def test_conv3x3(tile, NB, H, W, Cin, Cout, stride, ups, splitk):
     assert rel_l2(got, ref) < 2e-3
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 17, 18, 19, 20, 26, 27, 28, 29])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 17, 18, 19, 20, 23, 24, 25, 26, 27, 28, 29])
 @pytest.mark.parametrize("NB,H,W,Cin,Cin2,Cout,splitk", [
     (2, 16, 64, 128, 192, 96, 1), (2, 16, 64, 64, 128, 320, 2), (4, 8, 32, 128, 64, 128, 1), (8, 4, 16, 128, 320, 192, 2),
-    (8, 2, 8, 256, 128, 64, 4), (3, 4, 16, 64, 64, 64, 1)])
+    (8, 2, 8, 256, 128, 64, 4), (3, 4, 16, 64, 64, 64, 1),
+    # long one-tap tails of the producer-specialised halo tiles (23-25): 10 / 15 skip slices, three-slot ring wraps several times
+    (2, 16, 64, 128, 640, 128, 1), (8, 16, 64, 320, 960, 320, 1), (8, 4, 16, 1280, 2560, 256, 6)])
 def test_conv3x3_with_folded_skip(tile, NB, H, W, Cin, Cin2, Cout, splitk):
     """ResBlock conv2 with a channel change: conv3x3(h) + conv1x1(x) + bias as ONE implicit GEMM over K = 9 Cin + Cin2
     (openai_unetmodel.py:255-275: skip_connection(x) + h): the 1x1 is a tenth K range of the generic stride-1 kernel."""
@@ -349,6 +351,9 @@ def _ln_chain_ref(A0, W0, b0, res, gamma, beta, W1, b1, mode):
     # 21 / 22: the persistent GEGLU kernel (ffn.hip); valid for mode 1 only -- several tiles per block, ragged last row tile
     (8192, 320, 1024, 3, 1, 21, 1), (2048, 640, 256, 3, 1, 21, 1), (512, 1280, 64, 3, 1, 22, 1), (1024, 320, 256, 13, 1, 22, 1),
     (192, 128, 64, 0, 1, 21, 1), (4096, 640, 256, 3, 1, 22, 1),
+    # 30 / 31: the same kernel with 8 wavefronts per block (10 / 20 row-statistics slots)
+    (8192, 320, 1024, 3, 1, 30, 1), (2048, 640, 256, 3, 1, 30, 1), (512, 1280, 64, 3, 1, 31, 1), (192, 128, 64, 0, 1, 30, 1),
+    (1024, 320, 256, 13, 1, 31, 1),
     # 18-20: producer-specialised blocks as producer (PROD epilogue) and as LayerNorm-folded consumer (LNC / GEGLU / V^T epilogues)
     (1024, 320, 256, 18, 1, 19, 1), (512, 1280, 64, 19, 1, 18, 1), (2048, 640, 256, 20, 2, 20, 1), (256, 640, 64, 19, 1, 19, 2),
     (1024, 320, 256, 26, 1, 27, 1), (512, 1280, 64, 27, 1, 28, 1), (2048, 640, 256, 28, 2, 29, 1), (256, 640, 64, 29, 1, 26, 2)])
@@ -360,8 +365,8 @@ def test_ln_folded_gemm_chain(mode, M, C, T, tile0, sk0, tile1, sk1):
         pytest.skip("split-K consumers exist only for the plain LN-folded projection")
     N1 = {0: C, 1: 8 * C if C <= 320 else 2 * C, 2: 3 * C}[mode]
     bn = {0: 128, 1: 64, 2: 128, 3: 64, 4: 128, 8: 256, 9: 128, 10: 128, 11: 64, 12: 128, 13: 64, 14: 128, 18: 128, 19: 128, 20: 128, 26: 64, 27: 64, 28: 64, 29: 128,
-          21: 128, 22: 128}
-    if tile1 in (21, 22) and mode != 1:
+          21: 128, 22: 128, 30: 128, 31: 128}
+    if tile1 in (21, 22, 30, 31) and mode != 1:
         pytest.skip("the persistent kernel is the GEGLU projection only")
     if mode == 2 and (2 * C) % bn[tile1] != 0:
         tile1 = 3                                   # the transposed-V columns must start on a tile boundary

@@ -23,6 +23,13 @@ SHAPES = [
     ("conv 1280->1280 @4x16", "conv", 8, 4, 16, 1280, 1280),
     ("conv 2560->1280 @2x8", "conv", 8, 2, 8, 2560, 1280),
     ("conv 1280->1280 @2x8", "conv", 8, 2, 8, 1280, 1280),
+    # conv2 of the output-side ResBlocks with the 1x1 skip folded in as extra K: (name, 'skip', NB, H, W, Cin, Cout, Cin2)
+    ("skip 320+960->320 @16x64", "skip", 8, 16, 64, 320, 320, 960),
+    ("skip 320+640->320 @16x64", "skip", 8, 16, 64, 320, 320, 640),
+    ("skip 640+1920->640 @8x32", "skip", 8, 8, 32, 640, 640, 1920),
+    ("skip 640+960->640 @8x32", "skip", 8, 8, 32, 640, 640, 960),
+    ("skip 1280+2560->1280 @4x16", "skip", 8, 4, 16, 1280, 1280, 2560),
+    ("skip 1280+2560->1280 @2x8", "skip", 8, 2, 8, 1280, 1280, 2560),
     ("lin ff1 8192x2560x320", "lin", 8192, 2560, 320),
     ("lin ff2 8192x320x1280", "lin", 8192, 320, 1280),
     ("lin proj 8192x320x320", "lin", 8192, 320, 320),
@@ -65,6 +72,16 @@ def main():
             flops = 2.0 * NB * H * W * Cout * 9 * Cin
             nk = 9 * Cin // 64
             call = lambda t, sk: L.df_test_conv3x3(ptr(a), ptr(w), ptr(b), ptr(c), NB, H, W, Cin, Cout, 1, 0, t, sk, st)
+        elif sh[1] == "skip":
+            _, _, NB, H, W, Cin, Cout, Cin2 = sh
+            a = torch.randn(NB * H * W, Cin, device="cuda").to(torch.bfloat16)
+            a2 = torch.randn(NB * H * W, Cin2, device="cuda").to(torch.bfloat16)
+            w = (torch.randn(Cout, 9 * Cin + Cin2, device="cuda") * 0.02).to(torch.bfloat16)
+            b = torch.zeros(Cout, device="cuda")
+            c = torch.empty(NB * H * W, Cout, device="cuda")
+            flops = 2.0 * NB * H * W * Cout * (9 * Cin + Cin2)
+            nk = (9 * Cin + Cin2) // 64
+            call = lambda t, sk: L.df_test_conv3x3_skip(ptr(a), ptr(a2), ptr(w), ptr(b), ptr(c), NB, H, W, Cin, Cin2, Cout, t, sk, st)
         else:
             _, _, M, N, K = sh
             a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
@@ -75,7 +92,7 @@ def main():
             call = lambda t, sk: L.df_test_gemm(ptr(a), ptr(w), ptr(c), M, N, K, t, sk, st)
         res = []
         for t in TILES:
-            if t in HALO and sh[1] != "conv":
+            if t in HALO and sh[1] not in ("conv", "skip"):
                 continue
             for sk in (1, 2, 3, 4, 6, 8, 12, 16, 32):
                 if sk > 1 and (nk // sk < 4 or (t in HALO and sh[5] // 64 // sk < 1)):

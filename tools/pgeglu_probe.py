@@ -15,8 +15,10 @@ from gemm_bench import ptr, TILES
 L = E.lib()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 TILES = dict(TILES)
-TILES.update({21: "P128", 22: "P64"})
-tiles = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 9, 10, 11, 12, 13, 21, 22]
+TILES.update({21: "P128", 22: "P64", 30: "P128w8", 31: "P128w8L"})
+PG = (21, 22, 30, 31)
+SWITCHES = [0, 8, 6, 15, 31, 47, 63] if len(sys.argv) > 2 else [0]      # second argument: also the debug switches
+tiles = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 9, 10, 11, 12, 13, 18, 21, 22, 30, 31]
 for (M, K) in ((8192, 320), (2048, 640), (512, 1280)):
     N1 = 8 * K
     nbuf = max(2, (600 << 20) // (N1 * K * 2))
@@ -28,7 +30,7 @@ for (M, K) in ((8192, 320), (2048, 640), (512, 1280)):
     out = torch.empty(M, N1 // 2, device="cuda", dtype=torch.float16)
     line = []
     for t in tiles:
-        for dbg in ([0] if t < 21 else [0, 8, 6, 15, 31, 47, 63]):
+        for dbg in ([0] if t not in PG else SWITCHES):
             call = lambda i: L.df_test_geglu(ptr(a), ptr(ws[i % nbuf]), ptr(stats), ptr(cs), ptr(bias), ptr(out), M, K, N1, t, dbg, st)
             if call(0) != 0:
                 continue
