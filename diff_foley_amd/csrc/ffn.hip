@@ -26,7 +26,17 @@ namespace {
 
 // BM x 128 tile, WGM x WGN wavefronts (4 or 8); every wavefront owns 32 rows x (128 / WGN) columns.  Two resident blocks per CU.
 template <int BM, int WGM, int WGN, int NST, int LNS, bool DBG>
+__device__ __forceinline__ void geglu_persistent_body(const GemmParams& p);
+template <int BM, int WGM, int WGN, int NST, int LNS, bool DBG>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void geglu_persistent_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int ka = gemm_kernarg_touch();
+  geglu_persistent_body<BM, WGM, WGN, NST, LNS, DBG>(p);
+  gemm_kernarg_touch_end(ka);
+#endif
+}
+template <int BM, int WGM, int WGN, int NST, int LNS, bool DBG>
+__device__ __forceinline__ void geglu_persistent_body(const GemmParams& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BN = 128, NT = 64 * WGM * WGN, RPP = NT / 8;
   constexpr int WTN = BN / WGN, TN = WTN / 32, NG = TN / 2;     // NG (x | gate) group pairs per wavefront

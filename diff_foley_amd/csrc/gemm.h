@@ -71,6 +71,44 @@ struct GemmParams {
   int defer_reduce;   // split-K only: write the partial slabs and do NOT launch the reduce -- the consumer (GroupNorm) sums them
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Kernel-argument lines touched through the VECTOR memory path at kernel entry (round 5).  GemmParams arrives by value in the
+// kernarg segment (6 lines of 64 B, new memory at every launch, so the scalar cache and L2 miss on each); the compiler s_loads a
+// field where it is first used, and a block's prologue is a chain of scalar round trips, one per new line.  Scalar loads cannot be
+// issued ahead without being waited for (they return out of order: every use waits for all of them -- fetching the whole struct in
+// one batch measured +0.5 us per op in the plan, experiments/kernarg_batched_fetch_and_prologue_split.patch.txt).  One vector load,
+// lane i reading a dword of line i, brings all six lines into L2 side by side; nothing waits for it (its value is consumed by an
+// empty asm at the end of the kernel: gemm_kernarg_touch_end), and the later scalar loads of the chain become L2 hits.
+__device__ __forceinline__ int gemm_kernarg_touch() {
+#if defined(DF_NO_KERNARG_TOUCH)
+  return 0;
+#else
+  // (inline asm: a C++ load would be waited for where the compiler next needs its register -- or, volatile, at once)
+  const int lane = (int)threadIdx.x;
+  const unsigned long ka = reinterpret_cast<unsigned long>(__builtin_amdgcn_kernarg_segment_ptr()) + (unsigned long)lane * 64u;
+  int v = 0;
+  if (lane < (int)((sizeof(GemmParams) + 63) / 64)) asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ka) : "memory");
+#if defined(DF_CODE_TOUCH)
+  // the same for the kernel's own code: the next DF_CODE_TOUCH x 4 KB of instructions behind the program counter (the instruction
+  // cache is cold at every kernel boundary and fetches line by line)
+  if (lane < 64) {
+    unsigned long pc;
+    asm volatile("s_getpc_b64 %0" : "=s"(pc));
+    int w;
+#pragma unroll
+    for (int k = 0; k < DF_CODE_TOUCH; ++k) {
+      const unsigned long a = pc + (unsigned long)(k * 64 + lane) * 64u;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(w) : "v"(a) : "memory");
+      v ^= 0;      // (w is never read: its register is only ever rewritten by the next touch; the final wait covers them)
+    }
+  }
+#endif
+  return v;
+#endif
+}
+__device__ __forceinline__ void gemm_kernarg_touch_end(int v) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(v) : "memory"); }      // (long since landed)
+#endif
+
 enum GemmTile {
   TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x128 = 2, TILE_64x64 = 3, TILE_32x128 = 4, TILE_COUNT = 5,   // generic
   // conv3x3 stride-1 kernels with an LDS-staged halo tile (BM output pixels = patches of th x tw, BN couts)

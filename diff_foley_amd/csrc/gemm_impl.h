@@ -577,9 +577,19 @@ __device__ __forceinline__ void tile_of(int lid, int nbm, int nbn, int gm, int& 
 // deliver ~31 B/clk (tools/gemm_bench.py: 128 x 128 tile, 1030 cycles per K step against 512 of MFMA).
 // After the K loop the first WGM x WGN producers join the consumers in the epilogue's store loops (2 * NT threads); further
 // producers only keep the epilogue's barriers company.
+template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI, int NSTB, int PS>
+__device__ __forceinline__ void gemm_bf16_body(const GemmParams& p);
 template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI, int NSTB = NST, int PS = 0>
 __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void gemm_bf16_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // host pass only needs the launch stub (LDS-DMA builtins do not parse there)
+  const int ka = gemm_kernarg_touch();      // the kernel-argument lines into L2, beside the first scalar loads (gemm.h)
+  gemm_bf16_body<BM, BN, WGM, WGN, NST, MODE, EPI, NSTB, PS>(p);
+  gemm_kernarg_touch_end(ka);
+#endif
+}
+template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI, int NSTB, int PS>
+__device__ __forceinline__ void gemm_bf16_body(const GemmParams& p) {
+#if defined(__HIP_DEVICE_COMPILE__)
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int NT = 64 * WGM * WGN;          // threads (4 or 8 wavefronts); PS: the CONSUMER threads
@@ -1161,8 +1171,18 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 // Zero padding and ragged edges come from out-of-bounds buffer offsets (hardware writes zeros to LDS).
 // PS > 0: producer-specialised block (see gemm_bf16_kernel): PS producer wavefronts per consumer wavefront issue every halo and
 // weight request in the symmetric kernel's order (so the counted waits are the same); consumers read fragments and run MFMAs.
+template <int BM, int BN, int WGM, int WGN, int NSTW, int EPI, int PS>
+__device__ __forceinline__ void conv3x3_halo_body(const GemmParams& p);
 template <int BM, int BN, int WGM, int WGN, int NSTW, int EPI, int PS = 0>
 __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int ka = gemm_kernarg_touch();
+  conv3x3_halo_body<BM, BN, WGM, WGN, NSTW, EPI, PS>(p);
+  gemm_kernarg_touch_end(ka);
+#endif
+}
+template <int BM, int BN, int WGM, int WGN, int NSTW, int EPI, int PS>
+__device__ __forceinline__ void conv3x3_halo_body(const GemmParams& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NT = 64 * WGM * WGN;          // threads (PS: the consumer threads)
   constexpr int NTP = PS ? NT * PS : NT;      // threads that issue the DMA requests
