@@ -58,6 +58,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 // 8-B (operand type) store.  Summation order s = 0..SK-1 is fixed, so results are deterministic.
 template <int SK>
 __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int ka = gemm_kernarg_touch();      // kernel-argument lines (and the code behind the pc) into L2 beside the first scalar loads
+#endif
   const int n4 = p.N >> 2;
   const long total = (long)p.M * n4;
   const long slab = (long)p.M * p.N;
@@ -126,6 +129,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
       if (p.aux) st_wt(reinterpret_cast<uint2*>(p.aux + orow * p.ld_aux + col), make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)));
     }
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  gemm_kernarg_touch_end(ka);
+#endif
 }
 
 }  // namespace
