@@ -238,7 +238,7 @@ def run_mode(precision, sd_dev, a, dev, rank, world, lo, hi, barrier, dump_ops="
             bus = torch.cuda.get_device_properties(dev).pci_bus_id
         except Exception:
             bus = None
-        seen = dict(rccl_world_seen=torch.distributed.get_world_size(), backend=torch.distributed.get_backend(),
+        seen = dict(rccl_world_seen=torch.distributed.get_world_size(), pg_backend=torch.distributed.get_backend(),
                     cuda_device=torch.cuda.current_device(), pci_bus_id=bus, gpu_name=torch.cuda.get_device_name(dev))
         torch.distributed.all_gather_object(infos, dict(rank=rank, **seen, **{k: (round(v, 4) if isinstance(v, float) else v)
                                                                              for k, v in (dist_info or {}).items()}))

@@ -63,6 +63,56 @@ __device__ __forceinline__ void st_wt(float* p, float v) { asm volatile("global_
 template <class T> __device__ __forceinline__ void st_wt(T* p, const T& v) { *p = v; }
 #endif
 
+// ---- Kernel-entry touch (round 5): kernel-argument lines and the kernel's own code through the VECTOR memory path.
+// A kernel's arguments live in the kernarg segment -- new memory at every launch, so the scalar cache and L2 miss on every 64-B
+// line of it -- and the compiler s_loads a field where it is first used: the prologue of a kernel with a large argument block
+// (GemmParams: 6 lines) is a CHAIN of scalar round trips, one per new line (six `s_load ...; s_waitcnt lgkmcnt(0)` groups in front
+// of the first operand request of a GEMM block).  Scalar loads cannot be issued ahead without being waited for (they return out
+// of order: every use waits for all of them -- fetching the whole struct in one batch measured +0.5 us per op IN THE PLAN although
+// it is 1 k cycles faster warm, experiments/kernarg_batched_fetch_and_prologue_split.patch.txt).  One vector load, lane i reading a
+// dword of line i, brings all lines into L2 side by side; nothing waits for it (its register stays reserved until
+// df_entry_touch_end at the end of the kernel), and the later scalar loads of the chain become L2 hits: +1.8 % end to end for the
+// GEMM kernels alone (same box, 270.7 -> 275.7 steps/s).
+// The same for the kernel's own CODE: the next DF_CODE_TOUCH x 4 KB of instructions behind the program counter (the instruction
+// cache is cold at every kernel boundary and fetches line by line; +0.4 %).  Never past the code object: df_code_object_tail is a
+// zero-initialised variable of THIS translation unit's code object, i.e. it lives in .bss, the last section of the loaded image
+// (tools/check_code_touch.py verifies that layout for every built code object) -- lanes at or beyond it stay off.
+#if !defined(DF_CODE_TOUCH)
+#define DF_CODE_TOUCH 4
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ char df_code_object_tail[64];
+__device__ __forceinline__ int df_entry_touch(int kernarg_bytes) {
+  int v = 0;
+#if !defined(DF_NO_KERNARG_TOUCH)
+  // (inline asm: a C++ load would be waited for where the compiler next needs its register -- or, volatile, at once.  "+v": every
+  // touch lands in the ONE register that stays reserved until the final wait.)
+  const int lane = (int)threadIdx.x;
+  const unsigned long ka = reinterpret_cast<unsigned long>(__builtin_amdgcn_kernarg_segment_ptr()) + (unsigned long)lane * 64u;
+  if (lane < (kernarg_bytes + 63) / 64) asm volatile("global_load_dword %0, %1, off" : "+v"(v) : "v"(ka) : "memory");
+#if DF_CODE_TOUCH > 0
+  {
+    unsigned long pc;
+    asm volatile("s_getpc_b64 %0" : "=s"(pc));
+    const long room = (long)(reinterpret_cast<unsigned long>(&df_code_object_tail[0]) - pc);      // bytes of this image behind the pc
+    const int avail = room > (long)(DF_CODE_TOUCH * 4096) ? DF_CODE_TOUCH * 4096 : (int)room;
+#pragma unroll
+    for (int k = 0; k < DF_CODE_TOUCH; ++k) {
+      const int off = (k * 64 + lane) * 64;
+      const unsigned long a = pc + (unsigned long)off;
+      if (lane < 64 && off + 64 <= avail) asm volatile("global_load_dword %0, %1, off" : "+v"(v) : "v"(a) : "memory");
+    }
+  }
+#endif
+#endif
+  return v;
+}
+__device__ __forceinline__ void df_entry_touch_end(int v) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(v) : "memory"); }      // (long since landed)
+#else     // host pass: the kernels' bodies are parsed, never run
+__device__ __forceinline__ int df_entry_touch(int) { return 0; }
+__device__ __forceinline__ void df_entry_touch_end(int) {}
+#endif
+
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   const f32x2 f = {op_clamp(lo), op_clamp(hi)};
   const op_x2 v = __builtin_convertvector(f, op_x2);

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "common.h"
 
 struct GemmParams {
   // operands
@@ -72,49 +73,9 @@ struct GemmParams {
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// Kernel-argument lines touched through the VECTOR memory path at kernel entry (round 5).  GemmParams arrives by value in the
-// kernarg segment (6 lines of 64 B, new memory at every launch, so the scalar cache and L2 miss on each); the compiler s_loads a
-// field where it is first used, and a block's prologue is a chain of scalar round trips, one per new line.  Scalar loads cannot be
-// issued ahead without being waited for (they return out of order: every use waits for all of them -- fetching the whole struct in
-// one batch measured +0.5 us per op in the plan, experiments/kernarg_batched_fetch_and_prologue_split.patch.txt).  One vector load,
-// lane i reading a dword of line i, brings all six lines into L2 side by side; nothing waits for it (its value is consumed by an
-// empty asm at the end of the kernel: gemm_kernarg_touch_end), and the later scalar loads of the chain become L2 hits.
-#if !defined(DF_CODE_TOUCH)
-#define DF_CODE_TOUCH 4
-#endif
-static __device__ char df_code_object_tail[64];
-__device__ __forceinline__ int gemm_kernarg_touch() {
-#if defined(DF_NO_KERNARG_TOUCH)
-  return 0;
-#else
-  // (inline asm: a C++ load would be waited for where the compiler next needs its register -- or, volatile, at once)
-  const int lane = (int)threadIdx.x;
-  const unsigned long ka = reinterpret_cast<unsigned long>(__builtin_amdgcn_kernarg_segment_ptr()) + (unsigned long)lane * 64u;
-  int v = 0;
-  if (lane < (int)((sizeof(GemmParams) + 63) / 64)) asm volatile("global_load_dword %0, %1, off" : "+v"(v) : "v"(ka) : "memory");
-#if DF_CODE_TOUCH > 0
-  // The same for the kernel's own CODE: the next DF_CODE_TOUCH x 4 KB of instructions behind the program counter.  The instruction
-  // cache is cold at every kernel boundary and fetches line by line from beyond L2; one vector load per 4 KB brings 64 lines in
-  // side by side (same-box A/B in the plan: 275.9 -> 279.0 steps/s with 8 KB).  Never past the code object: df_code_object_tail is a
-  // zero-initialised variable of THIS translation unit's code object, i.e. it lives in .bss, the last section of the loaded image
-  // (tools/check_code_touch.py verifies that layout for every built code object) -- lanes at or beyond it stay off.
-  {
-    unsigned long pc;
-    asm volatile("s_getpc_b64 %0" : "=s"(pc));
-    const long room = (long)(reinterpret_cast<unsigned long>(&df_code_object_tail[0]) - pc);      // bytes of this image behind the pc
-    const int avail = room > (long)(DF_CODE_TOUCH * 4096) ? DF_CODE_TOUCH * 4096 : (int)room;
-#pragma unroll
-    for (int k = 0; k < DF_CODE_TOUCH; ++k) {      // "+v": every touch lands in the ONE register that stays reserved until the final wait
-      const int off = (k * 64 + lane) * 64;
-      const unsigned long a = pc + (unsigned long)off;
-      if (lane < 64 && off + 64 <= avail) asm volatile("global_load_dword %0, %1, off" : "+v"(v) : "v"(a) : "memory");
-    }
-  }
-#endif
-  return v;
-#endif
-}
-__device__ __forceinline__ void gemm_kernarg_touch_end(int v) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(v) : "memory"); }      // (long since landed)
+// kernel-argument / own-code touch of the GEMM kernels: common.h df_entry_touch
+__device__ __forceinline__ int gemm_kernarg_touch() { return df_entry_touch((int)sizeof(GemmParams)); }
+__device__ __forceinline__ void gemm_kernarg_touch_end(int v) { df_entry_touch_end(v); }
 #endif
 
 enum GemmTile {

@@ -31,7 +31,7 @@ def test_bench_gpus2_launches_its_own_ranks():
     assert [p["rank"] for p in per_rank] == [0, 1]
     # every rank reports the world it saw on its backend and the device it ran on (bench.py run_mode)
     for p in per_rank:
-        assert p["rccl_world_seen"] == 2 and p["backend"] in ("nccl", "gloo") and p["cuda_device"] == 0 and p["pci_bus_id"]
+        assert p["rccl_world_seen"] == 2 and p["pg_backend"] in ("nccl", "gloo") and p["cuda_device"] == 0 and p["pci_bus_id"]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_2rank_shared_gpu.json"), "w") as f:
         f.write(lines[0] + "\n")
