@@ -14,15 +14,23 @@
 // and the A fragment is two 8-byte LDS reads of V^T (keys 16c+4h..+3 and 16c+8+4h..+3).
 // Softmax statistics (running max m, running sum l) are fp32; one __shfl_xor(32) joins the two
 // half-waves that share a query.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int KT = 32;          // keys per tile
-constexpr int VROW = 36;        // V^T LDS row stride in bf16 (72 B: conflict-free ds_read_b64, 8-B aligned)
+// KS = 32-key sub-tiles per loop iteration (round 5).  With KS = 1 a wavefront's iteration is ONE dependent chain -- K fragment read,
+// 3-10 MFMAs into one accumulator, a 16-deep max chain, exponentials, a sum chain, the P V MFMAs, one block barrier -- ~2.2 k cycles
+// for 7 MFMAs at D = 40 with two wavefronts per SIMD to hide it (34 us for the 1024-token self-attention, MFMA pipe busy 21 %).
+// KS = 2 walks 64 keys per iteration as two INDEPENDENT sub-tiles (two score accumulators, two max / sum chains that meet once),
+// one barrier and one staging round per 64 keys.  Used when Tk is a multiple of 64 and the two 64-key buffers fit (D <= 80).
+template <int KS> struct AttnGeo {
+  static constexpr int KT = 32 * KS;            // keys per iteration
+  static constexpr int VROW = KT + 4;           // V^T LDS row stride in bf16 (72 B / 136 B: conflict-free ds_read_b64, 8-B aligned)
+};
 
-template <int D, int NW>
+template <int D, int NW, int KS = 1>
 __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __restrict__ Q, int ldq,
                                                             const bf16_t* __restrict__ K, int ldk,
                                                             const bf16_t* __restrict__ Vt, int ldvt, int heads, int Tq,
@@ -33,6 +41,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
   constexpr int DKP = DKC * 16;           // padded head dim
   constexpr int DT = (D + 31) / 32;       // 32-row tiles of O^T
   constexpr int KROW = DKP + 8;           // K LDS row stride (bf16): +16 B pad de-conflicts ds_read_b128
+  constexpr int KT = AttnGeo<KS>::KT, VROW = AttnGeo<KS>::VROW;
   __shared__ __attribute__((aligned(16))) bf16_t sK[2 * KT * KROW];
   __shared__ __attribute__((aligned(16))) bf16_t sV[2 * DT * 32 * VROW];
 
@@ -74,7 +83,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
   // select) so they stay in flight together.  Thread t owns chunk slots t + i*NT.
   constexpr int NT = NW * 64;
   constexpr int KCH = (KT * (DKP / 8) + NT - 1) / NT;      // 16-B K chunks per thread
-  constexpr int VCH = (DT * 32 * 8 + NT - 1) / NT;         // 8-B V^T chunks per thread
+  constexpr int VCR = KT / 4;                              // 8-B chunks (4 keys) per V^T row
+  constexpr int VCH = (DT * 32 * VCR + NT - 1) / NT;       // 8-B V^T chunks per thread
   uint4 kreg[KCH];
   uint2 vreg[VCH];
   // Raw buffer loads: the per-thread byte offset is fixed (computed once), the tile advances through the scalar
@@ -97,8 +107,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
 #pragma unroll
   for (int i = 0; i < VCH; ++i) {
     const int c = tid + i * NT;
-    const int d = c >> 3, ch = c & 7;
-    const bool ok = (c < DT * 32 * 8) && (d < D);
+    const int d = c / VCR, ch = c - d * VCR;
+    const bool ok = (c < DT * 32 * VCR) && (d < D);
     v_off[i] = ok ? (unsigned)((d * ldvt + ch * 4) * 2) : OOB;
   }
   auto gfetch = [&](int k0) {
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
     if (k0 + KT > Tk) {   // ragged last tile only (e.g. 33 context tokens): the row padding may hold stale bits
 #pragma unroll
       for (int i = 0; i < VCH; ++i) {
-        const int ch = (tid + i * NT) & 7;
+        const int ch = (tid + i * NT) % VCR;
         const int nvalid = Tk - (k0 + ch * 4);   // keys of this 4-key chunk that exist
         uint2 v = vreg[i];
         if (nvalid < 4) {
@@ -140,8 +150,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
 #pragma unroll
     for (int i = 0; i < VCH; ++i) {
       const int c = tid + i * NT;
-      const int d = c >> 3, ch = c & 7;
-      if (c < DT * 32 * 8) *reinterpret_cast<uint2*>(&v_[d * VROW + ch * 4]) = vreg[i];
+      const int d = c / VCR, ch = c - d * VCR;
+      if (c < DT * 32 * VCR) *reinterpret_cast<uint2*>(&v_[d * VROW + ch * 4]) = vreg[i];
     }
   };
 
@@ -156,39 +166,59 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
     const bf16_t* cV = sV + buf * (DT * 32 * VROW);
     if (kt + 1 < ntiles) gfetch(k0 + KT);
 
-    // ---- S^T = K Q^T
-    f32x16 s;
+    // ---- S^T = K Q^T, KS independent 32-key sub-tiles
+    f32x16 s[KS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int u = 0; u < KS; ++u)
 #pragma unroll
-    for (int c = 0; c < DKC; ++c) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&cK[l31 * KROW + 16 * c + 8 * lh]);
-      s = DF_MFMA_32x32x16(kf, qf[c], s);
-    }
-    // ---- online softmax over this lane's 16 keys (+ partner half-wave)
+      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < DKC; ++c)
+#pragma unroll
+      for (int u = 0; u < KS; ++u) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&cK[(u * 32 + l31) * KROW + 16 * c + 8 * lh]);
+        s[u] = DF_MFMA_32x32x16(kf, qf[c], s[u]);
+      }
+    // ---- online softmax over this lane's 16 KS keys (+ partner half-wave)
     // The softmax scale (x log2 e) is applied inside the exponent's FMA: the maximum is taken over the RAW scores (the scale
     // is positive) and scaled once, p = exp2(fma(s, scale, -m)) -- 16 multiplies per tile fewer than scaling every score.
-    float mx = -INFINITY;
     if (k0 + KT > Tk) {          // ragged last tile only: mask keys that do not exist
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        s[r] = (key < Tk) ? s[r] : -INFINITY;
-      }
-    }
+      for (int u = 0; u < KS; ++u)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          s[u][r] = (key < Tk) ? s[u][r] : -INFINITY;
+        }
+    }
+    float mxu[KS];
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      mxu[u] = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mxu[u] = fmaxf(mxu[u], s[u][r]);
+    }
+    float mx = mxu[0];
+#pragma unroll
+    for (int u = 1; u < KS; ++u) mx = fmaxf(mx, mxu[u]);
     mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;
     const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 valid key
-    float ps = 0.f;
-    uint32_t pk[8];
+    float psu[KS];
+    uint32_t pk[KS][8];
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2e, -m_new)),
-                  p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r + 1], scale_log2e, -m_new));
-      ps += p0 + p1;
-      pk[r >> 1] = pack_bf2_bounded(p0, p1);      // p in [0, 1]
+    for (int u = 0; u < KS; ++u) {
+      psu[u] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], scale_log2e, -m_new)),
+                    p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r + 1], scale_log2e, -m_new));
+        psu[u] += p0 + p1;
+        pk[u][r >> 1] = pack_bf2_bounded(p0, p1);      // p in [0, 1]
+      }
     }
+    float ps = psu[0];
+#pragma unroll
+    for (int u = 1; u < KS; ++u) ps += psu[u];
     if (__any(m_new != m_run)) {                   // wave-uniform: rescale only when some row's running max moved
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
       l_run *= alpha;
@@ -201,19 +231,21 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
     l_run += ps;
     // ---- O^T += V^T P^T
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      uint4 pv = make_uint4(pk[4 * c], pk[4 * c + 1], pk[4 * c + 2], pk[4 * c + 3]);
-      const bf16x8 pf = *reinterpret_cast<bf16x8*>(&pv);
+    for (int u = 0; u < KS; ++u)
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        const bf16_t* vr = &cV[(t * 32 + l31) * VROW + 16 * c + 4 * lh];
-        const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
-        const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
-        uint4 vv = make_uint4(v0.x, v0.y, v1.x, v1.y);
-        const bf16x8 vf = *reinterpret_cast<bf16x8*>(&vv);
-        o[t] = DF_MFMA_32x32x16(vf, pf, o[t]);
+      for (int c = 0; c < 2; ++c) {
+        uint4 pv = make_uint4(pk[u][4 * c], pk[u][4 * c + 1], pk[u][4 * c + 2], pk[u][4 * c + 3]);
+        const bf16x8 pf = *reinterpret_cast<bf16x8*>(&pv);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          const bf16_t* vr = &cV[(t * 32 + l31) * VROW + u * 32 + 16 * c + 4 * lh];
+          const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
+          const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
+          uint4 vv = make_uint4(v0.x, v0.y, v1.x, v1.y);
+          const bf16x8 vf = *reinterpret_cast<bf16x8*>(&vv);
+          o[t] = DF_MFMA_32x32x16(vf, pf, o[t]);
+        }
       }
-    }
     if (kt + 1 < ntiles) sstore(buf ^ 1);   // the other buffer was last read in iteration kt-1
     __syncthreads();
   }
@@ -242,6 +274,14 @@ template <int D>
 hipError_t launch_d(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt,
                     uint16_t* O, int ldo, int N, int heads, int Tq, int Tk, float scale, hipStream_t s) {
   const float sl2 = scale * 1.4426950408889634f;
+  if constexpr (D <= 80) {        // two 64-key buffers of K and V^T fit beside each other (<= 35 KB)
+    static const bool no_ks2 = getenv("DF_ATTN_KS1") != nullptr;      // tools: A/B
+    if (Tq >= 128 && Tk % 64 == 0 && !no_ks2) {
+      dim3 grid((Tq + 127) / 128, heads, N);
+      hipLaunchKernelGGL((attention_kernel<D, 4, 2>), grid, dim3(256), 0, s, Q, ldq, K, ldk, Vt, ldvt, heads, Tq, Tk, sl2, O, ldo);
+      return hipGetLastError();
+    }
+  }
   if (Tq >= 128) {
     dim3 grid((Tq + 127) / 128, heads, N);
     hipLaunchKernelGGL((attention_kernel<D, 4>), grid, dim3(256), 0, s, Q, ldq, K, ldk, Vt, ldvt, heads, Tq, Tk, sl2,
