@@ -225,6 +225,7 @@ class LatentDiffusion:
         finally:
             eng.debug_saturations(False)
             self._ctx_owner = None
+            eng.finalize()        # drops the probe's (untuned) plans: a later autotune(True) must meet no ready-made plan of this shape
         if bad:
             shown = ", ".join(f"{lab}: {n}" for lab, n in bad[:6]) + (" ..." if len(bad) > 6 else "")
             warnings.warn(
