@@ -178,6 +178,7 @@ struct df_ctx {
   std::map<std::string, uint64_t> plan_tick;     // last use of every plan (least-recently-used eviction, DF_MAX_PLANS)
   uint64_t tick = 0;
   Plan* last_unet = nullptr;
+  bool last_unet_hoisted = false;   // the last UNet run looked its time embedding up (df_unet_forward*_ts)
   int ctx_N = 0, ctx_T = 0;
   float* ctx_copy = nullptr;
   size_t ctx_copy_bytes = 0;
@@ -2947,6 +2948,7 @@ static void unet_run(df_ctx* c, const float* x, const float* t, float* out, int 
     run_ops(c, p, nctx, p->ops.size(), s, a);
   }
   c->last_unet = p;
+  c->last_unet_hoisted = ts_index >= 0;
 }
 
 // Time embedding of every step of a sample() call, once, before the loop (it depends on t only; the reference
@@ -2975,16 +2977,21 @@ static void unet_set_timesteps(df_ctx* c, const float* t_host, int S, int N, int
     HIPCHK(hipMalloc((void**)&p->ttab, (size_t)S * p->t_rows * 4));
     p->etab_cap = S;
   }
-  std::vector<float> tt((size_t)S * p->t_rows);
-  for (int i = 0; i < S; ++i)
-    for (int r = 0; r < p->t_rows; ++r) tt[(size_t)i * p->t_rows + r] = t_host[i];
+  std::vector<float> tt((size_t)S * p->t_rows);      // S timesteps, then padding (the last timestep repeated) for the last run
+  for (size_t i = 0; i < tt.size(); ++i) tt[i] = t_host[std::min<size_t>(i, (size_t)S - 1)];
   HIPCHK(hipMemcpyAsync(p->ttab, tt.data(), tt.size() * 4, hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));       // tt leaves scope
   p->etab_S = 0;
-  for (int i = 0; i < S; ++i) {
-    a.t = p->ttab + (size_t)i * p->t_rows;
+  // The time ops map t_rows timesteps to t_rows rows of E, row by row (the embedding kernel and the three GEMMs are row-independent;
+  // with CFG the second half of E repeats the first): one run of them serves t_rows DIFFERENT timesteps, so the table takes
+  // ceil(S / t_rows) runs, not S (round 5: 7 instead of 25 for B = 4 -- the 52 MB of emb-projection weights are streamed 7 times per
+  // sample() call instead of 25).  Row r of a run is bit-identical to the in-step form's row for that timestep.
+  const int tr = std::max(p->t_rows, 1);
+  for (int i = 0; i < S; i += tr) {
+    const int nrow = std::min(tr, S - i);
+    a.t = p->ttab + (size_t)i;          // ttab, read as S consecutive timesteps (the tail of the last run reads into the padding)
     run_ops(c, p, (size_t)p->op_t0, (size_t)p->op_tl, s, a);
-    HIPCHK(hipMemcpyAsync(p->Etab + (size_t)i * p->etot, p->E, (size_t)p->etot * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(p->Etab + (size_t)i * p->etot, p->E, (size_t)nrow * p->etot * 4, hipMemcpyDeviceToDevice, s));
   }
   p->etab_S = S;
 }
@@ -3327,7 +3334,12 @@ int df_unet_plan_stats(df_ctx* c, int64_t* n_launches, double* gemm_flops, doubl
     if (!c->last_unet) fail("no UNet plan has been executed yet");
     const size_t nctx = c->last_unet->n_ctx;
     int64_t n = 0;
-    for (size_t i = nctx; i < c->last_unet->ops.size(); ++i) n += 1 + (c->last_unet->ops[i].is_gemm && c->last_unet->ops[i].gp.splitk > 1);
+    for (size_t i = nctx; i < c->last_unet->ops.size(); ++i) {
+      const Plan* lp = c->last_unet;
+      // the last run took either the time ops [op_t0, op_tl) or the table look-up op_tl, never both
+      if (lp->op_tl >= 0 && (c->last_unet_hoisted ? ((long)i >= lp->op_t0 && (long)i < lp->op_tl) : (long)i == lp->op_tl)) continue;
+      n += 1 + (lp->ops[i].is_gemm && lp->ops[i].gp.splitk > 1 && !lp->ops[i].defer);      // (a deferred reduce runs inside the GroupNorm that follows)
+    }
     *n_launches = n;
     *gemm_flops = c->last_unet->gemm_flops;
     *weight_bytes = c->last_unet->weight_bytes;

@@ -98,8 +98,11 @@ class _Guided:
         self.hoisted = False
         if timesteps is not None and size is not None and not _NO_HOIST:
             B, _, H, W = size
-            self.eng.set_timesteps([float(v) for v in timesteps], B, H, W, self.cfg)
-            self.hoisted = True
+            try:      # an optimisation, never a requirement: a UNet configuration without a hoistable time embedding
+                self.eng.set_timesteps([float(v) for v in timesteps], B, H, W, self.cfg)      # keeps the in-step t path
+                self.hoisted = True
+            except RuntimeError:
+                self.hoisted = False
 
     def reclaim_context(self):
         """A caller-supplied callback (score_corrector) may have evaluated the model itself -- ``model.apply_model`` and the
@@ -110,9 +113,17 @@ class _Guided:
 
     def __call__(self, x, t, k=None):
         k = k if self.hoisted else None
-        if self.cfg:
-            return self.eng.unet_forward_cfg(x, t, self.scale, ts_index=k)
-        return self.eng.unet_forward(x, t, ts_index=k)
+        fwd = (lambda kk: self.eng.unet_forward_cfg(x, t, self.scale, ts_index=kk)) if self.cfg else \
+              (lambda kk: self.eng.unet_forward(x, t, ts_index=kk))
+        if k is None:
+            return fwd(None)
+        try:
+            return fwd(k)
+        except RuntimeError:
+            # the plan that owned the timestep table was rebuilt in the middle of the sample (plan-cache eviction, a callback that
+            # re-finalised the engine): the in-step path computes the same embedding from t, bit-identically
+            self.hoisted = False
+            return fwd(None)
 
 
 def _classifier_grad(model, classifier, x, t, origin_cond):

@@ -242,6 +242,15 @@ def test_score_corrector_callback(P, tiny):
     eps = lambda x, t, cc: tiny.engine.unet_forward_cfg(x.cuda(), t.cuda().float(), 4.5).cpu()
     zo, _ = osamp.ddim_sample(lambda x, t, cc: 0.75 * eps(x, t, cc), osch.ddpm_schedule()["alphas_cumprod"], 6, xT, c.cpu())
     assert rel_l2(z2.cpu(), zo) < 5e-3        # (a wrong factor -- 0.5 or 1.0 for 0.75 -- is an O(1) difference)
+    # ... and one check that does NOT share the engine's eps: the oracle's fp32 UNet (oracle/unet.py) through the oracle's CFG loop,
+    # its eps scaled by the same 0.75 (the guidance combination is linear in eps, so scaling the model's output scales the guided
+    # eps).  Tolerance: TRAJ_TOL, what this tiny bf16 model's 6-step trajectories are held to against the reference's goldens.
+    usd, vsd, csd, _ = _oracle_tiny()
+    from oracle import unet as ou, vae as ov
+    c_ref = ov.cond_stage(csd, synth.synthetic_cavp(B, 32, 64, seed=1234))
+    zi, _ = osamp.ddim_sample(lambda x, t, cc: 0.75 * ou.unet_forward(usd, synth.UNET_TINY, x, t, cc),
+                              osch.ddpm_schedule()["alphas_cumprod"], 6, xT, c_ref, scale=4.5, uc=torch.zeros_like(c_ref))
+    assert rel_l2(z2.cpu(), zi) < TRAJ_TOL
 
     # a corrector that calls the model: apply_model and the module facades put THEIR context into the engine (B rows, another
     # conditioning); the next step's CFG forward needs the sampler's 2B-row context back
