@@ -183,6 +183,28 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   for (int i = 0; i < nw; ++i) t += red[i];
   return t;
 }
+// Wave total without the LDS pipe: the four in-row DPP steps, then row_bcast:15 (row r's lane 15 into row r + 1, rows 1 and 3) and
+// row_bcast:31 (lane 31 into rows 2 and 3) leave the total in lane 63; v_readlane hands it to every lane through an SGPR.  (The
+// __shfl_xor(16 / 32) steps of wave_sum_dpp are ds_bpermute round trips, ~100 cycles each on a latency chain.)
+__device__ __forceinline__ float wave_sum_dpp_bcast(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// block_sum_dpp on a `red` array that nobody has read yet (first use in the kernel, or a second array): no leading barrier.
+__device__ __forceinline__ float block_sum_dpp_fresh(float v, float* red) {
+  v = wave_sum_dpp_bcast(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
 // The same with the in-wave steps as DPP adds (wave_sum_dpp): 2 LDS-pipe exchanges per wavefront instead of 6.
 __device__ __forceinline__ float block_sum_dpp(float v, float* red) {
   v = wave_sum_dpp(v);

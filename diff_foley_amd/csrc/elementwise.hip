@@ -43,7 +43,7 @@ __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW
                                      bf16_t* __restrict__ out, int ldo, int silu, int C,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                      bf16_t* __restrict__ raw, GnSlabs sl) {
-  __shared__ float red[16];
+  __shared__ float red[16], red2[16];      // one array per reduction: neither needs a barrier in front of its first (only) use
   // block b runs on XCD b%8.  Samples in multiples of 8 (the UNet's CFG batch): ALL groups of a sample on one XCD (b = g * nsamp +
   // n), so every 128-B line of the sample's rows is read into, and written back from, exactly one L2.  Otherwise: the 4
   // neighbouring groups that share lines on one XCD (b = n * 32 + (XCD-major group index)).
@@ -125,7 +125,7 @@ __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW
   for (int k = 0; k < PER; ++k)
     if (act && ty + k * R < HW) s += v[k].x + v[k].y;
   const float cnt = (float)HW * (float)cpg;
-  const float mean = block_sum_dpp(s, red) / cnt;
+  const float mean = block_sum_dpp_fresh(s, red) / cnt;
   float q = 0.f;
 #pragma unroll
   for (int k = 0; k < PER; ++k)
@@ -133,7 +133,7 @@ __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW
       const float a = v[k].x - mean, b = v[k].y - mean;
       q += a * a + b * b;
     }
-  const float rstd = rsqrtf(block_sum_dpp(q, red) / cnt + eps);
+  const float rstd = rsqrtf(block_sum_dpp_fresh(q, red2) / cnt + eps);
   const float sc0 = rstd * gamma[c], sc1 = rstd * gamma[c + 1], sh0 = beta[c], sh1 = beta[c + 1];
   bf16_t* ob = out + row0 * ldo + c;
   bf16_t* rb = raw ? raw + row0 * ldo + c : nullptr;
