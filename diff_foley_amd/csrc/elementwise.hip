@@ -553,6 +553,30 @@ __global__ void pack_latent_kernel(const float* __restrict__ x, bf16_t* __restri
   for (int c = C; c < cpad; ++c) o[c] = 0;
 }
 
+// The two launches a hoisted denoise step starts with, as one (round 5): blocks [0, npack) pack the latent (pack_latent_kernel without
+// the post-quant matrix), the blocks behind them broadcast row `src` of the timestep table to the `rows` rows of E (bcast_rows_kernel).
+// Both are independent elementwise jobs; a launch costs ~4.5 us whatever it does.
+__global__ void pack_latent_bcast_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B, int C, int HW, int cpad,
+                                         int rep, int npack, const float4* __restrict__ src, float4* __restrict__ dst, int rows,
+                                         int n4) {
+  if ((int)blockIdx.x < npack) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)rep * B * HW;
+    if (i >= total) return;
+    const int px = (int)(i % HW);
+    const int b = (int)((i / HW) % B);
+    bf16_t* o = out + i * cpad;
+    for (int c = 0; c < C; ++c) o[c] = f2bf(x[((long)b * C + c) * HW + px] * 1.0f);
+    for (int c = C; c < cpad; ++c) o[c] = 0;
+    return;
+  }
+  const int nb = (int)gridDim.x - npack;
+  for (int i = ((int)blockIdx.x - npack) * blockDim.x + threadIdx.x; i < n4; i += nb * blockDim.x) {
+    const float4 v = src[i];
+    for (int r = 0; r < rows; ++r) dst[(long)r * n4 + i] = v;
+  }
+}
+
 __global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     out[i] = f2bf(x[i]);
@@ -891,6 +915,16 @@ hipError_t launch_pack_latent(const float* x, uint16_t* out, int B, int C, int H
   const long n = (long)rep * B * HW;
   hipLaunchKernelGGL(pack_latent_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, x, out, B, C, HW, cpad, rep,
                      in_scale, wpq, bpq);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_latent_bcast(const float* x, uint16_t* out, int B, int C, int HW, int cpad, int rep, const float* src,
+                                    float* dst, int rows, int n, hipStream_t s) {
+  if (C > 8 || n <= 0 || (n & 3) != 0 || rows <= 0) return hipErrorInvalidValue;
+  const long np = (long)rep * B * HW;
+  const int npack = (int)((np + 255) / 256), nb = grid_for(n / 4);
+  hipLaunchKernelGGL(pack_latent_bcast_kernel, dim3(npack + nb), dim3(256), 0, s, x, out, B, C, HW, cpad, rep, npack,
+                     (const float4*)src, (float4*)dst, rows, n / 4);
   return hipGetLastError();
 }
 

@@ -74,6 +74,7 @@ struct Op {
   GemmParams gp{};
   int tile = 0, batch = 1;
   bool c_ext = false;            // gp.C <- RunArgs.out at run time
+  bool cfg_ext = false;          // split-K only: the reduce launch also does the CFG combine into RunArgs.out (GemmParams::cfg_out)
   bool defer = false;            // when tuned to split-K: leave the partial slabs to the next op (a GroupNorm that sums them)
   std::function<hipError_t(hipStream_t, const RunArgs&)> fn;
   const char* tag = "";
@@ -1373,6 +1374,9 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
     }
     pl->weight_bytes += 2.0 * etot * temb + 2.0 * (temb * mc + temb * temb);
   }
+  // (round 5) a hoisted step's two leading launches -- the table look-up and the latent packing -- are one launch
+  static const bool no_step_merge = getenv("DF_NO_STEP_MERGE") && atoi(getenv("DF_NO_STEP_MERGE"));
+  const bool step_merge = !no_step_merge && !which && etot % 4 == 0;
   if (!which && etot % 4 == 0) {
     // the table look-up that replaces the ops above when the caller announced its timesteps (df_unet_set_timesteps): the time
     // embedding depends on t only, so a sampler computes it for all S steps before the loop, like the context operands
@@ -1382,6 +1386,7 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
     b.other("t.lookup", [=](hipStream_t s, const RunArgs& a) {
       if (a.ts_index < 0) return hipSuccess;
       if (!plp->Etab || a.ts_index >= plp->etab_S) return hipErrorInvalidValue;
+      if (step_merge) return hipSuccess;       // the row broadcast rides in x.pack's launch (below)
       return launch_bcast_rows(plp->Etab + (size_t)a.ts_index * etot, E, N, etot, s);
     });
   }
@@ -1399,9 +1404,16 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
                      pxs.count(topo.input[1][1].prefix) > 0 && !(getenv("DF_NO_FFPROJ") && atoi(getenv("DF_NO_FFPROJ")));
   const int Np = dedup ? N / 2 : N;              // samples the prefix ops run on
   bf16_t* xin = b.buf<bf16_t>((size_t)Np * HW * 64);
-  b.other("x.pack", [=](hipStream_t s, const RunArgs& a) {
-    return launch_pack_latent(a.x, xin, B_ext, cin, HW, 64, (cfg_mode && !dedup) ? 2 : 1, 1.0f, nullptr, nullptr, s);
-  });
+  {
+    Plan* plp = pl;
+    float* Eb = E;
+    b.other("x.pack", [=](hipStream_t s, const RunArgs& a) {
+      if (step_merge && a.ts_index >= 0 && plp->Etab && a.ts_index < plp->etab_S)
+        return launch_pack_latent_bcast(a.x, xin, B_ext, cin, HW, 64, (cfg_mode && !dedup) ? 2 : 1,
+                                        plp->Etab + (size_t)a.ts_index * etot, Eb, N, etot, s);
+      return launch_pack_latent(a.x, xin, B_ext, cin, HW, 64, (cfg_mode && !dedup) ? 2 : 1, 1.0f, nullptr, nullptr, s);
+    });
+  }
 
   // ---- concat buffers of the decoder (skip tensors are produced straight into them)
   const int nin = (int)topo.input.size();
@@ -1543,9 +1555,17 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
   if (cfg_mode) {
     float* e2 = b.buf<float>((size_t)N * u.out_channels * HW);
     Builder::out_f32(g, e2, u.out_channels);
-    b.gemm(g, 1, "out.conv");
+    // (round 5) when the tuner runs out.conv split-K, its reduce launch forms the guided eps as well (gemm.hip
+    // splitk_reduce_cfg_kernel: same arithmetic, one launch fewer); cfg.combine then has nothing to do.  DF_NO_STEP_MERGE=1 reverts.
+    Op& oc_ = b.gemm(g, 1, "out.conv");
+    oc_.cfg_ext = !no_step_merge;
+    const size_t oci = pl->ops.size() - 1;
+    Plan* plq = pl;
     const long n = (long)(N / 2) * u.out_channels * HW;
-    b.other("cfg.combine", [=](hipStream_t s, const RunArgs& ar) { return launch_cfg_combine(e2, ar.out, n, ar.scale, s); });
+    b.other("cfg.combine", [=](hipStream_t s, const RunArgs& ar) {
+      if (plq->ops[oci].cfg_ext && plq->ops[oci].gp.splitk > 1) return hipSuccess;
+      return launch_cfg_combine(e2, ar.out, n, ar.scale, s);
+    });
   } else {
     Builder::out_f32(g, nullptr, u.out_channels);
     Op& o = b.gemm(g, 1, "out.conv");
@@ -2339,6 +2359,7 @@ void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const
     if (o.is_gemm) {
       GemmParams g = o.gp;
       if (o.c_ext) g.C = a.out;
+      if (o.cfg_ext && g.splitk > 1) { g.cfg_out = a.out; g.cfg_scale = a.scale; }
       if (o.defer && g.splitk > 1) g.defer_reduce = 1;
       e = launch_gemm(g, o.tile, o.batch, s);
     } else {

@@ -70,6 +70,9 @@ struct GemmParams {
   // split-K
   int splitk; float* partial;
   int defer_reduce;   // split-K only: write the partial slabs and do NOT launch the reduce -- the consumer (GroupNorm) sums them
+  // split-K + NCHW store of a CFG batch [uncond ; cond] (UNetModel.out): the reduce launch also forms e_u + cfg_scale (e_c - e_u)
+  // and writes THAT, [M / 2 rows][N] as NCHW, to cfg_out (ddim.py:241-245); C is not written.  null = off.
+  float* cfg_out; float cfg_scale;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)

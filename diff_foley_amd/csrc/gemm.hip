@@ -53,6 +53,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   }
 }
 
+// Split-K reduce of UNetModel.out on a classifier-free-guidance batch (round 5): rows [0, M/2) are the unconditional half, rows
+// [M/2, M) the conditional one; both are reduced in slab order, get alpha / bias like the scalar reduce above, and the guided
+// eps  e_u + scale (e_c - e_u)  leaves as NCHW -- the arithmetic of splitk_reduce_kernel followed by cfg_combine_kernel, bit for bit,
+// in one launch instead of two.
+__global__ __launch_bounds__(256) void splitk_reduce_cfg_kernel(GemmParams p) {
+  const int half = p.M >> 1;
+  const long total = (long)half * p.N;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(e / p.N), oc = (int)(e - (long)row * p.N);
+    float vu = 0.f, vc = 0.f;
+    for (int s = 0; s < p.splitk; ++s) {
+      vu += p.partial[((long)s * p.M + row) * p.N + oc];
+      vc += p.partial[((long)s * p.M + row + half) * p.N + oc];
+    }
+    const float u = epi_bias(p, row, oc, vu), c = epi_bias(p, row + half, oc, vc);
+    const int b = row / p.hw_out, px = row - b * p.hw_out;
+    p.cfg_out[((long)b * p.N + oc) * p.hw_out + px] = u + p.cfg_scale * (c - u);
+  }
+}
+
 // Vectorised reduce: one thread per 4 consecutive output columns; the SK slab loads of a thread are independent and
 // issued together (compile-time split count), then alpha / bias / FiLM bias / residual / ReLU and one 16-B (fp32) or
 // 8-B (operand type) store.  Summation order s = 0..SK-1 is fixed, so results are deterministic.
@@ -263,6 +283,13 @@ hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t
         default: hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p); break;
       }
 #undef DF_RED
+    } else if (p.cfg_out) {
+      if (!p.store_nchw || p.geglu || p.res || p.aux || p.silu || p.relu || (p.M & 1) || p.hw_out <= 0 || (p.M >> 1) % p.hw_out != 0)
+        return hipErrorInvalidValue;
+      const long total = (long)(p.M >> 1) * p.N;
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(splitk_reduce_cfg_kernel, dim3(blocks), dim3(256), 0, stream, p);
     } else {
       const int nout = p.geglu ? (p.N >> 1) : p.N;
       const long total = (long)p.M * nout;

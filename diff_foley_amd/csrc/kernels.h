@@ -99,6 +99,8 @@ hipError_t launch_pack_geglu(const float* w, const float* b, uint16_t* wout, flo
 // ---- sampler elementwise ops on fp32 latents -------------------------------------------------
 // e = e_u + scale * (e_c - e_u) for e2 = [e_u ; e_c] (each n elements)
 hipError_t launch_bcast_rows(const float* src, float* dst, int rows, int n, hipStream_t s);
+hipError_t launch_pack_latent_bcast(const float* x, uint16_t* out, int B, int C, int HW, int cpad, int rep, const float* src,
+                                    float* dst, int rows, int n, hipStream_t s);
 hipError_t launch_cfg_combine(const float* e2, float* e, long n, float scale, hipStream_t s);
 // out = sum_i coef[i] * in[i]   (up to 4 terms; out may alias any input)
 hipError_t launch_lincomb(float* out, const float* const* in, const float* coef, int nterms, long n, hipStream_t s);
