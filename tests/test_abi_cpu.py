@@ -33,6 +33,21 @@ def test_header_symbols_exported():
     assert declared == set(E.exported_symbols()), declared ^ set(E.exported_symbols())
 
 
+def test_built_libraries_pass_the_layout_checks():
+    """Two hand-placed idioms the compiler cannot vouch for are checked on the BUILT code objects (run by __graft_entry__.build() as
+    well): every GEMM translation unit's own-code prefetch is bounded by a .bss symbol that really lies behind .text
+    (tools/check_code_touch.py), and -- sampled here on one library, the full scan takes 20 s -- no inline-asm 16-byte write-through
+    store is followed by a VALU write of its data registers within two wait states (tools/check_store_hazard.py)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_code_touch.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 violation(s)" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_store_hazard.py"), E.LIB_PATHS["fp16"]],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "0 hazard(s)" in r.stdout, r.stdout + r.stderr
+
+
 def test_no_gpu_fails_loudly():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
