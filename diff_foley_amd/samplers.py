@@ -33,7 +33,9 @@ def _warn_batch(conditioning, batch_size):
 # plms.py:60-110; dpm_solver/sampler.py:24-56); silently dropping one would return a plausible but wrong sample, so a
 # non-default value raises.  Anything not listed is ignored exactly like the reference's own **kwargs.
 # (`normals_sequence` is accepted and never read by the reference's samplers -- ddim.py:65,123, plms.py:64 -- so it is ignored here too.)
-_UNSUPPORTED_DEFAULTS = dict(quantize_x0=False, noise_dropout=0.0)
+# (`noise_dropout` IS on the path since round 5: DDIMSampler applies it as ddim.py:270-271 does; with PLMS -- eta = 0, no noise --
+# and DPM-Solver++ -- whose reference sampler drops the argument -- it has nothing to act on and is accepted like the reference.)
+_UNSUPPORTED_DEFAULTS = dict(quantize_x0=False)
 
 
 def reject_unsupported(sampler, kwargs, extra=None):
@@ -154,8 +156,10 @@ class DDIMSampler(object):
     def sample(self, S, batch_size, shape, conditioning=None, eta=0.0, x_T=None, log_every_t=100,
                unconditional_guidance_scale=1.0, unconditional_conditioning=None, temperature=1.0,
                verbose=True, callback=None, img_callback=None, classifier=None, origin_cond=None,
-               classifier_guide_scale=0.0, mask=None, x0=None, score_corrector=None, corrector_kwargs=None, **kwargs):
+               classifier_guide_scale=0.0, mask=None, x0=None, score_corrector=None, corrector_kwargs=None,
+               noise_dropout=0.0, **kwargs):
         reject_unsupported("DDIMSampler", kwargs)
+        noise_fn = kwargs.get("noise_fn")       # tests: replaces the device generator (the reference run's CPU noise sequence)
         _warn_batch(conditioning, batch_size)
         self.make_schedule(S, ddim_eta=eta, verbose=verbose)
         dev = self.model.device
@@ -185,8 +189,11 @@ class DDIMSampler(object):
                 eps_fn.reclaim_context()
             sigma = tb.sigmas[index]
             noise = None
-            if sigma != 0.0:
-                noise = torch.randn(size, device=dev) * temperature
+            if sigma != 0.0:         # ddim.py:269-271: noise * temperature, then dropout of the noise (functional default: training)
+                noise = (noise_fn(size) if noise_fn is not None else torch.randn(size, device=dev)) * temperature
+                if noise_dropout > 0.0:
+                    noise = torch.nn.functional.dropout(noise, p=float(noise_dropout))
+                noise = noise.to(dev, torch.float32).contiguous()
             img, pred_x0 = E.ddim_update(img, e_t, a_t, a_prev, sigma, tb.sqrt_one_minus_alphas[index], noise)
             if callback:
                 callback(i)

@@ -51,7 +51,7 @@ def q_sample_blend(img, x0, mask, alphas_cumprod, t, noise):
 
 def ddim_sample(apply_model, alphas_cumprod, S, x_T, cond, scale=1.0, uc=None, eta=0.0,
                 log_every_t=100, classifier=None, origin_cond=None, classifier_scale=0.0,
-                noise_fn=None, mask=None, x0=None, q_noise_fn=None):
+                noise_fn=None, mask=None, x0=None, q_noise_fn=None, temperature=1.0, noise_dropout=0.0):
     sch = ddim_schedule(alphas_cumprod, S, eta)
     steps = sch["timesteps"]
     b = x_T.shape[0]
@@ -74,7 +74,10 @@ def ddim_sample(apply_model, alphas_cumprod, S, x_T, cond, scale=1.0, uc=None, e
             e_t = e_t - (1 - a_t).sqrt() * g
         pred_x0 = (img - s1m * e_t) / a_t.sqrt()
         dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t
-        noise = sigma_t * (noise_fn(img.shape) if noise_fn is not None else torch.randn(img.shape))
+        # ddim.py:269-271: sigma_t * noise_like(...) * temperature, then F.dropout (functional default: training=True) on the noise
+        noise = sigma_t * (noise_fn(img.shape) if noise_fn is not None else torch.randn(img.shape)) * temperature
+        if noise_dropout > 0.0:
+            noise = torch.nn.functional.dropout(noise, p=noise_dropout)
         img = a_prev.sqrt() * pred_x0 + dir_xt + noise
         if index % log_every_t == 0 or index == total - 1:
             inter["x_inter"].append(img)

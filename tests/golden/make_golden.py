@@ -395,6 +395,32 @@ def inpaint(seed=0):
     save("g10_tiny_inpaint.npz", **out)
 
 
+def stochastic(seed=0):
+    """G12: the stochastic DDIM step of the reference (ddim.py:258-273), tiny config, CFG 4.5, 6 steps: eta = 1 with temperature 1
+    and 0.7, and with noise_dropout = 0.25 (torch.nn.functional.dropout on the noise, ddim.py:270-271).  Every random draw -- the
+    per-step noise AND the dropout mask -- comes from the global CPU generator after torch.manual_seed(77), in the reference's
+    order (noise, then mask), so a replay that draws in the same order reproduces the run."""
+    spec = synth.state_dict_spec(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
+    sd = synth.make_state_dict(spec, seed)
+    cfg = ref_import.load_ldm_config(unet=synth.UNET_TINY, vae=synth.VAE_TINY, cond=synth.COND_TINY)
+    model, ns = ref_import.build_reference_ldm(cfg, sd)
+    B = 2
+    xT = synth.synthetic_xT(B, seed=21)
+    feats = synth.synthetic_cavp(B, 32, 64, seed=1234)
+    out = {"noise_seed": np.int64(77)}
+    with torch.no_grad():
+        c = model.get_learned_conditioning(feats)
+        uc = torch.zeros_like(c)
+        for tag, kw in (("eta1", dict()), ("eta1_temp07", dict(temperature=0.7)), ("eta1_drop025", dict(noise_dropout=0.25)),
+                        ("eta05_drop05_temp13", dict(noise_dropout=0.5, temperature=1.3))):
+            torch.manual_seed(77)
+            eta = 0.5 if tag.startswith("eta05") else 1.0
+            z, _ = model.sample_log_diff_sampler(c, B, "DDIM", 6, unconditional_guidance_scale=4.5, unconditional_conditioning=uc,
+                                                 x_T=xT.clone(), eta=eta, **kw)
+            out[f"DDIM_6_{tag}_z"] = z
+    save("g12_tiny_ddim_stochastic.npz", **out)
+
+
 def full_extra(seed=0):
     """G5 extension (round 3): reference DDIM-25 trajectories for seeds 23 and 24, so that a full 25-step B=4 run of BASELINE
     configs[1] can be compared ROW BY ROW with four B=1 reference runs (seeds 21..24; samples are independent, so row i of
@@ -450,6 +476,7 @@ if __name__ == "__main__":
     ap.add_argument("--configs", action="store_true", help="G8: BASELINE configs[2] / configs[4] at full size (~8 min)")
     ap.add_argument("--inpaint", action="store_true", help="G10: mask / x0 inpainting through DDIM, PLMS and the ancestral sampler (tiny)")
     ap.add_argument("--quad", action="store_true", help="G11: the 'quad' DDIM discretisation tables (seconds)")
+    ap.add_argument("--stochastic", action="store_true", help="G12: eta > 0 DDIM with temperature / noise_dropout (tiny, seconds)")
     ap.add_argument("--full-extra", action="store_true", help="G5 extension: DDIM-25 reference runs for seeds 23 / 24 (~4 min)")
     a = ap.parse_args()
     torch.set_num_threads(8)
@@ -469,3 +496,5 @@ if __name__ == "__main__":
         inpaint()
     if a.quad:
         quad()
+    if a.stochastic:
+        stochastic()

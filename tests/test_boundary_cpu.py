@@ -10,11 +10,12 @@ import diff_foley_amd as P
 from diff_foley_amd import samplers as S, synth
 
 
-@pytest.mark.parametrize("kw", [dict(quantize_x0=True), dict(noise_dropout=0.1)])
+@pytest.mark.parametrize("kw", [dict(quantize_x0=True)])
 def test_unsupported_sampler_kwargs_raise(kw):
-    """ddim.py:58-113 accepts these; they select VQ / dropout code that is not built here.  (mask / x0 -- inpainting -- and the
-    score_corrector callback ARE on the path since round 3: tests/test_path_gpu.py::test_tiny_inpainting_vs_golden,
-    ::test_score_corrector_callback.)"""
+    """ddim.py:58-113 accepts this; it selects the VQ first stage's quantiser, which an AutoencoderKL model does not have.  (mask /
+    x0 -- inpainting -- and the score_corrector callback ARE on the path since round 3, noise_dropout since round 5:
+    tests/test_path_gpu.py::test_tiny_inpainting_vs_golden, ::test_score_corrector_callback,
+    ::test_tiny_stochastic_ddim_vs_golden.)"""
     with pytest.raises(NotImplementedError):
         S.reject_unsupported("DDIMSampler", kw)
 

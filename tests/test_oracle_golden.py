@@ -164,6 +164,23 @@ def test_g10_tiny_inpainting():
     assert float((z - xT).abs().mean()) > 0
 
 
+def test_g12_tiny_stochastic_ddim_temperature_and_noise_dropout():
+    """eta > 0 DDIM through the oracle against the reference's own runs (G12): sigma_t * noise * temperature, then
+    torch.nn.functional.dropout on the noise (ddim.py:269-271).  The reference drew the noise and the dropout mask from the global
+    CPU generator in that order; the oracle draws in the same order after the same seed."""
+    g = gold("g12_tiny_ddim_stochastic.npz")
+    apply_model, xT, c, uc, vsd = _tiny_sampling_setup()
+    acp = osch.ddpm_schedule()["alphas_cumprod"]
+    for tag, eta, kw in (("eta1", 1.0, dict()), ("eta1_temp07", 1.0, dict(temperature=0.7)),
+                         ("eta1_drop025", 1.0, dict(noise_dropout=0.25)),
+                         ("eta05_drop05_temp13", 0.5, dict(noise_dropout=0.5, temperature=1.3))):
+        torch.manual_seed(int(g["noise_seed"]))
+        z, _ = osamp.ddim_sample(apply_model, acp, 6, xT, c, 4.5, uc, eta=eta, **kw)
+        close(z, g[f"DDIM_6_{tag}_z"], 2e-4)
+    # the dropout really acts: with it the run differs from the plain eta = 1 run by far more than the tolerance
+    assert float((g["DDIM_6_eta1_drop025_z"] - g["DDIM_6_eta1_z"]).abs().mean()) > 1e-2
+
+
 def test_g6_tiny_classifier_and_double_guidance():
     g = gold("g6_tiny_classifier.npz")
     csd = ou.sub_state_dict(tiny_classifier_sd(), "model.")

@@ -200,6 +200,34 @@ def test_tiny_inpainting_vs_golden(tiny):
         tiny.sample_log_diff_sampler(c, B, "DDIM", 6, x_T=xT.clone(), mask=mask)          # mask without x0: like the reference
 
 
+def test_tiny_stochastic_ddim_vs_golden(tiny):
+    """eta > 0 DDIM with temperature and noise_dropout (ddim.py:269-271) through the product sampler against the reference's own
+    runs (G12).  The reference drew noise and dropout mask from the global CPU generator; the `noise_fn` hook hands the sampler CPU
+    noise from the same generator, and the sampler applies the dropout to that tensor where it lives, in the reference's order."""
+    g = gold("g12_tiny_ddim_stochastic.npz")
+    from diff_foley_amd import synth
+    B = 2
+    xT = synth.synthetic_xT(B, seed=21)
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+    uc = torch.zeros_like(c)
+    for tag, eta, kw in (("eta1", 1.0, dict()), ("eta1_temp07", 1.0, dict(temperature=0.7)),
+                         ("eta1_drop025", 1.0, dict(noise_dropout=0.25)),
+                         ("eta05_drop05_temp13", 0.5, dict(noise_dropout=0.5, temperature=1.3))):
+        torch.manual_seed(int(g["noise_seed"]))
+        z, _ = tiny.sample_log_diff_sampler(c, B, "DDIM", 6, unconditional_guidance_scale=4.5, unconditional_conditioning=uc,
+                                            x_T=xT.clone(), eta=eta, noise_fn=lambda s: torch.randn(s), **kw)
+        assert rel_l2(z.cpu(), g[f"DDIM_6_{tag}_z"]) < TRAJ_TOL, tag
+    # without the hook the noise comes from the device generator: finite, and different from the eta = 0 trajectory
+    z2, _ = tiny.sample_log_diff_sampler(c, B, "DDIM", 6, x_T=xT.clone(), eta=1.0, noise_dropout=0.25)
+    z0, _ = tiny.sample_log_diff_sampler(c, B, "DDIM", 6, x_T=xT.clone())
+    assert torch.isfinite(z2).all() and rel_l2(z2.cpu(), z0.cpu()) > 1e-2
+    # PLMS (eta = 0: no noise to drop) and DPM-Solver++ (its reference sampler drops the argument) accept it like the reference
+    for name in ("PLMS", "DPM_Solver"):
+        za, _ = tiny.sample_log_diff_sampler(c, B, name, 6, x_T=xT.clone(), noise_dropout=0.25)
+        zb, _ = tiny.sample_log_diff_sampler(c, B, name, 6, x_T=xT.clone())
+        assert torch.equal(za, zb), name
+
+
 def test_score_corrector_callback(P, tiny):
     """score_corrector.modify_score(model, e_t, x, t, c, **corrector_kwargs) (ddim.py:249-251, 382-384, plms.py:186-188): a caller's
     callback on the guided eps.  An identity corrector changes nothing; a scaling one gives the trajectory of the scaled eps
