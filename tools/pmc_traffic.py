@@ -37,7 +37,7 @@ def steady(rows, marker, steps):
     return rows[idx[-steps - 1]:idx[-1]], steps
 
 
-marker = sys.argv[4] if len(sys.argv) > 4 else "bcast_rows_kernel"      # t.lookup: first kernel of a step (time embedding hoisted)
+marker = sys.argv[4] if len(sys.argv) > 4 else "pack_latent_bcast_kernel"      # t.lookup + x.pack: first kernel of a hoisted step (round 5)
 out = {"note": "bytes per launch = 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes, dispatches of the last full steps only",
        "marker_kernel": marker}
 per_kernel = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])

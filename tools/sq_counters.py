@@ -1,6 +1,6 @@
 """Per-kernel SQ counters of the denoise step from two rocprofv3 --pmc passes (tools/sq_counters.sh).
 
-Only the dispatches of the last 4 full denoise steps are used (a step starts at bcast_rows_kernel = t.lookup), so tuning /
+Only the dispatches of the last 4 full denoise steps are used (a step starts at pack_latent_bcast_kernel = t.lookup + x.pack), so tuning /
 packing launches never enter.  Units (checked on this chip against kernel durations): SQ_BUSY_CYCLES is summed over the 32
 shader engines, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (32 per SE; = MFMA instructions x 32 clk for 32x32x16),
 SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT over the 256 CUs (8 per SE), SQ_WAVE_CYCLES / SQ_WAIT_* count 4-cycle quanta per wave.
@@ -18,7 +18,7 @@ import json
 import re
 import sys
 
-MARK = "bcast_rows_kernel"      # first kernel of a step since the time embedding is hoisted (t.lookup); was timestep_embedding_b16_kernel
+MARK = "pack_latent_bcast_kernel"      # first kernel of a hoisted step since round 5 (table look-up + latent packing in one launch); was bcast_rows_kernel
 
 
 def short(name):
