@@ -16,6 +16,11 @@ bash tools/sq_counters.sh gpurun_out/sq > gpurun_out/sq.log 2>&1
   echo "# tools/pgeglu_probe.py 18,21,22,30,31 dbg: isolated times (us), /dN = debug switches (bit 0 no MFMA, 1 no stores, 2 no GELU, 3 no requests, 4 no fragment reads, 5 no statistics loads)"
   python tools/pgeglu_probe.py 18,21,22,30,31 dbg 2>&1 | grep -v amdgpu
 } > gpurun_out/r5_pgeglu_stamps.txt
+{
+  echo "# tools/gemm_stamps_cold.py <tile> M N K: the same stamps, warm (third launch in a row) and COLD (behind a 2 GiB sweep of the caches,"
+  echo "# another kernel's code and fresh operands -- the state a launch finds in the plan); three cold repetitions each"
+  for a in "26 512 1280 1280" "28 512 3840 1280" "26 8192 320 320" "3 8192 320 320" "26 2048 640 640"; do echo "## tile $a"; python tools/gemm_stamps_cold.py $a 2>&1 | grep -v amdgpu; done
+} > gpurun_out/r5_gemm_stamps_cold.txt
 python tools/gemm_bench.py skip 2>&1 | grep -v amdgpu > gpurun_out/r5_skip_conv_bench.txt
 DF_DIST_SHARE_GPU0=1 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r5_bench_2rank_shared_gpu.json
 python -m pytest tests/test_multi_rank_gpu.py tests/test_bench_selflaunch_gpu.py -q 2>&1 | tail -3 > gpurun_out/r5_two_rank_gpu_test.log
