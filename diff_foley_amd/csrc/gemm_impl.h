@@ -614,9 +614,12 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p) {
   // tools (p.dbg bit 6, split-K 1): thread 0 stamps the shader clock at phase boundaries into p.partial[block][32] (uint64):
   // entry, operand requests of the prologue issued, first tile landed, K loop done; the epilogue's stamps follow at slots 24..
   int n_stamp = 0;
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();     // before any kernel argument is needed (slot 31 of the stamp row)
   auto stamp = [&]() {
-    if ((p.dbg & 64) && p.splitk <= 1 && p.partial && threadIdx.x == 0 && blockIdx.z == 0 && n_stamp < 24)
+    if ((p.dbg & 64) && p.splitk <= 1 && p.partial && threadIdx.x == 0 && blockIdx.z == 0 && n_stamp < 24) {
+      if (n_stamp == 0) reinterpret_cast<unsigned long long*>(p.partial)[(long)blockIdx.x * 32 + 31] = t_entry;
       reinterpret_cast<unsigned long long*>(p.partial)[(long)blockIdx.x * 32 + n_stamp++] = __builtin_amdgcn_s_memtime();
+    }
   };
   stamp();
   // ---- tile id with XCD-aware remap (block b runs on XCD b%8; give each XCD a contiguous range)

@@ -30,7 +30,7 @@ def stamps(tag):
     assert L.df_test_scratch_read(buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
     buf = buf.reshape(4096, 32)
     nb = int((buf[:, 0] > 0).sum())
-    tot, d0, d1, d2 = [], [], [], []
+    tot, d0, d1, d2, dk = [], [], [], [], []
     for blk in range(nb):
         row = buf[blk].astype(np.int64)
         n = int((row[:24] > 0).sum())
@@ -38,9 +38,11 @@ def stamps(tag):
         tot.append(last - int(row[0]))
         dd = np.diff(row[:n])
         d0.append(dd[0]); d1.append(dd[1]); d2.append(dd[2])
+        if row[31] > 0:
+            dk.append(int(row[0]) - int(row[31]))      # first instruction of the wavefront -> first stamp (= the first kernel-argument wait)
     first = min(int(buf[b][0]) for b in range(nb))
     end = max(max(int(buf[b][24:28].max()), int(buf[b][:24].max())) for b in range(nb))
-    print(f"{tag:5s} blocks {nb}: entry->requests {int(np.median(d0)):5d}  ->first tile {int(np.median(d1)):5d}  K loop {int(np.median(d2)):6d}  "
+    print(f"{tag:5s} blocks {nb}: wave start->args {int(np.median(dk)) if dk else -1:5d}  entry->requests {int(np.median(d0)):5d}  ->first tile {int(np.median(d1)):5d}  K loop {int(np.median(d2)):6d}  "
           f"block lifetime median {int(np.median(tot)):6d} max {int(max(tot)):6d}  (first entry -> last stamp, one XCD clock: {end - first} cycles)")
 
 
