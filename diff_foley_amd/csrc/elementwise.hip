@@ -291,28 +291,58 @@ __global__ __launch_bounds__(64) void gn_merge_stats_kernel(const float* __restr
   }
 }
 
+// Round 5: a thread owns EIGHT consecutive channels (two float4 loads -> one 16-byte operand store) and keeps GN_APPLY_UN pixels in
+// flight (16 independent loads per thread before the first use).  The first form walked its pixels one dependent load -> store at a
+// time with 8-byte stores: 46.8 us per norm on average in the VAE decoder (4.3 TB/s on the 128 x 512 maps, where the statistics
+// pass over the same bytes runs at 7.6).  Same arithmetic per element, bit-identical output.
+constexpr int GN_APPLY_UN = 8;
 __global__ __launch_bounds__(256) void gn_chunk_apply_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ stat, int silu,
                                                              bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw) {
   const int n = blockIdx.y, chunk = blockIdx.x;
-  const int q = C >> 2;
+  const int q = C >> 3;                                 // 8-channel lanes per pixel (16 | 32 | 64)
   const int lane_c = threadIdx.x % q, lane_p = threadIdx.x / q, ppi = 256 / q;
   const int p0 = chunk * GN_CHUNK_PX, p1 = min(HW, p0 + GN_CHUNK_PX);
-  const int c0 = lane_c * 4, grp = c0 / cpg;
-  const float mean = stat[((long)n * 32 + grp) * 2], rstd = stat[((long)n * 32 + grp) * 2 + 1];
-  const float4 gm = *reinterpret_cast<const float4*>(gamma + c0), bt = *reinterpret_cast<const float4*>(beta + c0);
-  const float4 sc = make_float4(rstd * gm.x, rstd * gm.y, rstd * gm.z, rstd * gm.w);
-  const float4 sh = make_float4(bt.x - mean * sc.x, bt.y - mean * sc.y, bt.z - mean * sc.z, bt.w - mean * sc.w);
+  const int c0 = lane_c * 8;
+  float4 sc[2], sh[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = c0 + 4 * h, grp = c / cpg;
+    const float mean = stat[((long)n * 32 + grp) * 2], rstd = stat[((long)n * 32 + grp) * 2 + 1];
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c), bt = *reinterpret_cast<const float4*>(beta + c);
+    sc[h] = make_float4(rstd * gm.x, rstd * gm.y, rstd * gm.z, rstd * gm.w);
+    sh[h] = make_float4(bt.x - mean * sc[h].x, bt.y - mean * sc[h].y, bt.z - mean * sc[h].z, bt.w - mean * sc[h].w);
+  }
   const float* xb = x + (long)n * HW * ld + c0;
   bf16_t* ob = out + (long)n * HW * ldo + c0;
   bf16_t* rb = raw ? raw + (long)n * HW * ldo + c0 : nullptr;
-  for (int p = p0 + lane_p; p < p1; p += ppi) {
-    const float4 v = *reinterpret_cast<const float4*>(xb + (long)p * ld);
-    float a = v.x * sc.x + sh.x, b = v.y * sc.y + sh.y, c = v.z * sc.z + sh.z, d = v.w * sc.w + sh.w;
-    if (silu) { a = silu_f(a); b = silu_f(b); c = silu_f(c); d = silu_f(d); }
-    *reinterpret_cast<uint2*>(ob + (long)p * ldo) = make_uint2(pack_bf2(a, b), pack_bf2(c, d));
-    if (rb) *reinterpret_cast<uint2*>(rb + (long)p * ldo) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+  for (int pb = p0 + lane_p; pb < p1; pb += GN_APPLY_UN * ppi) {
+    float4 v[GN_APPLY_UN][2];
+#pragma unroll
+    for (int u = 0; u < GN_APPLY_UN; ++u) {
+      const float* src = xb + (long)min(pb + u * ppi, HW - 1) * ld;     // clamped: every load is issued, tails are masked below
+      v[u][0] = *reinterpret_cast<const float4*>(src);
+      v[u][1] = *reinterpret_cast<const float4*>(src + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < GN_APPLY_UN; ++u) {
+      const int p = pb + u * ppi;
+      if (p >= p1) continue;
+      uint32_t w[4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float a = v[u][h].x * sc[h].x + sh[h].x, b = v[u][h].y * sc[h].y + sh[h].y;
+        float c = v[u][h].z * sc[h].z + sh[h].z, d = v[u][h].w * sc[h].w + sh[h].w;
+        if (silu) { a = silu_f(a); b = silu_f(b); c = silu_f(c); d = silu_f(d); }
+        w[2 * h] = pack_bf2(a, b);
+        w[2 * h + 1] = pack_bf2(c, d);
+      }
+      *reinterpret_cast<uint4*>(ob + (long)p * ldo) = make_uint4(w[0], w[1], w[2], w[3]);
+      if (rb)
+        *reinterpret_cast<uint4*>(rb + (long)p * ldo) = make_uint4(pack_bf2(v[u][0].x, v[u][0].y), pack_bf2(v[u][0].z, v[u][0].w),
+                                                                  pack_bf2(v[u][1].x, v[u][1].y), pack_bf2(v[u][1].z, v[u][1].w));
+    }
   }
 }
 
@@ -758,7 +788,7 @@ size_t groupnorm_scratch_bytes(int N, int HW, int C) {
 hipError_t launch_groupnorm_chunked(const float* x, int ld, int N, int HW, int C, const float* gamma, const float* beta,
                                     float eps, int silu, uint16_t* out, int ldo, uint16_t* raw_out, float* scratch,
                                     hipStream_t s) {
-  if ((C != 128 && C != 256 && C != 512) || (ld & 3) || (ldo & 3) || !scratch) return hipErrorInvalidValue;
+  if ((C != 128 && C != 256 && C != 512) || (ld & 3) || (ldo & 7) || !scratch) return hipErrorInvalidValue;
   const int cpg = C / 32, cpx = gn_stats_chunk_px(C), nchunk = (HW + cpx - 1) / cpx;
   const int nchunk_apply = (HW + GN_CHUNK_PX - 1) / GN_CHUNK_PX;
   float* part = scratch;
