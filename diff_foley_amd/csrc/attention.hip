@@ -42,6 +42,13 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
   constexpr int DT = (D + 31) / 32;       // 32-row tiles of O^T
   constexpr int KROW = DKP + 8;           // K LDS row stride (bf16): +16 B pad de-conflicts ds_read_b128
   constexpr int KT = AttnGeo<KS>::KT, VROW = AttnGeo<KS>::VROW;
+  // Row sum by the matrix pipe (round 5): when D is not a multiple of 32 the last 32-row tile of O^T has padding rows; row D of the
+  // staged V^T tile is kept at 1.0, so O^T[D][q] accumulates sum_key P[key][q] beside the outputs -- rescaled with them, in fp32, over
+  // the operand-rounded probabilities the numerator sums -- and the 16 adds per 32 keys of the lane-local sum chain disappear
+  // (D = 40: 34 of 136 VALU instructions per 64 keys; the kernel is bound by its VALU issue, section 3).
+  constexpr bool ONES = (D % 32) != 0;
+  constexpr int ONE_T = D / 32, ONE_R = ((D % 32) / 8) * 4 + (D % 4);      // tile / accumulator register of row D (held by half-wave (D % 8) / 4)
+  static_assert(!ONES || (D % 8) == 0, "row D sits in half-wave 0");
   __shared__ __attribute__((aligned(16))) bf16_t sK[2 * KT * KROW];
   __shared__ __attribute__((aligned(16))) bf16_t sV[2 * DT * 32 * VROW];
 
@@ -151,12 +158,23 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
     for (int i = 0; i < VCH; ++i) {
       const int c = tid + i * NT;
       const int d = c / VCR, ch = c - d * VCR;
-      if (c < DT * 32 * VCR) *reinterpret_cast<uint2*>(&v_[d * VROW + ch * 4]) = vreg[i];
+      if (c < DT * 32 * VCR && !(ONES && d == D)) *reinterpret_cast<uint2*>(&v_[d * VROW + ch * 4]) = vreg[i];
     }
   };
 
   gfetch(0);
   sstore(0);
+  if (ONES) {                       // row D of both V^T buffers = 1.0 (never overwritten: sstore skips it)
+#if defined(DF_OPERAND_F16)
+    constexpr uint32_t ONE2 = 0x3C003C00u;
+#else
+    constexpr uint32_t ONE2 = 0x3F803F80u;
+#endif
+    for (int i = tid; i < 2 * (KT / 2); i += NT) {
+      const int b = i / (KT / 2), k2 = i - b * (KT / 2);
+      *reinterpret_cast<uint32_t*>(&sV[b * (DT * 32 * VROW) + D * VROW + 2 * k2]) = ONE2;
+    }
+  }
   __syncthreads();
 
   for (int kt = 0; kt < ntiles; ++kt) {
@@ -212,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
       for (int r = 0; r < 16; r += 2) {
         const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], scale_log2e, -m_new)),
                     p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r + 1], scale_log2e, -m_new));
-        psu[u] += p0 + p1;
+        if (!ONES) psu[u] += p0 + p1;
         pk[u][r >> 1] = pack_bf2_bounded(p0, p1);      // p in [0, 1]
       }
     }
@@ -221,14 +239,14 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
     for (int u = 1; u < KS; ++u) ps += psu[u];
     if (__any(m_new != m_run)) {                   // wave-uniform: rescale only when some row's running max moved
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
-      l_run *= alpha;
+      if (!ONES) l_run *= alpha;
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
       m_run = m_new;
     }
-    l_run += ps;
+    if (!ONES) l_run += ps;
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int u = 0; u < KS; ++u)
@@ -251,7 +269,14 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
   }
 
   // ---- normalise and store: lane (q, lh) holds O[q][32t + (r&3) + 8(r>>2) + 4lh]
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  float l_tot;
+  if (ONES) {
+    const float mine = o[ONE_T][ONE_R];          // valid in half-wave 0
+    const float other = __shfl_xor(mine, 32);
+    l_tot = lh == 0 ? mine : other;
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32);
+  }
   const float inv = 1.0f / l_tot;
   if (qv) {
     bf16_t* orow = O + ((long)n * Tq + q) * ldo + h * D;
