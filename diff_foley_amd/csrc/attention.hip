@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
     float mx = mxu[0];
 #pragma unroll
     for (int u = 1; u < KS; ++u) mx = fmaxf(mx, mxu[u]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;
+    mx = half_max(mx) * scale_log2e;              // the partner half-wave holds the other 16 keys of this query
     const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 valid key
     float psu[KS];
     uint32_t pk[KS][8];

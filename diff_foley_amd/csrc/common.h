@@ -150,6 +150,33 @@ __device__ __forceinline__ float gelu_erf(float x) {  // exact-erf GELU (F.gelu 
   return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 
+// The value of the partner lane 32 away (lane ^ 32) without the LDS pipe: v_permlane32_swap_b32 (gfx950) exchanges the upper half of its
+// first operand with the lower half of its second, so after swapping two copies of v every lane holds its own value in one register and
+// the partner's in the other.  (__shfl_xor(v, 32) is a ds_bpermute round trip and an lgkmcnt(0) on the dependent chain; the builtin
+// __builtin_amdgcn_permlane32_swap folded a following max of its two results away in this toolchain, hence the asm.  s_nop 1 on both
+// sides: the swap reads and writes VGPRs of neighbouring VALU instructions outside the compiler's hazard tracking.)
+__device__ __forceinline__ void half_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float half_max(float v) {      // max(v, v of lane ^ 32)
+  float a = v, b = v;
+  half_swap(a, b);
+  return fmaxf(a, b);
+}
+
+// Lane exchanges inside a group of 2 / 4 / 8 neighbouring lanes as DPP operands of the consuming VALU instruction (no ds_bpermute round
+// trip on the dependent chain): quad_perm [1,0,3,2] = lane ^ 1, quad_perm [2,3,0,1] = lane ^ 2, row_half_mirror = lane 7 - i of the same
+// 8 lanes (the other quad: after the two quad steps every lane of a quad holds the quad's total, so this completes 8 lanes).
+__device__ __forceinline__ float dpp_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_half_mirror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -181,11 +181,11 @@ __device__ __forceinline__ void geglu_persistent_body(const GemmParams& p) {
         s1 += lnv[s].x;
         s2 += lnv[s].y;
       }
-      s1 += __shfl_xor(s1, 1);
-      s2 += __shfl_xor(s2, 1);
+      s1 += dpp_xor1(s1);            // DPP operands: no ds_bpermute round trips in the fold
+      s2 += dpp_xor1(s2);
       if (TPR == 4) {
-        s1 += __shfl_xor(s1, 2);
-        s2 += __shfl_xor(s2, 2);
+        s1 += dpp_xor2(s1);
+        s2 += dpp_xor2(s2);
       }
       const float inv = 1.0f / (float)p.ln_C;
       const float mean = s1 * inv;

@@ -279,17 +279,17 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
       if (g0 + 2 >= p.sm_valid) v.z = NEG;
       if (g0 + 3 >= p.sm_valid) v.w = NEG;
       float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-      mx = fmaxf(mx, __shfl_xor(mx, 1));
-      mx = fmaxf(mx, __shfl_xor(mx, 2));
-      mx = fmaxf(mx, __shfl_xor(mx, 4));
+      mx = fmaxf(mx, dpp_xor1(mx));             // the 8 lanes that hold a head's 32 columns of this row
+      mx = fmaxf(mx, dpp_xor2(mx));
+      mx = fmaxf(mx, dpp_half_mirror(mx));
       v.x = g0 + 0 < p.sm_valid ? __expf(v.x - mx) : 0.f;
       v.y = g0 + 1 < p.sm_valid ? __expf(v.y - mx) : 0.f;
       v.z = g0 + 2 < p.sm_valid ? __expf(v.z - mx) : 0.f;
       v.w = g0 + 3 < p.sm_valid ? __expf(v.w - mx) : 0.f;
       float sm = (v.x + v.y) + (v.z + v.w);
-      sm += __shfl_xor(sm, 1);
-      sm += __shfl_xor(sm, 2);
-      sm += __shfl_xor(sm, 4);
+      sm += dpp_xor1(sm);
+      sm += dpp_xor2(sm);
+      sm += dpp_half_mirror(sm);
       const float inv = 1.0f / sm;
       if (row < p.M && col < p.N)
         st_wt(reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (long)row * p.ldc + col),
