@@ -223,13 +223,23 @@ __device__ __forceinline__ float wave_sum_dpp_bcast(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // block_sum_dpp on a `red` array that nobody has read yet (first use in the kernel, or a second array): no leading barrier.
+// `red` = 16 floats, 16-byte aligned.  The slots of wavefronts that do not exist are zeroed by wavefront 0 in front of the same barrier
+// and all 16 are read as four ds_read_b128 in flight together, summed in slot order (x + 0.0f == x: the same bits as the loop over
+// the live slots).  (Round 5: the loop over blockDim.x / 64 slots compiled to one 8-slot pass + up to seven DEPENDENT single-slot
+// LDS round trips, ~700 cycles per reduction at 14 wavefronts, two reductions per norm.)
 __device__ __forceinline__ float block_sum_dpp_fresh(float v, float* red) {
   v = wave_sum_dpp_bcast(v);
   const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   if ((threadIdx.x & 63) == 0) red[w] = v;
+  else if (threadIdx.x >= nw && threadIdx.x < 16) red[threadIdx.x] = 0.f;
   __syncthreads();
+  const float4* r4 = reinterpret_cast<const float4*>(red);
+  const float4 a = r4[0], b = r4[1], c = r4[2], d = r4[3];
   float t = 0.f;
-  for (int i = 0; i < nw; ++i) t += red[i];
+  t += a.x; t += a.y; t += a.z; t += a.w;
+  t += b.x; t += b.y; t += b.z; t += b.w;
+  t += c.x; t += c.y; t += c.z; t += c.w;
+  t += d.x; t += d.y; t += d.z; t += d.w;
   return t;
 }
 // The same with the in-wave steps as DPP adds (wave_sum_dpp): 2 LDS-pipe exchanges per wavefront instead of 6.

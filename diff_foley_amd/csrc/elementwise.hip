@@ -43,7 +43,7 @@ __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW
                                      bf16_t* __restrict__ out, int ldo, int silu, int C,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                      bf16_t* __restrict__ raw, GnSlabs sl) {
-  __shared__ float red[16], red2[16];      // one array per reduction: neither needs a barrier in front of its first (only) use
+  __shared__ __attribute__((aligned(16))) float red[16], red2[16];      // one array per reduction: neither needs a barrier in front of its first (only) use
   // block b runs on XCD b%8.  Samples in multiples of 8 (the UNet's CFG batch): ALL groups of a sample on one XCD (b = g * nsamp +
   // n), so every 128-B line of the sample's rows is read into, and written back from, exactly one L2.  Otherwise: the 4
   // neighbouring groups that share lines on one XCD (b = n * 32 + (XCD-major group index)).
