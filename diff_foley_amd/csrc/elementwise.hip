@@ -299,11 +299,11 @@ constexpr int GN_APPLY_UN = 8;
 __global__ __launch_bounds__(256) void gn_chunk_apply_kernel(const float* __restrict__ x, int ld, int HW, int C, int cpg,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ stat, int silu,
-                                                             bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw) {
+                                                             bf16_t* __restrict__ out, int ldo, bf16_t* __restrict__ raw, int chunk_px) {
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int q = C >> 3;                                 // 8-channel lanes per pixel (16 | 32 | 64)
   const int lane_c = threadIdx.x % q, lane_p = threadIdx.x / q, ppi = 256 / q;
-  const int p0 = chunk * GN_CHUNK_PX, p1 = min(HW, p0 + GN_CHUNK_PX);
+  const int p0 = chunk * chunk_px, p1 = min(HW, p0 + chunk_px);
   const int c0 = lane_c * 8;
   float4 sc[2], sh[2];
 #pragma unroll
@@ -790,13 +790,18 @@ hipError_t launch_groupnorm_chunked(const float* x, int ld, int N, int HW, int C
                                     hipStream_t s) {
   if ((C != 128 && C != 256 && C != 512) || (ld & 3) || (ldo & 7) || !scratch) return hipErrorInvalidValue;
   const int cpg = C / 32, cpx = gn_stats_chunk_px(C), nchunk = (HW + cpx - 1) / cpx;
-  const int nchunk_apply = (HW + GN_CHUNK_PX - 1) / GN_CHUNK_PX;
+  // apply chunk: 256 pixels, halved while the grid would not fill the chip twice (4 x 64 x 64 px at C = 512: 64 blocks of 256 px
+  // ran the pass at 0.9 TB/s: 39 us per norm) and one chunk still feeds the eight pixels a thread keeps in flight
+  int chunk_apply = GN_CHUNK_PX;
+  const int ppi = 256 / (C >> 3);
+  while ((long)N * ((HW + chunk_apply - 1) / chunk_apply) < 512 && chunk_apply / 2 >= GN_APPLY_UN * ppi) chunk_apply /= 2;
+  const int nchunk_apply = (HW + chunk_apply - 1) / chunk_apply;
   float* part = scratch;
   float* stat = scratch + (size_t)N * nchunk * 32 * 2;
   hipLaunchKernelGGL(gn_chunk_stats_kernel, dim3(nchunk, N), dim3(256), 0, s, x, ld, HW, C, cpg, part);
   hipLaunchKernelGGL(gn_merge_stats_kernel, dim3(32, N), dim3(64), 0, s, part, nchunk, cpx, HW, cpg, eps, stat);
   hipLaunchKernelGGL(gn_chunk_apply_kernel, dim3(nchunk_apply, N), dim3(256), 0, s, x, ld, HW, C, cpg, gamma, beta, stat, silu,
-                     out, ldo, raw_out);
+                     out, ldo, raw_out, chunk_apply);
   return hipGetLastError();
 }
 

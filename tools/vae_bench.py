@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """decode_first_stage at B=4 a few times (for rocprofv3 --kernel-trace --stats and the --pmc traffic passes of the
-VAE decoder; BASELINE.json configs[1] decodes 4 clips per sample() call).  usage: python tools/vae_bench.py [reps]"""
+VAE decoder; BASELINE.json configs[1] decodes 4 clips per sample() call).  usage: python tools/vae_bench.py [reps] [per-op csv]"""
 import os
 import sys
 
@@ -25,4 +25,10 @@ for _ in range(reps):                   # was seen to halve the speed of the lau
     m.decode_first_stage(z)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) * 1e3 / reps
+if len(sys.argv) > 2:                   # per-op CSV of one instrumented decode (HIP events around every op)
+    m.engine.profile_begin()
+    m.decode_first_stage(z)
+    torch.cuda.synchronize()
+    m.engine.profile_end()
+    m.engine.profile_dump(sys.argv[2])
 print(f"vae decode B=4: {ms:.3f} ms  ({622.2 * 4 / ms:.1f} TFLOP/s algorithmic, {(0.0989 + 0.6096 * 4) / ms * 1e3:.0f} GB/s algorithmic)")
