@@ -1003,6 +1003,104 @@ hipError_t launch_pack_conv_ups4(const float* w, uint16_t* out, int O, int I, in
   return hipGetLastError();
 }
 
+namespace {
+// 3x3 convolution (stride 1, zero padding 1) with a HANDFUL of output channels straight to an NCHW fp32 tensor: the VAE decoder's
+// conv_out (stage1_autoencoder/model.py: Decoder.conv_out, 128 -> 3 channels over the full 128 x 512 mel image).  On the implicit-GEMM
+// tiles the 3 output channels are padded to a 64-column tile (21x the MFMA work, 144 us at B = 4); the op is bound by reading the
+// activations once.  A block owns a 4-row x 32-pixel patch: its 6 x 34 halo pixels are staged into LDS with fully coalesced 16-byte
+// loads (16 lanes = one pixel's channel vector; a first form that loaded the MFMA fragments straight from global memory -- lane =
+// pixel, 32 B used of every 128-byte line per instruction -- ran at 133 us, bound by the texture-address path), zeros outside the
+// image.  Wavefront w owns row w of the patch: A operand = its 32 pixels' channel vectors out of LDS (row pitch C * 2 + 16 B: the 16
+// lanes of a read phase hit 64 distinct banks), B operand = the weight rows of the <= 4 output channels out of LDS (lanes >= Cout hold
+// zeros), one v_mfma_f32_32x32x16 per 16 input channels and tap.  Lane (co = lane & 31 < Cout, half) ends up with 16 pixels of output
+// channel co: four float4 stores.
+constexpr int FO_TH = 4, FO_TW = 32;
+__global__ __launch_bounds__(256) void conv3x3_fewout_kernel(const bf16_t* __restrict__ X /*[NB][H][W][C]*/, const bf16_t* __restrict__ Wt /*[Cout][9][C]*/,
+                                                             const float* __restrict__ bias, float* __restrict__ out /*[NB][Cout][H][W]*/,
+                                                             int NB, int H, int W, int C, int Cout) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int pitch = C * 2 + 16;                                  // bytes per staged pixel
+  char* sX = smem;                                               // [(FO_TH + 2) * (FO_TW + 2)][pitch]
+  bf16_t* sW = reinterpret_cast<bf16_t*>(smem + (FO_TH + 2) * (FO_TW + 2) * pitch);      // [Cout][9 * C]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tpr = (W + FO_TW - 1) / FO_TW, tpc = (H + FO_TH - 1) / FO_TH;
+  const int bx = blockIdx.x % tpr, by = (blockIdx.x / tpr) % tpc, n = blockIdx.x / (tpr * tpc);
+  const int x0 = bx * FO_TW, y0 = by * FO_TH;
+  // ---- stage the halo patch: chunk = 16 bytes, C / 8 chunks per pixel
+  const int cpp = C >> 3, nchunks = (FO_TH + 2) * (FO_TW + 2) * cpp;
+  for (int i = tid; i < nchunks; i += 256) {
+    const int px = i / cpp, ch = i - px * cpp;
+    const int py = px / (FO_TW + 2), pxx = px - py * (FO_TW + 2);
+    const int yy = y0 + py - 1, xx = x0 + pxx - 1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *reinterpret_cast<const uint4*>(X + (((long)n * H + yy) * W + xx) * C + ch * 8);
+    *reinterpret_cast<uint4*>(sX + px * pitch + ch * 16) = v;
+  }
+  for (int i = tid; i < Cout * 9 * C / 8; i += 256) reinterpret_cast<uint4*>(sW)[i] = reinterpret_cast<const uint4*>(Wt)[i];
+  __syncthreads();
+  const int y = y0 + wid;
+  if (y >= H) return;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nch = C >> 4;
+  const bool wrow = l31 < Cout;
+  const bf16_t* wl = sW + (wrow ? l31 : 0) * 9 * C + lh * 8;
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3, dx = tap - dy * 3;                   // patch coordinates: (wid + dy, l31 + dx)
+    const char* src = sX + ((wid + dy) * (FO_TW + 2) + l31 + dx) * pitch + lh * 16;
+    const bf16_t* wt = wl + tap * C;
+#pragma unroll 8
+    for (int c = 0; c < nch; ++c) {
+      const uint4 av = *reinterpret_cast<const uint4*>(src + c * 32);
+      uint4 bv = *reinterpret_cast<const uint4*>(wt + c * 16);
+      if (!wrow) bv = make_uint4(0, 0, 0, 0);
+      uint4 a2 = av;
+      acc = DF_MFMA_32x32x16(*reinterpret_cast<bf16x8*>(&a2), *reinterpret_cast<bf16x8*>(&bv), acc);
+    }
+  }
+  if (wrow) {
+    const float b = bias ? bias[l31] : 0.f;
+    float* o = out + (((long)n * Cout + l31) * H + y) * W + x0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int px = 8 * g + 4 * lh;
+      if (x0 + px + 3 < W) {
+        *reinterpret_cast<float4*>(o + px) = make_float4(acc[4 * g] + b, acc[4 * g + 1] + b, acc[4 * g + 2] + b, acc[4 * g + 3] + b);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (x0 + px + i < W) o[px + i] = acc[4 * g + i] + b;
+      }
+    }
+  }
+#endif
+}
+}  // namespace
+
+static size_t conv3x3_fewout_lds(int C, int Cout) { return (size_t)(FO_TH + 2) * (FO_TW + 2) * (C * 2 + 16) + (size_t)Cout * 9 * C * 2; }
+
+bool conv3x3_fewout_ok(int H, int W, int C, int Cout) {
+  return Cout >= 1 && Cout <= 4 && C % 16 == 0 && C >= 16 && conv3x3_fewout_lds(C, Cout) <= 160 * 1024 && W % 4 == 0 && H > 0;
+}
+
+hipError_t launch_conv3x3_fewout(const uint16_t* X, const uint16_t* Wt, const float* bias, float* out, int NB, int H, int W, int C,
+                                 int Cout, hipStream_t s) {
+  if (!conv3x3_fewout_ok(H, W, C, Cout)) return hipErrorInvalidValue;
+  const long blocks = (long)NB * ((H + FO_TH - 1) / FO_TH) * ((W + FO_TW - 1) / FO_TW);
+  const size_t lds = conv3x3_fewout_lds(C, Cout);
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_fewout_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = lds;
+  }
+  hipLaunchKernelGGL(conv3x3_fewout_kernel, dim3((unsigned)blocks), dim3(256), lds, s, X, Wt, bias, out, NB, H, W, C, Cout);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_conv_weight(const float* w, uint16_t* out, int O, int I, int KH, int KW, int Ipad,
                                    hipStream_t s) {
   const long n = (long)O * KH * KW * Ipad;

@@ -2070,6 +2070,14 @@ void build_vae(df_ctx* c, Plan* pl, int B, int H, int W) {
     }
   }
   bf16_t* a = b.groupnorm(h, B, "decoder.norm_out", 1e-6f, 1, nullptr);
+  static const bool no_fewout = getenv("DF_NO_FEWOUT") && atoi(getenv("DF_NO_FEWOUT"));      // tools / tests: the implicit-GEMM form
+  if (!no_fewout && conv3x3_fewout_ok(hh, ww, h.C, v.out_ch)) {
+    const bf16_t* wp = c->w_conv3(pre + "decoder.conv_out.weight", h.C);
+    const float* bo = c->f32(pre + "decoder.conv_out.bias");
+    const int H_ = hh, W_ = ww, C_ = h.C, O_ = v.out_ch;
+    b.other("vae.conv_out", [=](hipStream_t s, const RunArgs& ra) { return launch_conv3x3_fewout(a, wp, bo, ra.out, B, H_, W_, C_, O_, s); });
+    return;
+  }
   GemmParams g = Builder::gp_conv3(a, B, hh, ww, h.C, c->w_conv3(pre + "decoder.conv_out.weight", h.C), v.out_ch, 1, 0);
   Builder::out_f32(g, nullptr, v.out_ch);
   g.bias = c->f32(pre + "decoder.conv_out.bias");
@@ -3634,6 +3642,11 @@ int df_test_conv3x3(const uint16_t* A, const uint16_t* W, const float* bias, flo
     else if (g.dbg & 64) g.partial = test_partial((size_t)4096 * 32 * 8);      // halo kernels: per-block clock stamps
     HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
   });
+}
+
+int df_test_conv3x3_fewout(const uint16_t* A, const uint16_t* W, const float* bias, float* out_nchw, int NB, int H, int Wd, int Cin,
+                           int Cout, void* stream) {
+  return guard([&] { HIPCHK(launch_conv3x3_fewout(A, W, bias, out_nchw, NB, H, Wd, Cin, Cout, (hipStream_t)stream)); });
 }
 
 int df_test_conv3x3_skip(const uint16_t* A, const uint16_t* A2, const uint16_t* W, const float* bias, float* C, int NB, int H,

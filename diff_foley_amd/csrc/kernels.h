@@ -42,6 +42,11 @@ hipError_t launch_attention(const uint16_t* Q, int ldq, const uint16_t* K, int l
                             hipStream_t s);
 bool attention_supported(int D);
 
+// 3x3 convolution with <= 4 output channels, NHWC operand-type input -> NCHW fp32 output (elementwise.hip; the VAE decoder's conv_out)
+bool conv3x3_fewout_ok(int H, int W, int C, int Cout);
+hipError_t launch_conv3x3_fewout(const uint16_t* X, const uint16_t* Wt /*[Cout][9][C]*/, const float* bias, float* out, int NB, int H, int W,
+                                 int C, int Cout, hipStream_t s);
+
 // Row softmax: fp32 scores [rows][T] -> bf16 probabilities [rows][T]  (VAE single-head attention)
 hipError_t launch_softmax_rows(const float* s, uint16_t* p, int rows, int T, hipStream_t st);
 

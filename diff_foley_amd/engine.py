@@ -104,6 +104,7 @@ _SIGS = {
     "df_test_geglu": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_int, C.c_void_p],
     "df_test_scratch_read": [C.c_void_p, C.c_int64],
+    "df_test_conv3x3_fewout": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p],
     "df_debug_saturations": [C.c_void_p, C.c_int, C.c_int64],
     "df_debug_saturations_read": [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(C.c_int64)],
     "df_debug_saturation_label": [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64],

@@ -242,6 +242,8 @@ int df_debug_saturation_label(df_ctx* ctx, int64_t index, char* buf, int64_t len
 int df_test_scratch_read(void* host, int64_t bytes);     /* the shared scratch of the test entry points (debug stamps) */
 int df_test_geglu(const uint16_t* A_dev, const uint16_t* W_dev, const void* stats_dev, const float* cs_dev, const float* bias_dev,
                   uint16_t* out_dev, int M, int K, int N1, int tile, int dbg, void* stream);
+int df_test_conv3x3_fewout(const uint16_t* A_nhwc_dev, const uint16_t* W_okki_dev, const float* bias_dev, float* out_nchw_dev, int NB,
+                           int H, int W, int Cin, int Cout /* <= 4 */, void* stream);
 int df_test_gemm_epi(const uint16_t* A_dev, const uint16_t* W_dev, const float* bias_dev, const float* res_dev, void* C_dev,
                      int M, int N, int K, int act /*0 none, 1 SiLU, 2 ReLU*/, int out_operand, int tile, int splitk,
                      void* stream);

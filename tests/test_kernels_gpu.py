@@ -161,6 +161,25 @@ def test_conv3x3(tile, NB, H, W, Cin, Cout, stride, ups, splitk):
     assert rel_l2(got, ref) < 2e-3
 
 
+@pytest.mark.parametrize("NB,H,W,Cin,Cout", [(2, 16, 64, 128, 3), (1, 5, 36, 64, 1), (3, 2, 8, 256, 4), (1, 128, 512, 128, 3), (2, 3, 100, 32, 2)])
+def test_conv3x3_few_output_channels(NB, H, W, Cin, Cout):
+    """The VAE decoder's conv_out (Decoder.conv_out: 128 -> 3 channels) as its own kernel: NHWC operand-type input, NCHW fp32 output,
+    ragged row tiles (W not a multiple of 32), image borders."""
+    E = _eng()
+    x = bf(rnd((NB, Cin, H, W), 13))
+    w = bf(rnd((Cout, Cin, 3, 3), 14) / (3 * Cin ** 0.5))
+    b = rnd((Cout,), 15)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1)
+    a = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = w.permute(0, 2, 3, 1).contiguous().cuda()
+    out = torch.full((NB, Cout, H, W), float("nan"), device="cuda")
+    rc = E.lib(PREC).df_test_conv3x3_fewout(ptr(a), ptr(wp), ptr(b.cuda()), ptr(out), NB, H, W, Cin, Cout, stream())
+    assert rc == 0, E.lib(PREC).df_last_error()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert rel_l2(out.cpu(), ref) < 2e-3
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 17, 18, 19, 20, 23, 24, 25, 26, 27, 28, 29])
 @pytest.mark.parametrize("NB,H,W,Cin,Cin2,Cout,splitk", [
     (2, 16, 64, 128, 192, 96, 1), (2, 16, 64, 64, 128, 320, 2), (4, 8, 32, 128, 64, 128, 1), (8, 4, 16, 128, 320, 192, 2),
