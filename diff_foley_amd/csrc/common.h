@@ -132,7 +132,10 @@ __device__ __forceinline__ float bf2f(uint16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
 #endif
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (v_div_scale / v_div_fmas / v_div_fixup
+// + Newton steps, ~12 instructions): the result is rounded to the operand type right after, and the GroupNorm that applies it is a
+// latency chain whose tail this sits on (round 5).
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off level): 1 rcp + 1 exp + 6 FMA instead of
 // the ~50-instruction libm erff -- the GEGLU epilogue evaluates it for every FF hidden unit.
 __device__ __forceinline__ float erf_as(float x) {
