@@ -2559,6 +2559,7 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
   a.out2 = (float*)(ext + 4 * slab);
   const bool prof_was = c->prof_on;
   const int reps = 3;
+  static const bool tune_pair = !(getenv("DF_TUNE_PAIR") && atoi(getenv("DF_TUNE_PAIR")) == 0);
   // one in-plan pass over candidate ranks [0, nr): every GEMM class runs its r-th candidate, per-op minimum over `nrep` runs
   auto evaluate = [&](size_t nr, int nrep) {
     for (auto& kv : cands)
@@ -2585,8 +2586,11 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
         const Op& o = pl->ops[i];
         if (!o.is_gemm || o.c_ext) continue;
         std::vector<TuneCand>& v = cands[tune_key(o)];
-        // a deferred split-K reduce is paid by the next op (the GroupNorm sums the slabs): judge the pair
-        if (r < v.size()) v[r].situ_ms += best[i] + ((o.defer && i + 1 < pl->ops.size()) ? best[i + 1] : 0.f);
+        // a deferred split-K reduce is paid by the next op (the GroupNorm sums the slabs): judge the pair.  (round 5) Any consumer
+        // that is not a GEMM itself (GroupNorm, attention: their time depends on nothing in this round but where this GEMM's tile
+        // walk left their input -- which XCD's L2 holds it) is judged with its producer too.
+        const bool pair = i + 1 < pl->ops.size() && (o.defer || (tune_pair && !pl->ops[i + 1].is_gemm));
+        if (r < v.size()) v[r].situ_ms += best[i] + (pair ? best[i + 1] : 0.f);
       }
     }
   };
@@ -2643,7 +2647,7 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
         if (!o.is_gemm || o.c_ext) continue;
         std::vector<double>& v = score[tune_key(o)];
         v.resize(NG, 0.0);
-        v[r] += best[i];
+        v[r] += best[i] + ((tune_pair && i + 1 < pl->ops.size() && !pl->ops[i + 1].is_gemm) ? best[i + 1] : 0.f);
       }
     }
     for (auto& o : pl->ops) {
