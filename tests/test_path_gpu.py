@@ -335,6 +335,7 @@ def test_hoisted_time_embedding_is_bit_identical(tiny):
     from diff_foley_amd import synth, samplers
     B = 2
     eng = tiny.engine
+    eng.finalize()               # drop the plans (and timestep tables) earlier tests of this session left: the "no table yet" case below
     x = synth.synthetic_xT(B, seed=5).cuda()
     c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
     uc = torch.zeros_like(c)
