@@ -140,7 +140,9 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // the ~50-instruction libm erff -- the GEGLU epilogue evaluates it for every FF hidden unit.
 __device__ __forceinline__ float erf_as(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  // v_rcp_f32 (1 ulp): __frcp_rn is the correctly rounded reciprocal, i.e. a whole IEEE division (v_div_scale x2, v_rcp, four FMAs,
+  // v_div_fmas, v_div_fixup) per hidden unit -- a quarter of the GEGLU epilogue's VALU instructions (ISA reading, round 5)
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
   float poly = 1.061405429f;
   poly = poly * t - 1.453152027f;
   poly = poly * t + 1.421413741f;
