@@ -124,6 +124,17 @@ __device__ __forceinline__ uint32_t pack_bf2_bounded(float lo, float hi) {
   const op_x2 v = __builtin_convertvector(f, op_x2);
   return *reinterpret_cast<const uint32_t*>(&v);
 }
+// fp16 build: conversions that clamp in HARDWARE.  MODE.FP16_OVFL (bit 23 of the wavefront's MODE register) makes an fp32 -> fp16
+// conversion whose finite result overflows return +-65504 instead of +-inf (checked on gfx950: 1e6 -> 0x7bff, 70000 -> 0x7bff, inf
+// stays inf) -- what op_clamp does with a v_max + v_med3 per value.  A kernel that calls df_fp16_hw_clamp() first may pack with
+// pack_bf2_hw; everything else keeps pack_bf2.  (df_debug_saturations counts stored +-65504 either way.)
+__device__ __forceinline__ void df_fp16_hw_clamp() {
+#if defined(DF_OPERAND_F16) && defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1 /* hwreg(HW_REG_MODE, 23, 1) */, 1);
+#endif
+}
+__device__ __forceinline__ uint32_t pack_bf2_hw(float lo, float hi) { return pack_bf2_bounded(lo, hi); }
+
 __device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)(pack_bf2(f, 0.f) & 0xFFFFu); }
 __device__ __forceinline__ float bf2f(uint16_t h) {
 #if defined(DF_OPERAND_F16)

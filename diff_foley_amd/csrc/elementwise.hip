@@ -43,6 +43,7 @@ __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW
                                      bf16_t* __restrict__ out, int ldo, int silu, int C,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                      bf16_t* __restrict__ raw, GnSlabs sl) {
+  df_fp16_hw_clamp();            // the stores pack with pack_bf2_hw
   __shared__ __attribute__((aligned(16))) float red[16], red2[16];      // one array per reduction: neither needs a barrier in front of its first (only) use
   // block b runs on XCD b%8.  Samples in multiples of 8 (the UNet's CFG batch): ALL groups of a sample on one XCD (b = g * nsamp +
   // n), so every 128-B line of the sample's rows is read into, and written back from, exactly one L2.  Otherwise: the 4
@@ -146,8 +147,8 @@ __global__ void groupnorm_reg_kernel(const float* __restrict__ x, int ld, int HW
       a = silu_f(a);
       b = silu_f(b);
     }
-    *reinterpret_cast<uint32_t*>(ob + DF_ROW(k) * ldo) = pack_bf2(a, b);
-    if (rb) *reinterpret_cast<uint32_t*>(rb + DF_ROW(k) * ldo) = pack_bf2(v[k].x, v[k].y);
+    *reinterpret_cast<uint32_t*>(ob + DF_ROW(k) * ldo) = pack_bf2_hw(a, b);
+    if (rb) *reinterpret_cast<uint32_t*>(rb + DF_ROW(k) * ldo) = pack_bf2_hw(v[k].x, v[k].y);
   }
 #undef DF_ROW
 }

@@ -31,6 +31,7 @@ template <int BM, int WGM, int WGN, int NST, int LNS, bool DBG>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void geglu_persistent_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int ka = gemm_kernarg_touch();
+  df_fp16_hw_clamp();           // the epilogue packs with pack_bf2_hw
   geglu_persistent_body<BM, WGM, WGN, NST, LNS, DBG>(p);
   gemm_kernarg_touch_end(ka);
 #endif
@@ -293,7 +294,7 @@ __device__ __forceinline__ void geglu_persistent_body(const GemmParams& p) {
             const float gv = acc[2 * g + 1][r] * rs[r8] + (rm[r8] * xcs[2 * g + 1] + xbb[2 * g + 1]); \
             o[h] = (DBG && (p.dbg & 4)) ? xv + gv : xv * gelu_erf(gv);                          \
           }                                                                                     \
-          o32[g][4 * (H) + q4] = pack_bf2(o[0], o[1]);                                          \
+          o32[g][4 * (H) + q4] = pack_bf2_hw(o[0], o[1]);                                          \
         }                                                                                       \
     }
     PG_HALF(0)
