@@ -151,9 +151,11 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // the ~50-instruction libm erff -- the GEGLU epilogue evaluates it for every FF hidden unit.
 __device__ __forceinline__ float erf_as(float x) {
   const float ax = fabsf(x);
-  // v_rcp_f32 (1 ulp): __frcp_rn is the correctly rounded reciprocal, i.e. a whole IEEE division (v_div_scale x2, v_rcp, four FMAs,
-  // v_div_fmas, v_div_fixup) per hidden unit -- a quarter of the GEGLU epilogue's VALU instructions (ISA reading, round 5)
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  // (__frcp_rn is the correctly rounded reciprocal, i.e. a whole IEEE division per hidden unit -- a quarter of the GEGLU epilogue's
+  // VALU instructions.  v_rcp_f32 in its place measured +0.55 % and passed every kernel test, but the full bf16 model then stored
+  // non-finite values from st.ffproj on in the second step of a B = 4 DDIM run (tests/test_path_gpu.py::test_full_batch4_matches_batch1;
+  // tools/nan_probe.py); the cause was not found in the time left, so the division stays: experiments/round5_measured_and_dropped.md 20)
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
   float poly = 1.061405429f;
   poly = poly * t - 1.453152027f;
   poly = poly * t + 1.421413741f;

@@ -1,0 +1,24 @@
+"""Which op first stores a non-finite operand value?  Full UNet, bf16 build, B = 4 CFG forward(s) (df_debug_saturations)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import diff_foley_amd as P
+from diff_foley_amd import synth
+m = P.LatentDiffusion(precision="bf16", **P.stage2_config())
+m.load_state_dict(synth.make_state_dict(synth.state_dict_spec(), 0))
+m.cuda()
+xT = synth.synthetic_xT(4, seed=21).cuda()
+c = m.get_learned_conditioning(synth.synthetic_cavp(4, 32, 512, seed=1234).cuda())
+uc = torch.zeros_like(c)
+eng = m.engine
+eng.set_context(torch.cat([uc, c]))
+eng.debug_saturations(True)
+x = xT
+for step, t in enumerate([961.0, 761.0, 561.0]):
+    y = eng.unet_forward_cfg(x, torch.full((4,), t, device="cuda"), 4.5)
+    res = eng.debug_saturations_read()
+    bad = [(i, lab, n) for i, (lab, n) in enumerate(res) if n]
+    print("step", step, "finite out:", bool(torch.isfinite(y).all()), "ops:", len(res), "bad:", bad[:6])
+    if bad:
+        break
+    x = x - 0.1 * y
