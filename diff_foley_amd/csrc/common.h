@@ -155,7 +155,11 @@ __device__ __forceinline__ float erf_as(float x) {
   // VALU instructions.  v_rcp_f32 in its place measured +0.55 % and passed every kernel test, but the full bf16 model then stored
   // non-finite values from st.ffproj on in the second step of a B = 4 DDIM run (tests/test_path_gpu.py::test_full_batch4_matches_batch1;
   // tools/nan_probe.py); the cause was not found in the time left, so the division stays: experiments/round5_measured_and_dropped.md 20)
+#if defined(DF_ERF_RCP)          /* experiment switch, see the comment above */
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+#else
   const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+#endif
   float poly = 1.061405429f;
   poly = poly * t - 1.453152027f;
   poly = poly * t + 1.421413741f;

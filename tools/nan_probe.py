@@ -20,5 +20,13 @@ for step, t in enumerate([961.0, 761.0, 561.0]):
     bad = [(i, lab, n) for i, (lab, n) in enumerate(res) if n]
     print("step", step, "finite out:", bool(torch.isfinite(y).all()), "ops:", len(res), "bad:", bad[:6])
     if bad:
+        i0 = bad[0][0]
+        print("ops in front of the first flagged one:", [res[k][0] for k in range(max(0, i0 - 3), i0 + 1)])
+        eng.debug_saturations(False)
+        eng.profile_begin(); eng.unet_forward_cfg(xT, torch.full((4,), 961.0, device="cuda"), 4.5); torch.cuda.synchronize(); eng.profile_end()
+        eng.profile_dump("/tmp/nan_ops.csv")
+        rows = open("/tmp/nan_ops.csv").read().splitlines()
+        tag = bad[0][1].split(":")[1]; idx = int(bad[0][1].split("#")[1].split(":")[0])
+        print("plan rows around it:", rows[idx - 1:idx + 2])
         break
     x = x - 0.1 * y
