@@ -7,11 +7,14 @@ from diff_foley_amd import synth
 m = P.LatentDiffusion(precision="bf16", **P.stage2_config())
 m.load_state_dict(synth.make_state_dict(synth.state_dict_spec(), 0))
 m.cuda()
+if os.environ.get("NAN_TUNE"): m.autotune(True)
 xT = synth.synthetic_xT(4, seed=21).cuda()
 c = m.get_learned_conditioning(synth.synthetic_cavp(4, 32, 512, seed=1234).cuda())
 uc = torch.zeros_like(c)
 eng = m.engine
 eng.set_context(torch.cat([uc, c]))
+eng.unet_forward_cfg(xT, torch.full((4,), 961.0, device="cuda"), 4.5)      # builds (and, with NAN_TUNE, tunes) the plan before counting
+torch.cuda.synchronize()
 eng.debug_saturations(True)
 x = xT
 for step, t in enumerate([961.0, 761.0, 561.0]):
