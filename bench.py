@@ -68,14 +68,14 @@ def cpu_baseline(sd, nsteps):
                 threads_8={"value": v8, "cores": th8}, host_cores=os.cpu_count())
 
 
-def pmc_traffic():
+def pmc_traffic(key="gemm_bytes_per_step"):
     """HBM-side bytes per GEMM launch (FETCH_SIZE x2 per the gfx950 calibration + WRITE_SIZE, separate --pmc passes of
     this same command; tools/pmc_traffic.sh).  rocprofv3 cannot run inside the timed process, so the number is read
     from the committed profile of the current round; null when absent."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)["gemm_bytes_per_launch"]
+            return json.load(f)[key]
     except Exception:
         return None
 
@@ -140,12 +140,14 @@ def run_mode(precision, sd_dev, a, dev, rank, world, lo, hi, barrier, dump_ops="
     if rank == 0:
         model.load_state_dict(sd_dev)
     model.cuda(dev)
-    if rank == 0 and not a.no_autotune:
+    # The product default (round 6): the plans come from the shipped table of this GPU model (diff_foley_amd/tuned/, imported by
+    # Engine.__init__) -- no tuning call, exactly what a notebook user gets.  --autotune re-tunes in this process instead.
+    if rank == 0 and a.autotune:
         model.autotune(True)
     dist_info = None
     if world > 1:      # rank 0 packs ONCE, one broadcast of the packed operand blob (RCCL over xGMI), the others import
         dist_info = parallel.broadcast_packed_model(model, B, src=0)
-        if rank != 0 and not a.no_autotune:
+        if rank != 0 and a.autotune:
             model.autotune(True)
     feats = synth.synthetic_cavp(B * world)[lo:hi].to(dev)
     x = synth.synthetic_xT(hi - lo, first_index=lo).to(dev)
@@ -243,7 +245,61 @@ def run_mode(precision, sd_dev, a, dev, rank, world, lo, hi, barrier, dump_ops="
         torch.distributed.all_gather_object(infos, dict(rank=rank, **seen, **{k: (round(v, 4) if isinstance(v, float) else v)
                                                                              for k, v in (dist_info or {}).items()}))
         dist_info = {"per_rank": infos}
-    return dict(model=model, dt=dt, prof=prof, sub=sub, stats=eng.plan_stats(), t_setup=t_setup, dist=dist_info, loop=loop)
+    plan_source = ("autotuned in this process (--autotune)" if a.autotune else
+                   (f"shipped table {os.path.relpath(eng.tuned_defaults, ROOT)}" if eng.tuned_defaults else
+                    "cost-model tiles (DF_TUNED_DEFAULTS=0 or no table for this device)"))
+    return dict(model=model, dt=dt, prof=prof, sub=sub, stats=eng.plan_stats(), t_setup=t_setup, dist=dist_info, loop=loop,
+                plan_source=plan_source)
+
+
+def batch8_block(model, dev, steps, warmup):
+    """BASELINE configs[2]'s step shape on the headline engine: sampler batch 8 (UNet batch 16), same loop body as the headline
+    (CFG forward with hoisted time embedding + DDIM update).  Reported beside the B = 4 headline: more rows per launch."""
+    B = 8
+    eng = model.engine
+    c = model.get_learned_conditioning(synth.synthetic_cavp(B).to(dev))
+    eng.set_context(torch.cat([torch.zeros_like(c), c]))
+    tb = DDIMTables(model.alphas_cumprod, 25)
+    ts = np.flip(tb.timesteps)
+    t_all = torch.tensor(ts.copy(), dtype=torch.float32, device=dev)[:, None].expand(25, B).contiguous()
+    eng.set_timesteps([float(v) for v in ts], B, 16, 64, True)
+    x = synth.synthetic_xT(B).to(dev)
+
+    def step(i, x):
+        i = i % 25
+        idx = 25 - i - 1
+        e = eng.unet_forward_cfg(x, t_all[i], 4.5, ts_index=i)
+        return E.ddim_update(x, e, tb.alphas[idx], tb.alphas_prev[idx], 0.0, tb.sqrt_one_minus_alphas[idx])[0]
+    for i in range(warmup):
+        x = step(i, x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        x = step(warmup + i, x)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = dt / steps * 1e3
+    return {"batch": B, "unet_batch": 2 * B, "steps": steps, "steps_per_s": round(steps / dt, 3), "ms_per_step": round(ms, 4),
+            "samples_steps_per_s": round(B * steps / dt, 2),
+            "step_tflops_algorithmic": round(GFLOP_PER_SAMPLE * 2 * B / ms, 2),
+            "frac_of_mfma_peak": round(GFLOP_PER_SAMPLE * 2 * B / ms / PEAK_BF16_TFLOPS, 4)}
+
+
+def untuned_child(a):
+    """`modes.untuned`: the same command in a child process with DF_TUNED_DEFAULTS=0 (the shipped table is imported once per
+    process and library, so the cost-model plans need a fresh process): headline loop only."""
+    import subprocess
+    env = dict(os.environ, DF_TUNED_DEFAULTS="0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(a.steps), "--warmup", str(a.warmup), "--batch",
+           str(a.batch), "--precision", a.precision, "--no-cpu-baseline", "--no-modes", "--no-vae", "--no-batch8"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {"steps_per_s": d["value"], "ms_per_step": d["ms_per_step"], "plan": d["config"].get("plan_source"),
+                "launches_per_step": d["plan"]["launches"], "sampler_loop_steps_per_s": (d.get("sampler_loop") or {}).get("steps_per_s")}
+    except Exception as ex:
+        return {"error": str(ex)[:200]}
 
 
 def vae_roofline(model, dev, B):
@@ -293,7 +349,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="samples per GPU (UNet batch is 2x this)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
-    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--autotune", action="store_true", help="re-tune the plans in this process instead of using the shipped table")
+    ap.add_argument("--no-autotune", action="store_true", help="(accepted for older command lines; not tuning is the default now)")
+    ap.add_argument("--no-batch8", action="store_true", help="skip the configs[2]-shape (B = 8) step block")
     ap.add_argument("--no-modes", action="store_true", help="skip the second operand type and the in-bench golden check")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE decode roofline block (profiling runs of the step only)")
     ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16"],
@@ -358,6 +416,7 @@ def main():
                        "time_embedding": ("inside every step" if a.no_time_hoist else
                                           "hoisted: all 25 timesteps by df_unet_set_timesteps before the loop, as DDIMSampler.sample "
                                           "does (depends on t only, like the context operands); a step does one table look-up"),
+                       "plan_source": main_run["plan_source"],
                        "weight_distribution": main_run["dist"],
                        "engine_setup_s": round(main_run["t_setup"], 3)},
             "step_tflops_algorithmic": round(GFLOP_PER_SAMPLE * N / ms_step, 2),
@@ -369,7 +428,10 @@ def main():
                          "family_ms_per_step": round(gemm_ms, 4),
                          "time_source": "HIP events around every op of the K steps on the launch stream, normalised so that the "
                                         "families sum to the un-instrumented ms_per_step (events add ~2 us per op)",
-                         "traffic": pmc_traffic(), "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command; not measured in this run)",
+                         "traffic": pmc_traffic("gemm_bytes_per_step"), "traffic_unit": "HBM-side bytes per STEP of this kernel family (2 x FETCH_SIZE + WRITE_SIZE)",
+                         "traffic_per_launch": pmc_traffic("gemm_bytes_per_launch"),
+                         "algorithmic_bytes_per_step": round((1.7186 + 0.4478 * B) * 1e9),
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command; not measured in this run)",
                          "peak_measured": measured_peak(), "peak_measured_source": "profiles/peaks.json (tools/peaks.py on an MI355X; not measured in this run)",
                          "mfma_busy_pmc": sq_counters(), "mfma_busy_pmc_source": "profiles/sq_counters.json (SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES) per kernel "
                                                                               "family over 4 denoise steps of this command; includes the matrix pipe's time on padded tiles, "
@@ -391,6 +453,8 @@ def main():
         }
         if world == 1 and not a.no_vae:
             out["vae_decode_roofline"] = vae_roofline(main_run["model"], dev, B)
+        if world == 1 and not a.no_batch8:
+            out["batch8"] = batch8_block(main_run["model"], dev, max(10, a.steps // 2), a.warmup)
         if world == 1 and not a.no_modes:
             # both MFMA operand types in ONE driver-run line: steps/s of the same workload + the north-star parity metric
             # (mel MAE of a 25-step DDIM sample against the reference's golden output) measured in this very process
@@ -405,6 +469,7 @@ def main():
                 del o
             except Exception as ex:      # a missing second build must not hide the headline number
                 modes[name[other]] = {"error": str(ex)[:200]}
+            modes["untuned"] = untuned_child(a)
             out["modes"] = modes
             out["parity_target"] = "north_star: mel-spec MAE < 1e-3 vs the CPU reference (absolute, mel units); " \
                                    "golden = tests/golden/g5_full_samplers.npz (reference output, B=1, seed 21)"

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const bf16_t* __rest
   // Long unrolled instantiations (D >= 128: 9-14 KB of code, run on 16 / 64-token maps where the whole kernel is a few k cycles of work):
   // the code behind the pc through the vector path, BEHIND the first operand requests (in front of them it delays the data: measured
   // slower for the D = 40 / 80 kernels, experiments/round5_measured_and_dropped.md section 16).
-  int code_touch = 0;
+  DfTouch code_touch = DfTouch();
   if constexpr (D >= 128) code_touch = df_entry_touch(0);
   sstore(0);
   if (ONES) {                       // row D of both V^T buffers = 1.0 (never overwritten: sstore skips it)

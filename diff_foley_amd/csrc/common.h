@@ -63,54 +63,83 @@ __device__ __forceinline__ void st_wt(float* p, float v) { asm volatile("global_
 template <class T> __device__ __forceinline__ void st_wt(T* p, const T& v) { *p = v; }
 #endif
 
-// ---- Kernel-entry touch (round 5): kernel-argument lines and the kernel's own code through the VECTOR memory path.
+// ---- Kernel-entry touch (round 5; rebuilt in round 6): kernel-argument lines and the kernel's own code through the VECTOR memory path.
 // A kernel's arguments live in the kernarg segment -- new memory at every launch, so the scalar cache and L2 miss on every 64-B
 // line of it -- and the compiler s_loads a field where it is first used: the prologue of a kernel with a large argument block
 // (GemmParams: 6 lines) is a CHAIN of scalar round trips, one per new line (six `s_load ...; s_waitcnt lgkmcnt(0)` groups in front
 // of the first operand request of a GEMM block).  Scalar loads cannot be issued ahead without being waited for (they return out
 // of order: every use waits for all of them -- fetching the whole struct in one batch measured +0.5 us per op IN THE PLAN although
 // it is 1 k cycles faster warm, experiments/kernarg_batched_fetch_and_prologue_split.patch.txt).  One vector load, lane i reading a
-// dword of line i, brings all lines into L2 side by side; nothing waits for it (its register stays reserved until
-// df_entry_touch_end at the end of the kernel), and the later scalar loads of the chain become L2 hits: +1.8 % end to end for the
-// GEMM kernels alone (same box, 270.7 -> 275.7 steps/s).
+// dword of line i, brings all lines into L2 side by side, and the later scalar loads of the chain become L2 hits: +1.8 % end to end
+// for the GEMM kernels alone (same box, 270.7 -> 275.7 steps/s).
 // The same for the kernel's own CODE: the next DF_CODE_TOUCH x 4 KB of instructions behind the program counter (the instruction
 // cache is cold at every kernel boundary and fetches line by line; +0.4 %).  Never past the code object: df_code_object_tail is a
 // zero-initialised variable of THIS translation unit's code object, i.e. it lives in .bss, the last section of the loaded image
 // (tools/check_code_touch.py verifies that layout for every built code object) -- lanes at or beyond it stay off.
+//
+// ROUND 6 -- the touch loads are ORDINARY loads the compiler can see.  Rounds 4-5 issued them from inline asm into one "+v" register
+// that "stays reserved until the final wait".  It does not: the compiler does not know a load is in flight to that register, so under
+// register pressure it copies the (to it, settled) value to an AGPR or another VGPR and re-uses the register -- for an operand-request
+// offset, an MFMA fragment, an accumulator -- and a touch load that returns later (a cold code line is an HBM miss, ~1-2 us) overwrites
+// live data.  In the shipped builds the copies sat > 1200 instructions behind the touch in eight GEMM instantiations (rare: a loaded
+// box, a second process); with GELU's erf on v_rcp_f32 (-DDF_ERF_RCP: shorter scalar-fallback code in every EPI_ANY kernel) the
+// allocator moved the copy of gemm_bf16_kernel<128,128,2,2,4,0,EPI_ANY> -- the cost-model plan's st.ffproj -- to 220 instructions
+// behind the touch and re-used the register for request offsets: every forward differed from the last and stored garbage / NaN a few
+// ops later (tools/race_hunt.py: deterministic with either half of the touch compiled out, or with the touch out of the MODE 0
+// kernels only; round 5 had blamed the GEGLU epilogue).  tools/check_touch_regs.py now scans the built code objects for any
+// hand-issued load whose destination is written or copied later; the touch itself no longer needs it: with a compiler-visible load
+// SIInsertWaitcnts puts the covering s_waitcnt in front of ANY instruction that reads or overwrites the register.
 #if !defined(DF_CODE_TOUCH)
 #define DF_CODE_TOUCH 4
 #endif
+struct DfTouch { int v[DF_CODE_TOUCH > 0 ? DF_CODE_TOUCH : 1]; };
+typedef const int __attribute__((address_space(1)))* df_gptr_t;      // global address space: global_load, not flat_load
 #if defined(__HIP_DEVICE_COMPILE__)
 static __device__ char df_code_object_tail[64];
-__device__ __forceinline__ int df_entry_touch(int kernarg_bytes) {
-  int v = 0;
-#if !defined(DF_NO_KERNARG_TOUCH)
-  // (inline asm: a C++ load would be waited for where the compiler next needs its register -- or, volatile, at once.  "+v": every
-  // touch lands in the ONE register that stays reserved until the final wait.)
-  const int lane = (int)threadIdx.x;
-  const unsigned long ka = reinterpret_cast<unsigned long>(__builtin_amdgcn_kernarg_segment_ptr()) + (unsigned long)lane * 64u;
-  if (lane < (kernarg_bytes + 63) / 64) asm volatile("global_load_dword %0, %1, off" : "+v"(v) : "v"(ka) : "memory");
-#if DF_CODE_TOUCH > 0
-  {
-    unsigned long pc;
-    asm volatile("s_getpc_b64 %0" : "=s"(pc));
-    const long room = (long)(reinterpret_cast<unsigned long>(&df_code_object_tail[0]) - pc);      // bytes of this image behind the pc
-    const int avail = room > (long)(DF_CODE_TOUCH * 4096) ? DF_CODE_TOUCH * 4096 : (int)room;
+__device__ __forceinline__ DfTouch df_entry_touch(int kernarg_bytes) {
+  DfTouch t;
 #pragma unroll
-    for (int k = 0; k < DF_CODE_TOUCH; ++k) {
-      const int off = (k * 64 + lane) * 64;
-      const unsigned long a = pc + (unsigned long)off;
-      if (lane < 64 && off + 64 <= avail) asm volatile("global_load_dword %0, %1, off" : "+v"(v) : "v"(a) : "memory");
-    }
+  for (int k = 0; k < (DF_CODE_TOUCH > 0 ? DF_CODE_TOUCH : 1); ++k) t.v[k] = 0;
+#if !defined(DF_NO_KERNARG_TOUCH)
+  const int lane = (int)threadIdx.x;
+  const int nka = (kernarg_bytes + 63) / 64;        // kernel-argument lines: lanes [0, nka) of the first load
+  const char* const kseg = reinterpret_cast<const char*>(__builtin_amdgcn_kernarg_segment_ptr());
+#if DF_CODE_TOUCH > 0
+  unsigned long pc;
+  asm volatile("s_getpc_b64 %0" : "=s"(pc));
+  const long room = (long)(reinterpret_cast<unsigned long>(&df_code_object_tail[0]) - pc);      // bytes of this image behind the pc
+  const int avail = room > (long)(DF_CODE_TOUCH * 4096) ? DF_CODE_TOUCH * 4096 : (int)room;
+#pragma unroll
+  for (int k = 0; k < DF_CODE_TOUCH; ++k) {
+    // load k: lane i reads a dword of code line k * 64 + i; in load 0 the first nka lanes read the kernel-argument lines instead
+    const int off = (k * 64 + lane) * 64;
+    const bool is_ka = (k == 0) && lane < nka;
+#if defined(DF_NO_KERNARG_LINES)
+    const bool ka_on = false;
+#else
+    const bool ka_on = true;
+#endif
+    // (a GLOBAL-segment load with the default cache policy: a generic pointer would make it a FLAT load -- counted in lgkmcnt too,
+    // so the first scalar-load wait of the prologue would wait for the code line -- and `nt` would mark the lines evict-first in L2)
+    const unsigned long a = (is_ka && ka_on) ? reinterpret_cast<unsigned long>(kseg) + (unsigned long)(lane * 64) : pc + (unsigned long)off;
+    const bool on = lane < 64 && ((is_ka && ka_on) || (!is_ka && off + 64 <= avail));
+    if (on) t.v[k] = *reinterpret_cast<df_gptr_t>(a);
   }
+#else
+  if (lane < nka) t.v[0] = *reinterpret_cast<df_gptr_t>(reinterpret_cast<unsigned long>(kseg) + (unsigned long)(lane * 64));
 #endif
+  asm volatile("" ::: "memory");      // the loads stay in front of everything below (nothing may sink them to their use)
 #endif
-  return v;
+  return t;
 }
-__device__ __forceinline__ void df_entry_touch_end(int v) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(v) : "memory"); }      // (long since landed)
+// The one use of the loaded dwords: an empty asm that takes them as operands -- the compiler's own wait sits in front of it.
+__device__ __forceinline__ void df_entry_touch_end(const DfTouch& t) {
+#pragma unroll
+  for (int k = 0; k < (DF_CODE_TOUCH > 0 ? DF_CODE_TOUCH : 1); ++k) asm volatile("" ::"v"(t.v[k]) : "memory");
+}
 #else     // host pass: the kernels' bodies are parsed, never run
-__device__ __forceinline__ int df_entry_touch(int) { return 0; }
-__device__ __forceinline__ void df_entry_touch_end(int) {}
+__device__ __forceinline__ DfTouch df_entry_touch(int) { return DfTouch(); }
+__device__ __forceinline__ void df_entry_touch_end(const DfTouch&) {}
 #endif
 
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
@@ -151,14 +180,17 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // the ~50-instruction libm erff -- the GEGLU epilogue evaluates it for every FF hidden unit.
 __device__ __forceinline__ float erf_as(float x) {
   const float ax = fabsf(x);
-  // (__frcp_rn is the correctly rounded reciprocal, i.e. a whole IEEE division per hidden unit -- a quarter of the GEGLU epilogue's
-  // VALU instructions.  v_rcp_f32 in its place measured +0.55 % and passed every kernel test, but the full bf16 model then stored
-  // non-finite values from st.ffproj on in the second step of a B = 4 DDIM run (tests/test_path_gpu.py::test_full_batch4_matches_batch1;
-  // tools/nan_probe.py); the cause was not found in the time left, so the division stays: experiments/round5_measured_and_dropped.md 20)
-#if defined(DF_ERF_RCP)          /* experiment switch, see the comment above */
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-#else
+  // The reciprocal is the hardware's v_rcp_f32 (1 ulp), not __frcp_rn: the correctly rounded form compiles to a whole IEEE division
+  // per hidden unit (v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup: 128 of the 584 VALU instructions of the persistent
+  // GEGLU kernel's epilogue block; with v_rcp_f32 the compiler also packs the block: 261), + 0.55 % end to end (round 5, same box).
+  // Round 5 had to revert it: the full bf16 model then stored garbage / NaN a few ops behind a generic GEGLU launch, at a different
+  // op from run to run.  Round 6 found the cause, and it was not this arithmetic: the kernel-entry touch loads of that era landed in
+  // a register the compiler had re-used (see df_entry_touch above); the shorter code only moved the register allocation of
+  // st.ffproj's kernel.  -DDF_ERF_DIV compiles the division back in (A/B).
+#if defined(DF_ERF_DIV)
   const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+#else
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
 #endif
   float poly = 1.061405429f;
   poly = poly * t - 1.453152027f;

@@ -103,6 +103,10 @@ struct Plan {
   float* Etab = nullptr;         // [etab_S][etot]
   float* ttab = nullptr;         // [etab_S][t_rows] timesteps as the time ops read them
   int etab_S = 0, etab_cap = 0;
+  // launch accounting (df_unet_plan_stats): t.lookup launches nothing when its row broadcast rides in x.pack (tl_merged), and
+  // cfg.combine (op_cfgc) launches nothing while out.conv (op_outconv) runs split-K with the guided reduce
+  bool tl_merged = false;
+  long op_cfgc = -1, op_outconv = -1;
   std::string name;              // cache key (debug labels)
   void* chk_list = nullptr;      // debug checksums: device array of (pointer, 32-bit words) of every workspace block
   int chk_n = 0;
@@ -1382,6 +1386,7 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
     // embedding depends on t only, so a sampler computes it for all S steps before the loop, like the context operands
     pl->op_tl = (long)pl->ops.size();
     pl->E = E; pl->etot = etot; pl->e_rows = N; pl->t_rows = B_ext;
+    pl->tl_merged = step_merge;
     Plan* plp = pl;
     b.other("t.lookup", [=](hipStream_t s, const RunArgs& a) {
       if (a.ts_index < 0) return hipSuccess;
@@ -1562,6 +1567,8 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
     const size_t oci = pl->ops.size() - 1;
     Plan* plq = pl;
     const long n = (long)(N / 2) * u.out_channels * HW;
+    pl->op_outconv = (long)oci;
+    pl->op_cfgc = (long)pl->ops.size();
     b.other("cfg.combine", [=](hipStream_t s, const RunArgs& ar) {
       if (plq->ops[oci].cfg_ext && plq->ops[oci].gp.splitk > 1) return hipSuccess;
       return launch_cfg_combine(e2, ar.out, n, ar.scale, s);
@@ -3371,6 +3378,8 @@ int df_unet_plan_stats(df_ctx* c, int64_t* n_launches, double* gemm_flops, doubl
       const Plan* lp = c->last_unet;
       // the last run took either the time ops [op_t0, op_tl) or the table look-up op_tl, never both
       if (lp->op_tl >= 0 && (c->last_unet_hoisted ? ((long)i >= lp->op_t0 && (long)i < lp->op_tl) : (long)i == lp->op_tl)) continue;
+      if ((long)i == lp->op_tl && lp->tl_merged) continue;      // hoisted: the look-up is part of x.pack's launch
+      if ((long)i == lp->op_cfgc && lp->op_outconv >= 0 && lp->ops[lp->op_outconv].cfg_ext && lp->ops[lp->op_outconv].gp.splitk > 1) continue;
       n += 1 + (lp->ops[i].is_gemm && lp->ops[i].gp.splitk > 1 && !lp->ops[i].defer);      // (a deferred reduce runs inside the GroupNorm that follows)
     }
     *n_launches = n;

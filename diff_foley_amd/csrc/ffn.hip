@@ -30,7 +30,7 @@ __device__ __forceinline__ void geglu_persistent_body(const GemmParams& p);
 template <int BM, int WGM, int WGN, int NST, int LNS, bool DBG>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void geglu_persistent_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const int ka = gemm_kernarg_touch();
+  const DfTouch ka = gemm_kernarg_touch();
   df_fp16_hw_clamp();           // the epilogue packs with pack_bf2_hw
   geglu_persistent_body<BM, WGM, WGN, NST, LNS, DBG>(p);
   gemm_kernarg_touch_end(ka);

@@ -77,8 +77,8 @@ struct GemmParams {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // kernel-argument / own-code touch of the GEMM kernels: common.h df_entry_touch
-__device__ __forceinline__ int gemm_kernarg_touch() { return df_entry_touch((int)sizeof(GemmParams)); }
-__device__ __forceinline__ void gemm_kernarg_touch_end(int v) { df_entry_touch_end(v); }
+__device__ __forceinline__ DfTouch gemm_kernarg_touch() { return df_entry_touch((int)sizeof(GemmParams)); }
+__device__ __forceinline__ void gemm_kernarg_touch_end(const DfTouch& v) { df_entry_touch_end(v); }
 #endif
 
 enum GemmTile {

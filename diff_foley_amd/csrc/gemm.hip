@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_cfg_kernel(GemmParams p) {
 template <int SK>
 __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const int ka = gemm_kernarg_touch();      // kernel-argument lines (and the code behind the pc) into L2 beside the first scalar loads
+  const DfTouch ka = gemm_kernarg_touch();      // kernel-argument lines (and the code behind the pc) into L2 beside the first scalar loads
 #endif
   const int n4 = p.N >> 2;
   const long total = (long)p.M * n4;

@@ -529,6 +529,12 @@ __device__ __forceinline__ void epilogue_block(const GemmParams& p, int z, int b
   }
 }
 
+// tools (tools/race_hunt.py): -DDF_HUNT=1 drains every LDS-DMA request at each K-step boundary of the symmetric generic kernel
+#if defined(DF_HUNT) && (DF_HUNT & 1)
+#define DF_HUNT_VM(VM) 0
+#else
+#define DF_HUNT_VM(VM) (VM)
+#endif
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
@@ -582,7 +588,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p);
 template <int BM, int BN, int WGM, int WGN, int NST, int MODE, int EPI, int NSTB = NST, int PS = 0>
 __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void gemm_bf16_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // host pass only needs the launch stub (LDS-DMA builtins do not parse there)
-  const int ka = gemm_kernarg_touch();      // the kernel-argument lines into L2, beside the first scalar loads (gemm.h)
+  const DfTouch ka = gemm_kernarg_touch();      // the kernel-argument lines into L2, beside the first scalar loads (gemm.h)
   gemm_bf16_body<BM, BN, WGM, WGN, NST, MODE, EPI, NSTB, PS>(p);
   gemm_kernarg_touch_end(ka);
 #endif
@@ -901,7 +907,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p) {
 #define DF_RING_SYNC(VM)                                                                          \
   {                                                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* my reads of the slot about to be refilled are done */ \
-    if constexpr (PS == 0) wait_vmcnt<(VM)>();   /* next tile landed: <= NST-2 younger tiles of this wave in flight */ \
+    if constexpr (PS == 0) wait_vmcnt<DF_HUNT_VM(VM)>();   /* next tile landed: <= NST-2 younger tiles of this wave in flight */ \
     __builtin_amdgcn_s_barrier();    /* all parts of it visible; everyone is done with the current slot */  \
   }
   // (A three-fragment-set form with pinned issue order was measured slower for this kernel: 221 vs 224.5 steps/s.)
@@ -1179,7 +1185,7 @@ __device__ __forceinline__ void conv3x3_halo_body(const GemmParams& p);
 template <int BM, int BN, int WGM, int WGN, int NSTW, int EPI, int PS = 0>
 __global__ __launch_bounds__(64 * WGM * WGN * (1 + PS)) void conv3x3_halo_kernel(GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const int ka = gemm_kernarg_touch();
+  const DfTouch ka = gemm_kernarg_touch();
   conv3x3_halo_body<BM, BN, WGM, WGN, NSTW, EPI, PS>(p);
   gemm_kernarg_touch_end(ka);
 #endif
@@ -1300,7 +1306,11 @@ __device__ __forceinline__ void conv3x3_halo_body(const GemmParams& p) {
     }
     atab[hr] = e;
   }
-  __syncthreads();
+  // (not __syncthreads(): its release fence waits for every outstanding vector-memory operation the compiler knows of -- since
+  // round 6 that includes the kernel-entry touch loads, i.e. a cold code line in front of the first operand request.  The table
+  // is LDS: the writers' lgkmcnt(0) + the barrier order it for every reader.)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   unsigned a_off[MAXAP];
 #pragma unroll
   for (int i = 0; i < MAXAP; ++i) {

@@ -11,6 +11,8 @@ Reference: diff_foley/models/diffusion/ddim.py:58-273, plms.py:60-236,
 dpm_solver/sampler.py:24-156 + dpm_solver/dpm_solver.py:504-549,755-810,1071-1105, ddpm.py:1083-1268.
 """
 import numpy as np
+import warnings
+
 import torch
 
 from . import engine as E
@@ -45,6 +47,12 @@ def reject_unsupported(sampler, kwargs, extra=None):
         if k in kwargs and kwargs[k] is not None and kwargs[k] != default:
             raise NotImplementedError(f"{sampler}: {k}={kwargs[k]!r} is not supported by the MI355X sampling path "
                                       f"(only the default {default!r}); see DESIGN.md section 1")
+
+
+def _is_table_error(ex):
+    """The engine's two messages for a missing / outgrown hoisted timestep table (csrc/engine.hip unet_forward_ts)."""
+    msg = str(ex)
+    return "no timestep table" in msg or "outside the table" in msg or "hoistable" in msg
 
 
 class _Inpaint:
@@ -103,7 +111,9 @@ class _Guided:
             try:      # an optimisation, never a requirement: a UNet configuration without a hoistable time embedding
                 self.eng.set_timesteps([float(v) for v in timesteps], B, H, W, self.cfg)      # keeps the in-step t path
                 self.hoisted = True
-            except RuntimeError:
+            except RuntimeError as ex:
+                if not _is_table_error(ex):      # anything else (bad shapes, a sticky HIP error) is the caller's to see
+                    raise
                 self.hoisted = False
 
     def reclaim_context(self):
@@ -121,9 +131,14 @@ class _Guided:
             return fwd(None)
         try:
             return fwd(k)
-        except RuntimeError:
+        except RuntimeError as ex:
             # the plan that owned the timestep table was rebuilt in the middle of the sample (plan-cache eviction, a callback that
-            # re-finalised the engine): the in-step path computes the same embedding from t, bit-identically
+            # re-finalised the engine): the in-step path computes the same embedding from t, bit-identically.  ONLY that case
+            # falls back (the engine names it in its message); every other engine error propagates.
+            if not _is_table_error(ex):
+                raise
+            warnings.warn("diff_foley_amd: the hoisted time-embedding table was dropped in the middle of a sample() call "
+                          f"({ex}); the remaining steps compute the embedding inside the step", RuntimeWarning, stacklevel=2)
             self.hoisted = False
             return fwd(None)
 

@@ -888,3 +888,62 @@ def test_debug_checksums_and_tune_cache_round_trip(P):
     assert eng.tune_cache_export() == text
     with pytest.raises(RuntimeError):
         eng.tune_cache_import(b"bogus_key 999 1 0\n")   # tile id out of range
+
+
+def test_full_cost_model_plan_is_reproducible_run_to_run():
+    """Regression test of the round-6 root cause (csrc/common.h df_entry_touch): the FULL bf16 model on the cost-model plans
+    (DF_TUNED_DEFAULTS=0 -- the plan whose st.ffproj kernel exposed it), with the short GELU epilogue (v_rcp_f32 erf, the build
+    that failed in round 5), repeated CFG forwards under per-op workspace checksums: every repetition must leave the very bytes
+    of the first one after every op, and every output must be finite.  (tools/race_hunt.py in a child process: the shipped plan
+    table is imported once per process, so the cost-model plans need their own.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DF_TUNED_DEFAULTS="0", HUNT_PREC="bf16")
+    env.pop("DF_LIB_OVERRIDE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "race_hunt.py"), "6"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["diverged"] == 0 and d["nonfinite_outputs"] == 0, d
+
+
+def test_facade_runs_the_shipped_plan_table(P):
+    """The drop-in never calls a tuning step (inference/diff_foley_inference.ipynb:80-95 has none): LatentDiffusion(...).cuda()
+    imports the shipped table of this GPU model (diff_foley_amd/tuned/, engine.load_tuned_defaults) and every GEMM of the
+    BASELINE configs[1] step then runs the (tile, split-K) the table holds for its shape -- the kernels bench.py times."""
+    import csv
+    import os
+    from diff_foley_amd import synth
+    m = P.LatentDiffusion(**P.stage2_config())          # default precision, no autotune call anywhere
+    m.load_state_dict(full_state_dict())
+    m.cuda()
+    eng = m.engine
+    if os.environ.get("DF_TUNED_DEFAULTS", "1") == "0":
+        pytest.skip("DF_TUNED_DEFAULTS=0")
+    assert eng.tuned_defaults and os.path.exists(eng.tuned_defaults), "no shipped table for this device"
+    table = {}
+    for line in open(eng.tuned_defaults):
+        key, tile, sk, gm = line.split()
+        f = key.split("_")
+        table.setdefault(tuple(int(v) for v in f[:4]), set()).add((int(tile), int(sk)))
+    B = 4
+    c = m.get_learned_conditioning(synth.synthetic_cavp(B).cuda())
+    xT = synth.synthetic_xT(B).cuda()
+    m.sample_log_diff_sampler(c, B, "DDIM", 2, unconditional_guidance_scale=4.5, unconditional_conditioning=torch.zeros_like(c), x_T=xT)
+    eng.profile_begin()
+    z, _ = m.sample_log_diff_sampler(c, B, "DDIM", 2, unconditional_guidance_scale=4.5, unconditional_conditioning=torch.zeros_like(c), x_T=xT)
+    eng.profile_end()
+    path = "/tmp/df_shipped_plan_ops.csv"
+    eng.profile_dump(path)
+    rows = [r for r in csv.DictReader(open(path)) if int(r["K"]) > 0 and r["tag"] != "out.conv"]
+    assert len(rows) > 200
+    missing = [r for r in rows if (int(r["M"]), int(r["N"]), int(r["K"]), int(r["taps"])) not in table]
+    assert not missing, missing[:3]
+    off = [r for r in rows if (int(r["tile"]), int(r["splitk"])) not in table[(int(r["M"]), int(r["N"]), int(r["K"]), int(r["taps"]))]]
+    assert not off, off[:3]
+    assert torch.isfinite(z).all()
+    # the tuned plan uses the producer-specialised / persistent tiles; the cost model never picks them
+    assert any(int(r["tile"]) >= 18 for r in rows)
