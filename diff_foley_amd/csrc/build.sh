@@ -11,7 +11,7 @@ cd "$(dirname "$0")"
 # family -- not the GEMMs, whose one argument is a struct) get them in SGPRs at wavefront launch instead of through s_load from the
 # cold scalar cache: GroupNorm family 0.596 -> 0.571 ms per step, +0.6 % end to end on the same box (round 4).
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-kernarg-preload-count=16"
-SRCS="gemm gemm_m0a gemm_m0b gemm_m1 gemm_m2 gemm_m3 gemm_halo gemm_ps gemm_ps2 ffn elementwise attention backward cavp vocoder diag engine"
+SRCS="gemm gemm_m0a gemm_m0b gemm_m1 gemm_m2 gemm_m3 gemm_halo gemm_ps gemm_ps2 ffn ffn_wide elementwise attention backward cavp vocoder diag engine"
 mkdir -p build/bf16 build/f16
 pids=()
 for v in bf16 f16; do

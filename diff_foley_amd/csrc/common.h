@@ -13,11 +13,13 @@ typedef uint16_t bf16_t;  // raw operand bits (bf16 or fp16)
 typedef _Float16 op_scalar;
 #define DF_OPERAND_NAME "f16"
 #define DF_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define DF_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 __device__ __forceinline__ float op_clamp(float f) { return __builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f); }
 #else
 typedef __bf16 op_scalar;
 #define DF_OPERAND_NAME "bf16"
 #define DF_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define DF_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 __device__ __forceinline__ float op_clamp(float f) { return f; }
 #endif
 typedef __attribute__((ext_vector_type(8))) op_scalar bf16x8;

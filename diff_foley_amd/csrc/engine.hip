@@ -437,6 +437,27 @@ struct df_ctx {
     *bb = (const float*)packed[kb];
   }
 
+  // The LayerNorm-folded GEGLU projection `key` (w_ln_stack with geglu = true: rows in (32 x | 32 gate) groups) once more in the
+  // 320-column packing of the wide tiles (ffn_wide.hip): a device-side row permutation of the packed operand -- needs no fp32
+  // data, so a rank that imported the packed blob builds it the same way.
+  void w_ln_w320(const std::string& key, int rows, int K, const bf16_t** w, const float** cs, const float** bb) {
+    const std::string kw = key + "#lnw", kc = key + "#lncs", kb = key + "#lnbb";
+    const std::string kw3 = key + "#lnw320", kc3 = key + "#lncs320", kb3 = key + "#lnbb320";
+    if (!packed.count(kw3)) {
+      if (!packed.count(kw) || !packed.count(kc) || !packed.count(kb)) fail("w_ln_w320 %s: the (32 | 32) packing does not exist", key.c_str());
+      bf16_t* wo = (bf16_t*)pmalloc((size_t)rows * K * 2);
+      float* co = (float*)pmalloc((size_t)rows * 4);
+      float* bo = (float*)pmalloc((size_t)rows * 4);
+      HIPCHK(launch_pack_w320((const bf16_t*)packed[kw], (const float*)packed[kc], (const float*)packed[kb], wo, co, bo, rows, K, pack_stream));
+      packed[kw3] = wo;
+      packed[kc3] = co;
+      packed[kb3] = bo;
+    }
+    *w = (const bf16_t*)packed[kw3];
+    *cs = (const float*)packed[kc3];
+    *bb = (const float*)packed[kb3];
+  }
+
   void w_geglu(const std::string& prefix, const bf16_t** w, const float** b) {
     const std::string kw = prefix + ".weight#geglu", kb = prefix + ".bias#geglu";
     auto it = packed.find(kw);
@@ -1021,6 +1042,12 @@ struct Builder {
       out_b16(g, gl, 4 * C);
       ln_fold(g, cs, bb);
       g.geglu = 1;
+      if ((8 * C) % 320 == 0) {      // the wide tiles' packing of the same operand (TILE_WGEGLU_*; the tuner decides who runs)
+        const bf16_t* w3;
+        const float *cs3, *bb3;
+        c->w_ln_w320(nm(tb + ".ff.net.0.proj"), 8 * C, C, &w3, &cs3, &bb3);
+        g.W_w320 = w3; g.cs_w320 = cs3; g.bias_w320 = bb3;
+      }
       gemm(g, 1, "st.ff1");
     }
     static const bool no_ffproj = getenv("DF_NO_FFPROJ") && atoi(getenv("DF_NO_FFPROJ"));
@@ -3563,6 +3590,26 @@ int df_test_geglu(const uint16_t* A, const uint16_t* W, const void* stats, const
     g.splitk = 1;
     g.dbg = dbg;
     if (dbg & 64) g.partial = test_partial((size_t)1024 * 32 * 8);     // per-block clock stamps (read back with df_test_scratch_read)
+    if (gemm_tile_is_wgeglu(tile)) {      // the wide tiles read the 320-column packing: permuted here, per call (test entry)
+      if (N1 % 320 != 0) fail("tile %d: N = %d is not a multiple of 320", tile, N1);
+      static void* buf = nullptr;
+      static size_t cap = 0;
+      const size_t need = (size_t)N1 * K * 2 + (size_t)N1 * 8 + 512;
+      if (need > cap) {
+        if (buf) HIPCHK(hipFree(buf));
+        HIPCHK(hipMalloc(&buf, need));
+        cap = need;
+      }
+      uint16_t* w3 = (uint16_t*)buf;
+      float* cs3 = (float*)((char*)buf + (((size_t)N1 * K * 2 + 255) & ~(size_t)255));
+      float* bb3 = cs3 + N1;
+      static const void* packed_from = nullptr;
+      if (!(dbg & 128) || packed_from != (const void*)W)      // dbg bit 7 (timing tools): keep the packing made from this W by the last call
+        HIPCHK(launch_pack_w320(W, cs, bias, w3, cs3, bb3, N1, K, (hipStream_t)stream));
+      packed_from = (const void*)W;
+      g.dbg = dbg & ~128;
+      g.W_w320 = w3; g.cs_w320 = cs3; g.bias_w320 = bb3;
+    }
     if (!gemm_tile_valid(g, tile, 1, 1)) fail("tile %d not valid for this GEGLU projection", tile);
     HIPCHK(launch_gemm(g, tile, 1, (hipStream_t)stream));
   });

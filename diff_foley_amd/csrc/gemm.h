@@ -47,6 +47,9 @@ struct GemmParams {
   // over 64-column slots of the fp32 tensor the operand copy was made from (ln_C columns in total).
   const float2* ln_stats; int ln_slots; int ln_C; float ln_eps;
   const float* ln_cs;                // [N] column sums of the (operand-rounded) gamma-scaled weights
+  // The same GEGLU projection in the 320-column packing of the wide tiles (ffn_wide.hip, round 6): weight rows, column sums and
+  // folded bias permuted so that every 160-row half of a 320-row tile is [80 x rows | their 80 gate rows].  null = not packed.
+  const uint16_t* W_w320; const float* cs_w320; const float* bias_w320;
   // Row-block weights: rows [i*w_rows, (i+1)*w_rows) multiply W + i*w_bs (one weight matrix per SAMPLE in one launch: the
   // cross-attention GEMMs whose "weights" are precomputed from each sample's context).  w_rows % BM == 0.
   int w_rows;
@@ -111,14 +114,20 @@ enum GemmTile {
   // in order -- its LDS-DMA requests (~130 cycles each), its MFMAs and its GELU arithmetic are one serial stream (1.8 k cycles per
   // K step for 512 of MFMA, 6.5 k of epilogue arithmetic per tile in the 4-wavefront form, whatever the co-resident block does:
   // the DF_PG_STAGGER experiment).  Twice the wavefronts halve every one of those streams.  31: 20 row-statistics slots (C = 1280)
-  TILE_PGEGLU_128_W8 = 30, TILE_PGEGLU_128_W8L = 31, TILE_ALL = 32
+  TILE_PGEGLU_128_W8 = 30, TILE_PGEGLU_128_W8L = 31,
+  // WIDE GEGLU tiles (ffn_wide.hip, round 6): BM x 320 output columns (5 * 2^6: the model's channel counts are 5 * 2^k, so N = 8C
+  // is always a multiple of 320 and (8192, 2560) / (2048, 5120) / (512, 10240) are EXACTLY 256 tiles of 256 / 128 / 64 rows -- one
+  // per CU, no second round), 8 wavefronts as 4 (M) x 2 (N) on v_mfma_f32_16x16x32 fragments (80-column x / gate halves), two per
+  // SIMD, one whole K panel per block, epilogue out of the accumulators.  Half the L2 -> LDS bytes per FLOP of the 128 x 128 tiles.
+  TILE_WGEGLU_256 = 32, TILE_WGEGLU_128 = 33, TILE_WGEGLU_64 = 34, TILE_ALL = 35
 };
 static inline bool gemm_tile_is_pgeglu(int cfg) { return cfg == TILE_PGEGLU_128 || cfg == TILE_PGEGLU_64 || cfg == TILE_PGEGLU_128_W8 || cfg == TILE_PGEGLU_128_W8L; }
+static inline bool gemm_tile_is_wgeglu(int cfg) { return cfg >= TILE_WGEGLU_256 && cfg <= TILE_WGEGLU_64; }
 static inline bool gemm_tile_is_ps(int cfg) { return (cfg >= TILE_PS_256x128 && cfg <= TILE_PS2_128x128) || (cfg >= TILE_PS_64x64 && cfg <= TILE_PS_64x128); }
 // ring depths (activation ring, weight ring) of the generic tiles; 0 for halo tiles
 static inline void gemm_tile_rings(int cfg, int* nsta, int* nstb) {
-  static const int a[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3, 0, 0, 0, 4, 4, 4, 4, 2, 2};
-  static const int b[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3, 0, 0, 0, 4, 4, 4, 4, 2, 2};
+  static const int a[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3, 0, 0, 0, 4, 4, 4, 4, 2, 2, 2, 2, 3};
+  static const int b[TILE_ALL] = {4, 5, 5, 4, 4, 0, 0, 0, 3, 3, 2, 2, 2, 2, 2, 0, 0, 0, 3, 4, 4, 2, 3, 0, 0, 0, 4, 4, 4, 4, 2, 2, 2, 2, 3};
   *nsta = a[cfg];
   *nstb = b[cfg];
 }
@@ -140,7 +149,8 @@ static inline void gemm_tile_dims(int cfg, int* bm, int* bn) {
                                      {128, 64},  {256, 64}, {128, 128}, {128, 256}, {256, 128},
                                      {128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128},
                                      {128, 64}, {256, 64}, {192, 64}, {256, 128}, {128, 128}, {128, 128}, {128, 128}, {64, 128},
-                                     {192, 64}, {128, 64}, {128, 128}, {64, 64}, {64, 64}, {128, 64}, {64, 128}, {128, 128}, {128, 128}};
+                                     {192, 64}, {128, 64}, {128, 128}, {64, 64}, {64, 64}, {128, 64}, {64, 128}, {128, 128}, {128, 128},
+                                     {256, 320}, {128, 320}, {64, 320}};
   *bm = d[cfg][0];
   *bn = d[cfg][1];
 }
@@ -150,3 +160,5 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk);
 
 // batch > 1 and splitk > 1 are mutually exclusive.
 hipError_t launch_gemm(const GemmParams& p, int tile_cfg, int batch, hipStream_t stream);
+// (32 x | 32 gate) GEGLU packing (rows of K operand values, column sums, folded bias) -> the wide tiles' 320-column packing (ffn_wide.hip)
+hipError_t launch_pack_w320(const uint16_t* w, const float* cs, const float* bb, uint16_t* wo, float* cso, float* bbo, int N, int K, hipStream_t s);

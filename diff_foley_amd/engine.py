@@ -219,6 +219,8 @@ def tuned_defaults_path(device, precision):
     """Package-data file with the autotuner's choices for this GPU model: tuned/<arch>_<CUs>cu_<precision>.txt
     (e.g. gfx950_256cu_fp16.txt; text lines 'key tile splitk gm', the df_tune_cache_export format).  None when this build
     ships no table for the device."""
+    if os.environ.get("DF_TUNED_TABLE"):          # tools: A/B of two tables on one box
+        return os.environ["DF_TUNED_TABLE"]
     pr = torch.cuda.get_device_properties(device)
     arch = getattr(pr, "gcnArchName", "").split(":")[0] or "unknown"
     path = os.path.join(TUNED_DIR, f"{arch}_{pr.multi_processor_count}cu_{precision}.txt")

@@ -220,7 +220,10 @@ class LatentDiffusion:
         H, W = (int(isz[0]), int(isz[1])) if isinstance(isz, (list, tuple)) and len(isz) == 2 else (16, 64)
         if H % 8 or W % 8:
             H, W = 16, 64
-        T = int(self.cond_cfg.get("seq_len", 32) or 32)
+        # context frames: the notebook's window length (truncate_len = 32, ipynb cell 13), never more than the condition stage's
+        # positional table holds.  (A longer probe context would also build -- and later export -- the K / V^T cross-attention
+        # packings no sampling call of the product shapes uses.)
+        T = min(32, int(self.cond_cfg.get("seq_len", 32) or 32))
         g = torch.Generator(device="cpu").manual_seed(999)
         x = torch.randn(2, int(self.unet_cfg["in_channels"]), H, W, generator=g).to(self.device)
         c = torch.randn(2, T, int(self.unet_cfg["context_dim"]), generator=g).to(self.device)

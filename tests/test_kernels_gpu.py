@@ -513,3 +513,52 @@ def test_upsample_conv_phase_decomposed(tile, splitk, NB, H, W, Cin, Cout):
     packed = scratch.float().cpu().reshape(2, 2, Cout, 2, 2, Cin)
     assert torch.equal(packed, w4)                                           # the packing kernel, bit for bit
 
+
+
+# ------------------------------------------------------------------------------------------- wide GEGLU tiles (ffn_wide.hip, round 6)
+def _geglu_ref(x, W, cs, bias, eps=1e-5):
+    """LayerNorm-folded GEGLU projection on the (32 x | 32 gate) packing, fp32: the arithmetic of attention_openai.py:37-64 behind
+    norm3 (:215) as the engine folds it -- rstd (A . W - mean cs) + b, then x * gelu(gate) with the exact-erf GELU."""
+    M, C = x.shape
+    A = bf(x).float()
+    mean = x.mean(1, keepdim=True)
+    rstd = torch.rsqrt((x * x).mean(1, keepdim=True) - mean * mean + eps)
+    v = rstd * (A @ bf(W).float().t() - mean * cs[None]) + bias[None]
+    v = v.view(M, -1, 2, 32)                       # [M][group][x | gate][32]
+    return (v[:, :, 0] * F.gelu(v[:, :, 1])).reshape(M, -1)
+
+
+@pytest.mark.parametrize("tile", [32, 33, 34, 30, 22])      # the three wide tiles; 30 / 22: the persistent kernel on the same data
+@pytest.mark.parametrize("M,C", [(512, 320), (256, 640), (200, 1280), (64, 320), (1024, 320)])
+def test_geglu_projection_wide_tiles(tile, M, C):
+    """ffn_wide.hip against fp32: ragged last row tile (M = 200), one row tile (M = 64), 5 / 10 / 20 K steps, several column tiles;
+    the 320-column packing is made from the (32 | 32) one by launch_pack_w320 inside the test entry, as the engine does."""
+    E = _eng()
+    L = E.lib(PREC)
+    N1 = 8 * C
+    x = rnd((M, C), 11) * 1.5 + 0.3
+    W = rnd((N1, C), 12) * 0.06
+    cs = bf(W).float().sum(1)                      # column sums of the operand-rounded rows, as the packer computes them
+    bias = rnd((N1,), 13) * 0.2
+    xs = x.view(M, C // 64, 64)
+    stats = torch.stack([xs.sum(2), (xs * xs).sum(2)], dim=-1).contiguous()      # per-row partials over 64-column slots
+    ref = _geglu_ref(x, W, cs, bias)
+    out = torch.full((M, N1 // 2), float("nan"), device="cuda", dtype=odt())
+    xd, wd, sd, cd, bd = bf(x).cuda(), bf(W).cuda(), stats.cuda(), cs.cuda(), bias.cuda()      # (kept alive: the ABI takes raw pointers)
+    rc = L.df_test_geglu(ptr(xd), ptr(wd), ptr(sd), ptr(cd), ptr(bd), ptr(out), M, C, N1, tile, 0, stream())
+    if rc != 0 and tile in (30,) and C > 640:
+        pytest.skip("tile 30 holds 10 row-statistics slots")
+    assert rc == 0, L.df_last_error()
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, ref) < (4e-3 if PREC == "bf16" else 1.5e-3)
+    # a second launch with other weights at the same addresses re-packs (the test entry permutes per call)
+    W2 = rnd((N1, C), 14) * 0.06
+    cs2 = bf(W2).float().sum(1)
+    wd.copy_(bf(W2))
+    cd.copy_(cs2)
+    rc = L.df_test_geglu(ptr(xd), ptr(wd), ptr(sd), ptr(cd), ptr(bd), ptr(out), M, C, N1, tile, 0, stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), _geglu_ref(x, W2, cs2, bias)) < (4e-3 if PREC == "bf16" else 1.5e-3)

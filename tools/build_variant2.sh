@@ -9,7 +9,7 @@ typ=$1; shift
 cd "$(dirname "$0")/../diff_foley_amd/csrc"
 DEF=""; [ $typ = f16 ] && DEF="-DDF_OPERAND_F16"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-kernarg-preload-count=16 $DEF $*"
-SRCS="gemm gemm_m0a gemm_m0b gemm_m1 gemm_m2 gemm_m3 gemm_halo gemm_ps gemm_ps2 ffn elementwise attention backward cavp vocoder diag engine"
+SRCS="gemm gemm_m0a gemm_m0b gemm_m1 gemm_m2 gemm_m3 gemm_halo gemm_ps gemm_ps2 ffn ffn_wide elementwise attention backward cavp vocoder diag engine"
 VSRCS=${VSRCS:-$SRCS}
 d=build/var_${name}_$typ; mkdir -p $d ab
 pids=()

@@ -26,7 +26,7 @@ cs = torch.randn(N1, device="cuda") * 0.1
 bias = torch.randn(N1, device="cuda") * 0.1
 out = torch.empty(M, N1 // 2, device="cuda", dtype=torch.float16)
 for _ in range(3):
-    assert L.df_test_geglu(ptr(a), ptr(w), ptr(stats), ptr(cs), ptr(bias), ptr(out), M, K, N1, tile, 64 | extra, st) == 0
+    assert L.df_test_geglu(ptr(a), ptr(w), ptr(stats), ptr(cs), ptr(bias), ptr(out), M, K, N1, tile, 64 | extra | (128 if tile >= 32 else 0), st) == 0
 buf = np.zeros(1024 * 32, dtype=np.uint64)
 assert L.df_test_scratch_read(buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
 buf = buf.reshape(1024, 32)
