@@ -222,3 +222,42 @@ def test_fp16_full_dpm50_and_classifier(P, full):
     err = rel_l2(grad, g6["cls_grad"])
     print(f"fp16 full classifier grad rel-L2 {err:.3e}")
     assert err < 1e-2
+
+
+def test_unrequested_precision_moves_itself_to_bf16_when_fp16_saturates(P, monkeypatch):
+    """No operand type requested (the notebook's case): the product picks fp16 AND keeps it safe.  The scaled-GEGLU state dict that
+    saturates fp16 (tests above) through a plain LatentDiffusion(**cfg) -> load_state_dict -> .cuda(): one RuntimeWarning, the model
+    is on the bf16 build afterwards, samples are finite and equal the explicit bf16 model's bit for bit; procedural weights stay on
+    fp16 silently; an explicit precision='fp16' is obeyed (warning only, covered above)."""
+    import warnings
+    from diff_foley_amd import synth
+    monkeypatch.delenv("DF_PRECISION", raising=False)
+    cfg = P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        m0 = P.LatentDiffusion(**cfg)
+        m0.load_state_dict(tiny_state_dict())
+        m0.cuda()
+    assert m0.engine.precision == "fp16"
+    sd = dict(tiny_state_dict())
+    key = [k for k in sd if k.endswith("input_blocks.2.1.transformer_blocks.0.ff.net.0.proj.weight")]
+    sd[key[0]] = sd[key[0]] * 3.0e4
+    m = P.LatentDiffusion(**cfg)
+    m.load_state_dict(sd)
+    with pytest.warns(RuntimeWarning, match=r"now runs on the bf16 build"):
+        m.cuda()
+    assert m.engine.precision == "bf16" and m.precision == "bf16"
+    mb = P.LatentDiffusion(precision="bf16", **cfg)
+    mb.load_state_dict(sd)
+    mb.cuda()
+    B = 2
+    xT = synth.synthetic_xT(B, seed=21).cuda()
+    outs = []
+    for mm in (m, mb):
+        c = mm.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+        z, _ = mm.sample_log_diff_sampler(c, B, "DDIM", 4, unconditional_guidance_scale=4.5, unconditional_conditioning=torch.zeros_like(c),
+                                          x_T=xT.clone())
+        outs.append(z)
+    assert torch.isfinite(outs[0]).all()
+    assert rel_l2(outs[0].cpu(), outs[1].cpu()) < 1e-2
+    assert torch.equal(outs[0], outs[1])

@@ -13,8 +13,7 @@ from diff_foley_amd import synth
 sd = synth.make_state_dict(synth.state_dict_spec(), 0)
 m = P.LatentDiffusion(**P.stage2_config())
 m.load_state_dict(sd)
-m.cuda()
-m.autotune(True)
+m.cuda()          # (round 6: no autotune call -- the facade runs the shipped plan table, like a notebook user)
 for B in (1, 4, 8):
     feats = synth.synthetic_cavp(B).cuda()
     xT = synth.synthetic_xT(B).cuda()
@@ -63,11 +62,9 @@ for prec in ("fp16", "bf16"):
     cavp = P.CAVPInference(embed_dim=512, precision=prec)
     cavp.load_state_dict(synth.make_state_dict(synth.cavp_spec(), 0))
     cavp.cuda()
-    cavp.autotune(True)
     m = P.LatentDiffusion(precision=prec, **P.stage2_config())
     m.load_state_dict(sd)
     m.cuda()
-    m.autotune(True)
     video = synth.synthetic_video(1, 32, 224).cuda()
     B = 8
     xT = synth.synthetic_xT(B).cuda()

@@ -11,7 +11,7 @@ import sys
 
 
 def family(name):
-    if "gemm_bf16" in name or "halo" in name or "splitk" in name or "geglu_persistent" in name:
+    if "gemm_bf16" in name or "halo" in name or "splitk" in name or "geglu_persistent" in name or "geglu_wide" in name:
         return "gemm"
     if "attention" in name:
         return "attention"

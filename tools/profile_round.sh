@@ -6,12 +6,12 @@
 ROOTD=$(pwd)
 OUT=$ROOTD/gpurun_out/profile
 rm -rf $OUT; mkdir -p $OUT
-export DF_TUNE_CACHE=$OUT/tune_cache.txt
+# (round 6: bench.py runs the shipped plan table -- no tuning pass, rocprof sees product launches only; DF_TUNE_CACHE no longer needed)
 python bench.py --dump-ops $OUT/ops_per_step.csv 2> $OUT/bench.err | tail -1 > $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $ROOTD/bench.py --steps 25 --no-cpu-baseline --no-modes --no-vae > $OUT/rocprof_bench.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $ROOTD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-modes --no-vae > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $ROOTD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-modes --no-vae > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $ROOTD/bench.py --steps 25 --no-cpu-baseline --no-modes --no-vae --no-batch8 > $OUT/rocprof_bench.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- python $ROOTD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-modes --no-vae --no-batch8 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- python $ROOTD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-modes --no-vae --no-batch8 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vae_stats -o s -- python $ROOTD/tools/vae_bench.py 10 > $OUT/vae_bench.txt 2>$OUT/vae_bench.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/vae_fetch -o f -- python $ROOTD/tools/vae_bench.py 4 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/vae_write -o w -- python $ROOTD/tools/vae_bench.py 4 > /dev/null 2>&1

@@ -97,7 +97,7 @@ def main():
     tot = sum(r["busy_us_per_step"] for r in res)
     fam = collections.defaultdict(lambda: [0.0, 0.0])
     for r in res:
-        f = "gemm" if ("gemm_bf16" in r["kernel"] or "halo" in r["kernel"] or "splitk" in r["kernel"] or "geglu_persistent" in r["kernel"]) else (
+        f = "gemm" if ("gemm_bf16" in r["kernel"] or "halo" in r["kernel"] or "splitk" in r["kernel"] or "geglu_persistent" in r["kernel"] or "geglu_wide" in r["kernel"]) else (
             "attention" if "attention" in r["kernel"] else ("groupnorm" if "groupnorm" in r["kernel"] else "other"))
         fam[f][0] += r["busy_us_per_step"]
         fam[f][1] += r["mfma_busy"] * r["busy_us_per_step"]

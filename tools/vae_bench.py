@@ -14,7 +14,6 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 m = P.LatentDiffusion(**P.stage2_config())
 m.load_state_dict(synth.make_state_dict(synth.state_dict_spec(), 0))
 m.cuda()
-m.autotune(True)
 z = synth.synthetic_xT(4).cuda()
 for _ in range(3):
     m.decode_first_stage(z)
