@@ -306,7 +306,7 @@ hipError_t launch_d(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, cons
                     uint16_t* O, int ldo, int N, int heads, int Tq, int Tk, float scale, hipStream_t s) {
   const float sl2 = scale * 1.4426950408889634f;
   if constexpr (D <= 80) {        // two 64-key buffers of K and V^T fit beside each other (<= 35 KB)
-    static const bool no_ks2 = getenv("DF_ATTN_KS1") != nullptr;      // tools: A/B
+    constexpr bool no_ks2 = false;
     if (Tq >= 128 && Tk % 64 == 0 && !no_ks2) {
       dim3 grid((Tq + 127) / 128, heads, N);
       hipLaunchKernelGGL((attention_kernel<D, 4, 2>), grid, dim3(256), 0, s, Q, ldq, K, ldk, Vt, ldvt, heads, Tq, Tk, sl2, O, ldo);

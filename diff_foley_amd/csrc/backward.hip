@@ -527,7 +527,7 @@ hipError_t launch_geglu_bwd(const uint16_t* u, const float* dy, uint16_t* du, lo
 hipError_t launch_attention_bwd(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt,
                                 const float* dO, int lddo, uint16_t* dQ, int lddq, uint16_t* dK, int lddk, uint16_t* dV,
                                 int lddv, int N, int heads, int D, int Tq, int Tk, float scale, hipStream_t s) {
-  static const bool valu_only = getenv("DF_ATTN_BWD_VALU") != nullptr;       // tools: A/B against the VALU kernel
+  constexpr bool valu_only = false;
   if (!valu_only && D == 32 && Tk <= 256 && (lddk & 3) == 0 && (lddv & 3) == 0) {
     const int nkt = (Tk + 31) / 32, nqt = (Tq + 31) / 32;
     const size_t ldm = (size_t)(2 * nkt + 2 * nqt) * 32 * 40 * 2 + (size_t)(3 * 8 * 32 + 3 * 32 + 8 * 32 * 33) * 4;

@@ -654,8 +654,6 @@ struct Builder {
     // x back -- in the launch it needs anyway; the producer's reduce launch and one fp32 round trip of x disappear.
     static const bool no_own = getenv("DF_NO_GNOWN") && atoi(getenv("DF_NO_GNOWN"));
     Pend pd = pend;
-    if (const char* only = getenv("DF_GNOWN_ONLY"))      // debugging: restrict the hand-over to producers of one tag
-      if (pd.op >= 0 && !strstr(pl->ops[pd.op].tag, only)) pd = Pend{};
     if (!no_own && !sb && pd.op >= 0 && pd.p == xp && pd.ld == ld && pd.rows == x.rows && pd.C <= C && (pd.C & 1) == 0 &&
         (ld & 1) == 0 && groupnorm_accepts_slabs(HW, C)) {
       Plan* plp = pl;
@@ -731,7 +729,7 @@ struct Builder {
     pl->release(a1);
     // h1 has ONE consumer, the second GroupNorm.  When conv1 runs split-K, its reduce launch is dropped: the norm sums
     // the partial slabs while loading and adds the bias / FiLM bias itself (no reduce kernel, no fp32 round trip of h1).
-    static const bool no_defer = getenv("DF_NO_GNSLABS") && atoi(getenv("DF_NO_GNSLABS"));
+    constexpr bool no_defer = false;
     const size_t ci = pl->ops.size() - 1;
     const bool can_defer = !no_defer && groupnorm_accepts_slabs(H * Wd, cout);
     pl->ops[ci].defer = can_defer;
@@ -757,7 +755,7 @@ struct Builder {
       pl->release(scr);
     }
     pl->release(h1);
-    static const bool no_skipfold = getenv("DF_NO_SKIPFOLD") && atoi(getenv("DF_NO_SKIPFOLD"));
+    constexpr bool no_skipfold = false;
     const bool fold_skip = has_skip && !no_skipfold && cin % 64 == 0;
     if (has_skip && !fold_skip) {
       GemmParams g = gp_linear(xraw, M, cin, c->w_linear(nm(skip + ".weight")), cout);
@@ -897,7 +895,7 @@ struct Builder {
   void spatial_transformer(const F32& x, const F32& out, int NB, int T, const std::string& p, int heads,
                            const bf16_t* ctxK, const bf16_t* ctxVt, int Tc, int ldvtc, const PX* px = nullptr,
                            bool cfg_prefix = false) {
-    static const bool no_fold = getenv("DF_NO_LNFOLD") && atoi(getenv("DF_NO_LNFOLD"));
+    constexpr bool no_fold = false;
     if (no_fold) return spatial_transformer_unfused(x, out, NB, T, p, heads, ctxK, ctxVt, Tc, ldvtc);
     const int C = x.C, M = x.rows, D = C / heads;
     if (cfg_prefix && (T % 4 != 0 || NB % 2 != 0)) fail("cfg prefix needs the fused QKV form");
@@ -999,7 +997,7 @@ struct Builder {
         produces_t0(g);
         // nobody reads the fp32 residual stream after this op on the merged-FF path (FF1 and ffproj consume the operand
         // copy + row statistics, the block residual is x): the epilogue skips the fp32 store
-        if (!(getenv("DF_NO_FFPROJ") && atoi(getenv("DF_NO_FFPROJ"))) && C % 64 == 0 && !(getenv("DF_XO_STORE") && atoi(getenv("DF_XO_STORE"))))
+        if (C % 64 == 0)
           g.no_c_store = 1;
         g.bias = c->f32(nm(tb + ".attn2.to_out.0.bias"));
         g.res = t0; g.ldr = C;
@@ -1050,7 +1048,7 @@ struct Builder {
       }
       gemm(g, 1, "st.ff1");
     }
-    static const bool no_ffproj = getenv("DF_NO_FFPROJ") && atoi(getenv("DF_NO_FFPROJ"));
+    constexpr bool no_ffproj = false;
     if (!no_ffproj && C % 64 == 0) {
       // FF's second Linear, the residual add and proj_out are ONE linear map of (h, t): proj_out(t + W2 h + b2) =
       // (Wp W2) h + Wp t + (Wp b2 + bp).  One GEMM with K = 4C + C over two A tensors -- the GEGLU output and the operand
@@ -1306,7 +1304,7 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
   bf16_t* ctxb = b.buf<bf16_t>((size_t)N * Tc * Dc);
   std::map<std::string, std::pair<bf16_t*, bf16_t*>> kv;
   std::map<std::string, Builder::PX> pxs;
-  static const bool no_lnfold = getenv("DF_NO_LNFOLD") && atoi(getenv("DF_NO_LNFOLD"));
+  constexpr bool no_lnfold = false;
   const size_t ctx_ops_begin = pl->ops.size();
   {
     const long n = (long)N * Tc * Dc;
@@ -1352,7 +1350,7 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
     }
     const bf16_t* w = c->w_stack(pre + "#embw", wn);
     const float* bb = c->b_stack(pre + "#embb", bn);
-    static const bool emb_mfma = !(getenv("DF_EMB_GEMV") && atoi(getenv("DF_EMB_GEMV")));
+    constexpr bool emb_mfma = true;
     if (emb_mfma && mc % 64 == 0) {
       // The time-embedding MLP and the stacked emb projections as three MFMA GEMMs (M = N rows, rows beyond M are
       // out-of-bounds zero fill): the 52 MB emb weight stream goes through the LDS-DMA ring of the GEMM kernel at the HBM
@@ -1406,7 +1404,7 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
     pl->weight_bytes += 2.0 * etot * temb + 2.0 * (temb * mc + temb * temb);
   }
   // (round 5) a hoisted step's two leading launches -- the table look-up and the latent packing -- are one launch
-  static const bool no_step_merge = getenv("DF_NO_STEP_MERGE") && atoi(getenv("DF_NO_STEP_MERGE"));
+  constexpr bool no_step_merge = false;
   const bool step_merge = !no_step_merge && !which && etot % 4 == 0;
   if (!which && etot % 4 == 0) {
     // the table look-up that replaces the ops above when the caller announced its timesteps (df_unet_set_timesteps): the time
@@ -1429,11 +1427,11 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
   // cross-attention -- conv_in, the first ResBlock, and the first SpatialTransformer up to its self-attention out-projection --
   // is identical in both halves.  Those ops run on ONE half; the ops whose outputs the full batch needs (conv_in -> skip +
   // ResBlock, ResBlock -> transformer residual, attn1.out -> residual stream) store every row twice (GemmParams::dup_rows).
-  static const bool no_dedup = getenv("DF_NO_CFGDEDUP") && atoi(getenv("DF_NO_CFGDEDUP"));
+  constexpr bool no_dedup = false;
   const bool dedup = cfg_mode && !which && !no_dedup && !no_lnfold && N % 2 == 0 && topo.input.size() >= 2 &&
                      topo.input[0].size() == 1 && topo.input[0][0].kind == BlockDesc::CONV_IN && topo.input[1].size() == 2 &&
                      topo.input[1][0].kind == BlockDesc::RES && topo.input[1][1].kind == BlockDesc::ST && (HW % 4) == 0 &&
-                     pxs.count(topo.input[1][1].prefix) > 0 && !(getenv("DF_NO_FFPROJ") && atoi(getenv("DF_NO_FFPROJ")));
+                     pxs.count(topo.input[1][1].prefix) > 0;
   const int Np = dedup ? N / 2 : N;              // samples the prefix ops run on
   bf16_t* xin = b.buf<bf16_t>((size_t)Np * HW * 64);
   {
@@ -1520,7 +1518,7 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
         bf16_t* hb = in_aux ? in_aux : b.cast2d(h);
         // Upsample (openai_unetmodel.py:100-119): four 2x2-tap convs on the input-resolution map instead of a 3x3 conv on
         // the x2 map (2.25x fewer multiply-adds, gemm_m3.hip); DF_NO_UPS4=1 keeps the 3x3 form (A/B, parity tests)
-        static const bool no_ups4 = getenv("DF_NO_UPS4") && atoi(getenv("DF_NO_UPS4"));
+        constexpr bool no_ups4 = false;
         GemmParams g = (!no_ups4 && d.cin % 64 == 0)
                            ? Builder::gp_conv3_ups4(hb, N, hh, ww, d.cin, c->w_conv3_ups4(pre + d.prefix + ".conv.weight", d.cin), d.cout)
                            : Builder::gp_conv3(hb, N, hh, ww, d.cin, c->w_conv3(pre + d.prefix + ".conv.weight", d.cin), d.cout, 1, 1);
@@ -2090,7 +2088,7 @@ void build_vae(df_ctx* c, Plan* pl, int B, int H, int W) {
       bf16_t* hb = b.cast2d(h);
       F32 o{b.buf<float>((size_t)h.rows * 4 * co), h.rows * 4, co, co};
       const std::string p = pre + "decoder.up." + std::to_string(lvl) + ".upsample.conv";
-      static const bool no_ups4 = getenv("DF_NO_UPS4") && atoi(getenv("DF_NO_UPS4"));
+      constexpr bool no_ups4 = false;
       GemmParams g = (!no_ups4 && co % 64 == 0) ? Builder::gp_conv3_ups4(hb, B, hh, ww, co, c->w_conv3_ups4(p + ".weight", co), co)
                                                 : Builder::gp_conv3(hb, B, hh, ww, co, c->w_conv3(p + ".weight", co), co, 1, 1);
       Builder::out_f32(g, o.p, co);
@@ -2104,7 +2102,7 @@ void build_vae(df_ctx* c, Plan* pl, int B, int H, int W) {
     }
   }
   bf16_t* a = b.groupnorm(h, B, "decoder.norm_out", 1e-6f, 1, nullptr);
-  static const bool no_fewout = getenv("DF_NO_FEWOUT") && atoi(getenv("DF_NO_FEWOUT"));      // tools / tests: the implicit-GEMM form
+  constexpr bool no_fewout = false;
   if (!no_fewout && conv3x3_fewout_ok(hh, ww, h.C, v.out_ch)) {
     const bf16_t* wp = c->w_conv3(pre + "decoder.conv_out.weight", h.C);
     const float* bo = c->f32(pre + "decoder.conv_out.bias");
@@ -2593,7 +2591,7 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
   a.out2 = (float*)(ext + 4 * slab);
   const bool prof_was = c->prof_on;
   const int reps = 3;
-  static const bool tune_pair = !(getenv("DF_TUNE_PAIR") && atoi(getenv("DF_TUNE_PAIR")) == 0);
+  constexpr bool tune_pair = true;
   // one in-plan pass over candidate ranks [0, nr): every GEMM class runs its r-th candidate, per-op minimum over `nrep` runs
   auto evaluate = [&](size_t nr, int nrep) {
     for (auto& kv : cands)
@@ -2631,7 +2629,7 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
   // stage 2a: every surviving candidate, coarse (2 runs); 2b: the four best of each class again, among good neighbours and
   // with 6 runs -- the final choice between near-equal candidates used to flip from run to run (227 .. 234 steps/s for the
   // same build and box), a second, finer round takes most of that variance out
-  static const bool two_pass = !(getenv("DF_TUNE_2PASS") && atoi(getenv("DF_TUNE_2PASS")) == 0);
+  constexpr bool two_pass = true;
   evaluate(rounds, two_pass ? 2 : reps);
   if (two_pass) {
     size_t keep = 0;
@@ -2652,7 +2650,7 @@ void autotune_plan(df_ctx* c, Plan* pl, hipStream_t s) {
     }
   }
   // stage 3: tile walk order of the chosen tile (GemmParams::gm), again timed inside the plan
-  static const bool tune_walk = !(getenv("DF_TUNE_WALK") && atoi(getenv("DF_TUNE_WALK")) == 0);
+  constexpr bool tune_walk = true;
   if (tune_walk) {
     static const int gms[] = {0, 1, 2, 4, 8, 16};
     constexpr int NG = sizeof(gms) / sizeof(gms[0]);
@@ -3663,7 +3661,7 @@ int df_test_unet_block(df_ctx* c, const char* prefix, int kind, const float* x, 
       bf16_t* ctxb = b.buf<bf16_t>((size_t)N * T * Dc);
       const long n = (long)N * T * Dc;
       b.other("ctx.cast", [=](hipStream_t st, const RunArgs&) { return launch_cast_bf16(context, ctxb, n, st); });
-      static const bool no_lnfold = getenv("DF_NO_LNFOLD") && atoi(getenv("DF_NO_LNFOLD"));
+      constexpr bool no_lnfold = false;
       if (!no_lnfold && Builder::px_ok(Cin, u.num_heads, T, H * W)) {     // same choice as build_unet_like
         Builder::PX px = b.context_px(ctxb, N, T, Dc, p, Cin, u.num_heads);
         b.spatial_transformer(xin, dst, N, H * W, p, u.num_heads, nullptr, nullptr, T, ldvtc, &px);
@@ -3675,7 +3673,7 @@ int df_test_unet_block(df_ctx* c, const char* prefix, int kind, const float* x, 
     } else {
       bf16_t* hb = b.cast2d(xin);
       const std::string wn = pre + p + (kind == 2 ? ".op" : ".conv");
-      const bool ups4 = kind == 3 && Cin % 64 == 0 && !(getenv("DF_NO_UPS4") && atoi(getenv("DF_NO_UPS4")));   // as in the plan
+      const bool ups4 = kind == 3 && Cin % 64 == 0;   // as in the plan
       GemmParams g = ups4 ? Builder::gp_conv3_ups4(hb, N, H, W, Cin, c->w_conv3_ups4(wn + ".weight", Cin), Cout)
                           : Builder::gp_conv3(hb, N, H, W, Cin, c->w_conv3(wn + ".weight", Cin), Cout, kind == 2 ? 2 : 1, kind == 3 ? 1 : 0);
       Builder::out_f32(g, dst.p, Cout);

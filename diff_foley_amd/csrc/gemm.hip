@@ -198,7 +198,7 @@ bool gemm_tile_valid(const GemmParams& p, int tile, int batch, int splitk) {
     return false;
   // the folded skip connection: generic stride-1 kernel, and (round 5) a one-tap K tail of the producer-specialised halo tiles
   const bool halo_ps = tile >= TILE_HALO_PS_192x64 && tile <= TILE_HALO_PS_128x128;
-  static const bool no_halo_skip = getenv("DF_NO_HALO_SKIP") != nullptr;      // tools: A/B of the halo tiles' folded-skip tail
+  constexpr bool no_halo_skip = false;
   if (p.Cin2 > 0 && (!halo_ps || no_halo_skip || (p.Cin2 & 63) != 0 || !p.A2 || (p.lda2 & 7) != 0)) return false;
   if (p.taps != 9 || p.stride != 1 || p.ups != 0 || p.geglu || batch > 1) return false;
   int bm, bn, th, tw;
