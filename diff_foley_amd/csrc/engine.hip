@@ -198,6 +198,9 @@ struct df_ctx {
   // debug: after every op, a 64-bit checksum of ALL workspace bytes of the plan (df_debug_checksums): two runs of the same
   // inputs must give the same sequence; the first index that differs names the op whose launch was not reproducible
   bool chk_on = false;
+  // debug (df_debug_requant, fp16 build): operand-type outputs of the ops whose tag starts with one of these prefixes are re-rounded
+  // to bf16 precision (8 significant bits) right behind the op -- the error budget of the bf16 build, one op family at a time
+  std::vector<std::string> rq_prefix;
   unsigned long long* chk_dev = nullptr;
   size_t chk_used = 0, chk_cap = 0;
   std::vector<std::string> chk_label;
@@ -2381,6 +2384,46 @@ void saturations_after_op(df_ctx* c, Plan* pl, size_t op_index, hipStream_t s) {
   ++c->sat_used;
 }
 
+// Operand-type values re-rounded to bf16's 8 significant bits (round to nearest even on the fp16 pattern: 3 of its 10 mantissa bits
+// go; values below bf16's fp16-representable range are kept).  fp16 build only; the bf16 build's values are already there.
+__global__ __launch_bounds__(256) void requant_bf16_kernel(uint16_t* p, long rows, int cols, int ld) {
+#if defined(DF_OPERAND_F16)
+  const long total = rows * (long)cols;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / cols;
+    uint16_t* q = p + r * ld + (e - r * cols);
+    const uint16_t v = *q;
+    if ((v & 0x7C00u) == 0x7C00u) continue;             // inf / nan
+    const uint16_t lsb = (v >> 3) & 1u;
+    *q = (uint16_t)((v + 3u + lsb) & 0xFFF8u);
+  }
+#endif
+}
+
+void requant_after_op(df_ctx* c, Plan* pl, size_t op_index, hipStream_t s) {
+  const Op& o = pl->ops[op_index];
+  bool hit = false;
+  for (auto& pre : c->rq_prefix)
+    if (pre == "*" || !strncmp(o.tag, pre.c_str(), pre.size())) hit = true;
+  if (!hit) return;
+  std::vector<OutBuf> outs = o.outs;
+  if (o.is_gemm) {
+    const GemmParams& g = o.gp;
+    const long rows = (long)g.M * (g.taps == 4 ? 4 : 1) + g.dup_rows;
+    const int cols = g.geglu ? g.N / 2 : (g.vt ? g.vt_col0 : g.N);
+    if (g.out_bf16 && g.C && !o.c_ext && !g.store_nchw)
+      for (int z = 0; z < (g.splitk > 1 ? 1 : o.batch); ++z) outs.push_back({(const uint16_t*)g.C + (long)z * g.c_bs, rows, cols, g.ldc});
+    if (g.aux) outs.push_back({g.aux, rows, g.N, g.ld_aux});
+    if (g.vt) outs.push_back({g.vt, (long)(g.M / g.vt_T) * (g.N - g.vt_col0), g.vt_T, g.ldvt});
+  }
+  for (auto& b : outs) {
+    const long total = b.rows * (long)b.cols;
+    if (total <= 0) continue;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(requant_bf16_kernel, dim3(blocks), dim3(256), 0, s, const_cast<uint16_t*>(b.p), b.rows, b.cols, b.ld);
+  }
+}
+
 void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const RunArgs& a) {
   for (size_t i = begin; i < end; ++i) {
     Op& o = pl->ops[i];
@@ -2417,6 +2460,7 @@ void run_ops(df_ctx* c, Plan* pl, size_t begin, size_t end, hipStream_t s, const
       c->prof_op.push_back(&o);
       c->prof_used += 2;
     }
+    if (!c->rq_prefix.empty()) requant_after_op(c, pl, i, s);
     if (c->chk_on) checksum_after_op(c, pl, i, s);
     if (c->sat_on) saturations_after_op(c, pl, i, s);
     static const bool trace = getenv("DF_TRACE_OPS") && atoi(getenv("DF_TRACE_OPS"));     // debug: name + sync every op
@@ -3374,6 +3418,22 @@ int df_debug_saturations(df_ctx* c, int enable, int64_t capacity) {
         c->sat_cap = cap;
       }
       HIPCHK(hipMemset(c->sat_dev, 0, c->sat_cap * 8));
+    }
+  });
+}
+
+// Comma-separated op-tag prefixes ("*" = every op, "" = off): see df_ctx::rq_prefix.
+int df_debug_requant(df_ctx* c, const char* prefixes) {
+  return guard([&] {
+    HIPCHK(hipDeviceSynchronize());
+    c->rq_prefix.clear();
+    std::string t = prefixes ? prefixes : "";
+    size_t pos = 0;
+    while (pos < t.size()) {
+      size_t e = t.find(',', pos);
+      if (e == std::string::npos) e = t.size();
+      if (e > pos) c->rq_prefix.push_back(t.substr(pos, e - pos));
+      pos = e + 1;
     }
   });
 }

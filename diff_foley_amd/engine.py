@@ -108,6 +108,7 @@ _SIGS = {
     "df_debug_saturations": [C.c_void_p, C.c_int, C.c_int64],
     "df_debug_saturations_read": [C.c_void_p, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(C.c_int64)],
     "df_debug_saturation_label": [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64],
+    "df_debug_requant": [C.c_void_p, C.c_char_p],
     "df_test_gemm_epi": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                          C.c_int, C.c_int, C.c_int, C.c_void_p],
     "df_test_gemm_dual": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -494,6 +495,11 @@ class Engine:
         buf = C.create_string_buffer(200)
         _chk(self.L.df_debug_checksum_label(self._h, int(i), buf, 200), self.L)
         return buf.value.decode()
+
+    def debug_requant(self, prefixes=""):
+        """fp16 build: re-round the operand-type outputs of the ops whose tag starts with one of ``prefixes`` (comma separated, "*" =
+        all, "" = off) to bf16 precision -- tools/error_budget.py."""
+        _chk(self.L.df_debug_requant(self._h, prefixes.encode()), self.L)
 
     def debug_saturations(self, enable, capacity=1 << 16):
         """Debug: after every op, count the operand-type values it stored at the fp16 saturation value +-65504 (fp16 build;

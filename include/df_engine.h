@@ -237,6 +237,10 @@ int df_debug_checksum_label(df_ctx* ctx, int64_t index, char* buf, int64_t len);
  * The reference computes in fp32 and has no such limit (openai_unetmodel.py:24-28: convert_module_to_f16 is a stub). */
 int df_debug_saturations(df_ctx* ctx, int enable, int64_t capacity);
 int df_debug_saturations_read(df_ctx* ctx, uint64_t* out, int64_t cap, int64_t* n);
+/* Error budget of the bf16 build (tools/error_budget.py; no reference counterpart): in the fp16 build, re-round the operand-type outputs of
+ * every op whose tag starts with one of the comma-separated prefixes ("*" = all, "" = off) to bf16's 8 significant bits right behind
+ * the op.  The bf16 build accepts the call and changes nothing. */
+int df_debug_requant(df_ctx* ctx, const char* tag_prefixes);
 int df_debug_saturation_label(df_ctx* ctx, int64_t index, char* buf, int64_t len);
 /* Run ONE op family in isolation for unit tests (see tests/test_kernels_gpu.py). */
 int df_test_scratch_read(void* host, int64_t bytes);     /* the shared scratch of the test entry points (debug stamps) */

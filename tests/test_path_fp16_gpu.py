@@ -261,3 +261,26 @@ def test_unrequested_precision_moves_itself_to_bf16_when_fp16_saturates(P, monke
     assert torch.isfinite(outs[0]).all()
     assert rel_l2(outs[0].cpu(), outs[1].cpu()) < 1e-2
     assert torch.equal(outs[0], outs[1])
+
+
+def test_requant_debug_hook_emulates_the_bf16_build(P, tiny):
+    """df_debug_requant (tools/error_budget.py): in the fp16 build, re-rounding the operand-type outputs of every op to bf16 precision
+    moves the result away from the plain fp16 result by about the distance of the bf16 build, re-rounding nothing changes nothing,
+    and the hook leaves no state behind."""
+    from diff_foley_amd import synth
+    B = 2
+    x = synth.synthetic_xT(B, seed=3).cuda()
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+    t = torch.tensor([500.0, 37.0]).cuda()
+    eng = tiny.engine
+    y0 = tiny.apply_model(x, t, c).clone()
+    eng.debug_requant("")
+    assert torch.equal(tiny.apply_model(x, t, c), y0)
+    eng.debug_requant("*")
+    y_all = tiny.apply_model(x, t, c).clone()
+    eng.debug_requant("groupnorm")
+    y_gn = tiny.apply_model(x, t, c).clone()
+    eng.debug_requant("")
+    assert torch.equal(tiny.apply_model(x, t, c), y0)
+    d_all, d_gn = rel_l2(y_all.cpu(), y0.cpu()), rel_l2(y_gn.cpu(), y0.cpu())
+    assert 1e-4 < d_gn <= d_all * 1.5 and 5e-4 < d_all < 5e-2, (d_gn, d_all)

@@ -8,7 +8,8 @@ from diff_foley_amd import synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 m = P.LatentDiffusion(**P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
 m.load_state_dict(synth.make_state_dict(synth.state_dict_spec(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY), 0))
-m.cuda(); m.autotune(True)
+m.cuda()
+if os.environ.get("CLS_TUNE"): m.autotune(True)
 cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_FULL)))
 cls.load_state_dict(synth.make_state_dict(synth.classifier_spec(synth.CLS_FULL), 0))
 cls.attach(m)
