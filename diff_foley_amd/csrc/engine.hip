@@ -163,6 +163,7 @@ struct Plan {
 struct F32 {  // fp32 NHWC activation view
   float* p = nullptr;
   int rows = 0, C = 0, ld = 0;
+  uint16_t* b16 = nullptr;      // operand-type copy [rows][C] written by the op that produced the tensor (classifier-gradient tape), or null
 };
 
 }  // namespace
@@ -700,6 +701,7 @@ struct Builder {
     emits(o, rows, C, C);
   }
   bf16_t* cast2d(const F32& x) {
+    if (x.b16) return x.b16;      // the producer already wrote the operand copy: no cast launch
     bf16_t* o = buf<bf16_t>((size_t)x.rows * x.C);
     const float* xp = x.p;
     const int ld = x.ld, C = x.C;
@@ -1625,10 +1627,15 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
 
   auto f32buf = [&](int rows, int C) { return F32{b.buf<float>((size_t)rows * C), rows, C, C}; };
   // dX = dY . W  for y = x W^T : plain GEMM against the transposed packing
-  auto lin_bwd = [&](const bf16_t* dyb, int M, int O, const bf16_t* wt, int I, const char* tag) {
+  auto lin_bwd = [&](const bf16_t* dyb, int M, int O, const bf16_t* wt, int I, const char* tag, bool want_copy = false) {
     F32 dx = f32buf(M, I);
     GemmParams g = Builder::gp_linear(dyb, M, O, wt, I);
     Builder::out_f32(g, dx.p, I);
+    if (want_copy) {      // the next backward GEMM reads this gradient as an operand: copy from this epilogue instead of a cast launch
+      dx.b16 = b.buf<bf16_t>((size_t)M * I);
+      g.aux = dx.b16;
+      g.ld_aux = I;
+    }
     b.gemm(g, 1, tag);
     return dx;
   };
@@ -1645,6 +1652,7 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
     F32 dx = f32buf(x.rows, x.C);
     bf16_t* db = want_b16 ? b.buf<bf16_t>((size_t)x.rows * x.C) : nullptr;
     if (b16) *b16 = db;
+    dx.b16 = db;
     const float* gm = c->f32(pre + p + ".weight");
     const float* bt = c->f32(pre + p + ".bias");
     const float *xp = x.p, *dyp = dy.p, *ap = addend ? addend->p : nullptr;
@@ -1776,7 +1784,7 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
       F32 ds = dout;
       if (has_skip)
         ds = lin_bwd(dob, M, co, c->w_stack_t(pre + p + ".skip#t", {pre + p + ".skip_connection.weight"}), ci, "res.skip.bwd");
-      return gn_bwd(x, p + ".in_layers.0", 1e-5f, 1, d_a1, &ds, false, nullptr);
+      return gn_bwd(x, p + ".in_layers.0", 1e-5f, 1, d_a1, &ds, true, nullptr);      // + operand copy: the next tape entry's first GEMM reads it
     });
     return out;
   };
@@ -1797,6 +1805,9 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
       GemmParams g2 = Builder::gp_conv3(dyb, N, hh / 2, ww / 2, co, c->w_conv3_bwd(wname), ci, 1, 1);
       g2.zstuff = 1;
       Builder::out_f32(g2, dx.p, ci);
+      dx.b16 = b.buf<bf16_t>((size_t)N * hh * ww * ci);      // operand copy for the tape entry in front (its conv2.bwd reads it)
+      g2.aux = dx.b16;
+      g2.ld_aux = ci;
       b.gemm(g2, 1, "down.bwd");
       return dx;
     });
@@ -1891,7 +1902,7 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
     tape.push_back([=, &b](F32 dout) mutable -> F32 {
       auto wt = [&](const std::string& n) { return c->w_stack_t(pre + n + "#t", {pre + n}); };
       bf16_t* doutb = b.cast2d(dout);
-      F32 dt3 = lin_bwd(doutb, M, C, wt(p + ".proj_out.weight"), C, "st.proj_out.bwd");
+      F32 dt3 = lin_bwd(doutb, M, C, wt(p + ".proj_out.weight"), C, "st.proj_out.bwd", true);
       bf16_t* dt3b = b.cast2d(dt3);
       F32 dgl = lin_bwd(dt3b, M, C, wt(tb + ".ff.net.2.weight"), 4 * C, "st.ff2.bwd");
       bf16_t* du = b.buf<bf16_t>((size_t)M * 8 * C);
@@ -1932,7 +1943,7 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
       F32 dt0 = ln_bwd(t0, tb + ".norm1", da1, dt1, &dt0b);
       (void)dt0;
       F32 da0 = lin_bwd(dt0b, M, C, wt(p + ".proj_in.weight"), C, "st.proj_in.bwd");
-      return gn_bwd(x, p + ".norm", 1e-6f, 0, da0, &dout, false, nullptr);
+      return gn_bwd(x, p + ".norm", 1e-6f, 0, da0, &dout, true, nullptr);
     });
     return out;
   };
@@ -1988,7 +1999,7 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
     b.other("cls.head.bwd", [=](hipStream_t s, const RunArgs&) { return launch_cls_head_bwd(prob, wcls, dp, dhob, N, hw2, co, s); });
   }
   F32 d_ah = conv_bwd(dhob, hm, wmid, co, pre + "out.2.weight", chf, "cls.out.bwd");
-  F32 g = gn_bwd(h, "out.0", 1e-5f, 1, d_ah, nullptr, false, nullptr);
+  F32 g = gn_bwd(h, "out.0", 1e-5f, 1, d_ah, nullptr, true, nullptr);
   for (int i = (int)tape.size() - 1; i >= 0; --i) g = tape[i](g);
 }
 
