@@ -75,9 +75,10 @@ template <class T> __device__ __forceinline__ void st_wt(T* p, const T& v) { *p 
 // dword of line i, brings all lines into L2 side by side, and the later scalar loads of the chain become L2 hits: +1.8 % end to end
 // for the GEMM kernels alone (same box, 270.7 -> 275.7 steps/s).
 // The same for the kernel's own CODE: the next DF_CODE_TOUCH x 4 KB of instructions behind the program counter (the instruction
-// cache is cold at every kernel boundary and fetches line by line; +0.4 %).  Never past the code object: df_code_object_tail is a
-// zero-initialised variable of THIS translation unit's code object, i.e. it lives in .bss, the last section of the loaded image
-// (tools/check_code_touch.py verifies that layout for every built code object) -- lanes at or beyond it stay off.
+// cache is cold at every kernel boundary and fetches line by line; +0.4 %).  Never past the code: `_etext` is the linker's own symbol
+// for the end of THIS code object's .text section (lld defines it when it is referenced; tools/check_code_touch.py verifies, for every
+// built code object, that it exists and equals .text's end) -- lanes whose line would reach it stay off.  (Rounds 4-5 bounded the touch by
+// a .bss variable of the code object, i.e. relied on the loader mapping everything between .text and .bss: round-5 advisor finding.)
 //
 // ROUND 6 -- the touch loads are ORDINARY loads the compiler can see.  Rounds 4-5 issued them from inline asm into one "+v" register
 // that "stays reserved until the final wait".  It does not: the compiler does not know a load is in flight to that register, so under
@@ -97,7 +98,7 @@ template <class T> __device__ __forceinline__ void st_wt(T* p, const T& v) { *p 
 struct DfTouch { int v[DF_CODE_TOUCH > 0 ? DF_CODE_TOUCH : 1]; };
 typedef const int __attribute__((address_space(1)))* df_gptr_t;      // global address space: global_load, not flat_load
 #if defined(__HIP_DEVICE_COMPILE__)
-static __device__ char df_code_object_tail[64];
+extern "C" __device__ const char _etext[];
 __device__ __forceinline__ DfTouch df_entry_touch(int kernarg_bytes) {
   DfTouch t;
 #pragma unroll
@@ -109,7 +110,7 @@ __device__ __forceinline__ DfTouch df_entry_touch(int kernarg_bytes) {
 #if DF_CODE_TOUCH > 0
   unsigned long pc;
   asm volatile("s_getpc_b64 %0" : "=s"(pc));
-  const long room = (long)(reinterpret_cast<unsigned long>(&df_code_object_tail[0]) - pc);      // bytes of this image behind the pc
+  const long room = (long)(reinterpret_cast<unsigned long>(&_etext[0]) - pc);      // bytes of this code object's .text behind the pc
   const int avail = room > (long)(DF_CODE_TOUCH * 4096) ? DF_CODE_TOUCH * 4096 : (int)room;
 #pragma unroll
   for (int k = 0; k < DF_CODE_TOUCH; ++k) {

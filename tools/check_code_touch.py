@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""Build-time check behind csrc/gemm.h gemm_kernarg_touch(): a GEMM kernel reads up to DF_CODE_TOUCH x 4 KB of its own code object
-behind the program counter, bounded by the address of df_code_object_tail, a zero-initialised variable of the same code object.
-That bound is only a bound if the variable lies BEHIND .text in the loaded image (in .bss, the last allocated section).  This
-script checks exactly that for every gfx950 code object of the built libraries that defines the symbol.  Exit code 1 otherwise."""
+"""Build-time check behind csrc/common.h df_entry_touch(): a kernel reads up to DF_CODE_TOUCH x 4 KB of its own code object behind
+the program counter, bounded by `_etext`, the linker's symbol for the end of the code object's .text section.  This script checks, for
+every gfx950 code object of the built libraries that references the symbol, that it is defined and equals .text's end (so no touched
+line can lie outside the mapped, executable section).  Exit code 1 otherwise."""
 import os
 import re
 import shutil
@@ -28,18 +28,15 @@ def main():
                 out = subprocess.run([LLVM + "llvm-readelf", "-S", "-s", "-W", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
                 sec = {m.group(1): (int(m.group(2), 16), int(m.group(3), 16)) for m in
                        re.finditer(r"\]\s+(\.\S+)\s+\S+\s+([0-9a-f]{16})\s+[0-9a-f]+\s+([0-9a-f]+)", out)}
-                tails = [int(m.group(1), 16) for m in re.finditer(r"\d+:\s+([0-9a-f]{16})\s+\d+\s+OBJECT\s+\S+\s+\S+\s+\d+\s+\S*df_code_object_tail", out)]
-                if not tails:
+                ends = [int(m.group(1), 16) for m in re.finditer(r"\d+:\s+([0-9a-f]{16})\s+\d+\s+\S+\s+\S+\s+\S+\s+\d+\s+_etext\s*$", out, re.M)]
+                if not ends:
                     continue
                 n_obj += 1
                 text_end = sec[".text"][0] + sec[".text"][1]
-                bss = sec.get(".bss")
-                alloc_end = max(a + s for a, s in sec.values() if a)
-                for t in tails:
-                    ok = bss is not None and bss[0] <= t < bss[0] + bss[1] and t >= text_end and t + 64 <= alloc_end
-                    if not ok:
+                for t in set(ends):
+                    if t != text_end:
                         bad += 1
-                        print(f"{os.path.basename(lib)}:{f}: df_code_object_tail at {t:#x} is not behind .text (ends {text_end:#x}) inside .bss {bss}")
+                        print(f"{os.path.basename(lib)}:{f}: _etext at {t:#x} is not the end of .text ({text_end:#x})")
     print(f"checked {n_obj} code objects: {bad} violation(s)")
     return 1 if bad or not n_obj else 0
 
