@@ -3,8 +3,11 @@
 
 One "step" = one DDIM denoise step of one batch: CFG UNet evaluation on N = 2B latents (batch duplication, UNet
 forward, guidance combine) + the DDIM update, exactly the body of ddim.py:206-227.  Workload = BASELINE.json
-configs[1]: B = 4 per GPU, 8 s audio latent (4x16x64), 32 CAVP context frames, guidance 4.5, bf16 MFMA operands,
+configs[1]: B = 4 per GPU, 8 s audio latent (4x16x64), 32 CAVP context frames, guidance 4.5, 16-bit MFMA operands (fp16
+headline -- the operand type that meets the north-star tolerance -- with the bf16 build timed beside it in `modes`),
 procedurally generated weights of the full 860 M-parameter UNet (no checkpoint is reachable offline).
+The engine is the PRODUCT's: no tuning call, plans from the shipped table of the GPU (diff_foley_amd/tuned/); `modes.untuned`
+times the cost-model plans in a child process, `sampler_loop` the same workload through LatentDiffusion.sample_log_diff_sampler.
 
     python bench.py --gpus 1 --steps 25 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
