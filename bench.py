@@ -293,10 +293,12 @@ def untuned_child(a):
     process and library, so the cost-model plans need a fresh process): headline loop only."""
     import subprocess
     env = dict(os.environ, DF_TUNED_DEFAULTS="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)          # a plain single-process child even when this process was started by torch.distributed.run
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(a.steps), "--warmup", str(a.warmup), "--batch",
            str(a.batch), "--precision", a.precision, "--no-cpu-baseline", "--no-modes", "--no-vae", "--no-batch8"]
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
         return {"steps_per_s": d["value"], "ms_per_step": d["ms_per_step"], "plan": d["config"].get("plan_source"),
