@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Generates the shipped plan tables diff_foley_amd/tuned/<arch>_<CUs>cu_<precision>.txt (engine.load_tuned_defaults): runs the
-in-plan autotuner on THIS GPU for the shapes BASELINE.json's configs use -- UNet denoise steps at sampler batch 1 / 2 / 4 / 8 (with
-and without CFG batch duplication, hoisted and in-step time embedding), the condition encoder, VAE decode at the same batches, the
-double-guidance classifier (forward + gradient) at batch 8, and the on-device CAVP encoder of configs[4] -- and writes the
+in-plan autotuner on THIS GPU for the shapes BASELINE.json's configs use and their neighbours -- UNet denoise steps at sampler batch
+1-8 and 16 (with and without CFG batch duplication, hoisted and in-step time embedding), the condition encoder, VAE decode at the same
+batches, the double-guidance classifier (forward + gradient) at batch 1 / 2 / 4 / 8, and the on-device CAVP encoder of configs[4] -- and writes the
 autotuner's choices (df_tune_cache_export) next to the package.  Run once per GPU model and precision; commit the text files.
 usage: tools/make_tuned_defaults.py [bf16|fp16 ...]"""
 import os
@@ -25,7 +25,7 @@ def tune(precision):
     m.cuda()
     m.autotune(True)
     eng = m.engine
-    for B in (4, 8, 1, 2):
+    for B in (4, 8, 1, 2, 3, 5, 6, 7, 16):
         feats = synth.synthetic_cavp(B).cuda()
         xT = synth.synthetic_xT(B).cuda()
         c = m.get_learned_conditioning(feats)
@@ -41,14 +41,14 @@ def tune(precision):
     cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_FULL)))
     cls.load_state_dict(synth.make_state_dict(synth.classifier_spec(synth.CLS_FULL), 0))
     cls.attach(m)
-    B = 8
-    feats = synth.synthetic_cavp(B, 33).cuda()
-    xT = synth.synthetic_xT(B).cuda()
-    c = m.get_learned_conditioning(feats[:, :32])
-    m.sample_log_with_classifier_diff_sampler(c, origin_cond=feats, batch_size=B, sampler_name="DPM_Solver", ddim_steps=3,
-                                              unconditional_guidance_scale=4.5, unconditional_conditioning=torch.zeros_like(c),
-                                              classifier=cls, classifier_guide_scale=50.0, x_T=xT)
-    torch.cuda.synchronize()
+    for B in (8, 4, 2, 1):          # configs[2] runs 8; the notebook 4 candidates per window
+        feats = synth.synthetic_cavp(B, 33).cuda()
+        xT = synth.synthetic_xT(B).cuda()
+        c = m.get_learned_conditioning(feats[:, :32])
+        m.sample_log_with_classifier_diff_sampler(c, origin_cond=feats, batch_size=B, sampler_name="DPM_Solver", ddim_steps=3,
+                                                  unconditional_guidance_scale=4.5, unconditional_conditioning=torch.zeros_like(c),
+                                                  classifier=cls, classifier_guide_scale=50.0, x_T=xT)
+        torch.cuda.synchronize()
     print(f"[{precision}] classifier tuned, {time.perf_counter() - t0:.0f} s", flush=True)
     # BASELINE configs[4]: the on-device CAVP video encoder (one 8 s clip = 32 frames at 224 x 224)
     cavp = P.CAVPInference(embed_dim=512, precision=precision)
