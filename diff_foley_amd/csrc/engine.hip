@@ -2534,13 +2534,41 @@ static void tune_cache_save() {
 // for tuning used to fall back to the heuristic tiles silently.
 static bool g_tune_imported = false;
 
+// A GEMM the table does not hold takes the entry of its NEAREST ROW COUNT among the entries that agree in everything else
+// (N, K, taps, stride, upsampling, batch count, GEGLU, epilogue class): the table is made at sampler batches 1-8 and 16, and another
+// batch size or latent width changes M only -- the tile family that wins at M = 8192 still wins at 10240.  Within a factor of 4 in M;
+// the choice is validated for the actual problem like an exact hit.  (Round 6: B = 10 without this ran the cost-model plan.)
+static const TuneChoice* nearest_tune_choice(const std::string& key) {
+  const size_t us = key.find('_');
+  if (us == std::string::npos) return nullptr;
+  const std::string suffix = key.substr(us);
+  const double m = (double)atol(key.substr(0, us).c_str());
+  if (m <= 0) return nullptr;
+  const TuneChoice* best = nullptr;
+  double bestd = 2.0001;           // |log2(M' / M)| <= 2
+  for (auto& kv : tune_cache()) {
+    const size_t u2 = kv.first.find('_');
+    if (u2 == std::string::npos || kv.first.compare(u2, std::string::npos, suffix) != 0) continue;
+    const double m2 = (double)atol(kv.first.substr(0, u2).c_str());
+    if (m2 <= 0) continue;
+    const double d = fabs(log2(m2 / m));
+    if (d < bestd) {
+      bestd = d;
+      best = &kv.second;
+    }
+  }
+  return best;
+}
+
 static void apply_tune_cache(Plan* pl) {
   auto& tc = tune_cache();
   for (auto& o : pl->ops) {
     if (!o.is_gemm || o.c_ext) continue;
-    auto it = tc.find(tune_key(o));
-    if (it == tc.end()) continue;
-    const TuneChoice& ch = it->second;
+    const std::string key = tune_key(o);
+    auto it = tc.find(key);
+    const TuneChoice* chp = it != tc.end() ? &it->second : nearest_tune_choice(key);
+    if (!chp) continue;
+    const TuneChoice& ch = *chp;
     const size_t need = (size_t)ch.sk * o.gp.M * o.gp.N * 4 * (o.gp.taps == 4 ? 4 : 1);
     if (!gemm_tile_valid(o.gp, ch.tile, o.batch, ch.sk) || (ch.sk > 1 && need > pl->partial_bytes)) continue;
     o.tile = ch.tile;

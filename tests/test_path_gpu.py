@@ -949,3 +949,33 @@ def test_facade_runs_the_shipped_plan_table(P):
     assert torch.isfinite(z).all()
     # the tuned plan uses the producer-specialised / persistent tiles; the cost model never picks them
     assert any(int(r["tile"]) >= 18 for r in rows)
+
+
+def test_batch_outside_the_shipped_table_takes_its_nearest_entries(full):
+    """A sampler batch the shipped table does not hold (B = 10: UNet batch 20) builds its plan from the entries of the nearest row
+    count (engine.hip nearest_tune_choice: another batch size changes M only), not from the cost model -- the plan carries the
+    producer-specialised / wide tiles -- and, samples being independent, its row 0 equals the B = 1 run to operand-rounding noise."""
+    import csv
+    import os
+    from diff_foley_amd import synth
+    if os.environ.get("DF_TUNED_DEFAULTS", "1") == "0" or not full.engine.tuned_defaults:
+        pytest.skip("no shipped table in this process")
+    B = 10
+    xT = synth.synthetic_xT(B, seed=21)
+    c = full.get_learned_conditioning(synth.synthetic_cavp(B, 32, 512, seed=1234).cuda())
+    uc = torch.zeros_like(c)
+    eng = full.engine
+    zB, _ = full.sample_log_diff_sampler(c, B, "DDIM", 4, unconditional_guidance_scale=4.5, unconditional_conditioning=uc, x_T=xT.clone())
+    eng.profile_begin()
+    full.sample_log_diff_sampler(c, B, "DDIM", 1 + 1, unconditional_guidance_scale=4.5, unconditional_conditioning=uc, x_T=xT.clone())
+    eng.profile_end()
+    eng.profile_dump("/tmp/df_b10_ops.csv")
+    rows = [r for r in csv.DictReader(open("/tmp/df_b10_ops.csv")) if int(r["K"]) > 0]
+    table_m = {int(line.split("_")[0]) for line in open(eng.tuned_defaults)}
+    assert any(int(r["M"]) not in table_m for r in rows)                      # the shape class really is outside the table
+    ff1 = [r for r in rows if r["tag"] == "st.ff1"]
+    assert ff1 and all(int(r["tile"]) >= 18 for r in ff1), [(r["M"], r["tile"]) for r in ff1][:6]
+    assert sum(int(r["tile"]) >= 18 for r in rows) > len(rows) // 3
+    z1, _ = full.sample_log_diff_sampler(c[:1], 1, "DDIM", 4, unconditional_guidance_scale=4.5, unconditional_conditioning=uc[:1],
+                                         x_T=xT[:1].clone())
+    assert torch.isfinite(zB).all() and rel_l2(zB[:1].cpu(), z1.cpu()) < TRAJ_TOL
