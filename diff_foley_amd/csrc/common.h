@@ -65,6 +65,27 @@ __device__ __forceinline__ void st_wt(float* p, float v) { asm volatile("global_
 template <class T> __device__ __forceinline__ void st_wt(T* p, const T& v) { *p = v; }
 #endif
 
+// ---- Packed-FP32 operand select on src1: broken on this hardware (round 6).  `v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32` whose LOW
+// result lane takes the HIGH register of src1 (`op_sel:[x,1]`) read that operand as ZERO in lanes 48-63 while another wavefront of
+// the same SIMD executes MFMAs: d + 0, d * 0, a * 0 + d.  Reproduced outside the engine by experiments/pk_opsel_probe.hip
+// (profiles/r6_pk_opsel_probe.txt: 2 or 4 blocks per CU with an MFMA loop next to the instruction: 10^4-10^5 wrong low results per
+// 2 * 10^9, all in the last lane quarter; none with one block per CU, none without MFMAs in the neighbour, none for the select on
+// src0 or src2).  The compiler emits the src1 form whenever a packed op broadcasts the odd element of a register pair from its
+// second operand; tools/check_pk_opsel.py (run by __graft_entry__.build()) fails the build on any such encoding in the libraries.
+// Where the source needs that broadcast it says so in the src0 form:   (lo, hi) += bhi   with (blo, bhi) a register pair.
+__device__ __forceinline__ void pk_add_hi(float& lo, float& hi, float blo, float bhi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x2 d = {lo, hi};
+  const f32x2 b = {blo, bhi};
+  asm("v_pk_add_f32 %0, %1, %0 op_sel:[1,0] op_sel_hi:[1,1]" : "+v"(d) : "v"(b));
+  lo = d.x;
+  hi = d.y;
+#else
+  lo += bhi;
+  hi += bhi;
+#endif
+}
+
 // ---- Kernel-entry touch (round 5; rebuilt in round 6): kernel-argument lines and the kernel's own code through the VECTOR memory path.
 // A kernel's arguments live in the kernarg segment -- new memory at every launch, so the scalar cache and L2 miss on every 64-B
 // line of it -- and the compiler s_loads a field where it is first used: the prologue of a kernel with a large argument block

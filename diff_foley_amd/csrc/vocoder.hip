@@ -37,9 +37,21 @@ __device__ __forceinline__ void fft1024(float2* s, const float2* __restrict__ tw
       float2 w = tw[j * stride];
       w.y *= sgn;
       const float2 u = s[a], v = s[b];
-      const float2 t = make_float2(w.x * v.x - w.y * v.y, w.x * v.y + w.y * v.x);
-      s[a] = make_float2(u.x + t.x, u.y + t.y);
-      s[b] = make_float2(u.x - t.x, u.y - t.y);
+      // scalar butterfly: as packed expressions the complex product and the +- pair become `v_pk_mul_f32 ... op_sel:[1,1]` /
+      // `v_pk_add_f32 ... op_sel:[0,1]` -- src1 operand selects (common.h pk_add_hi, tools/check_pk_opsel.py).  Every result goes
+      // through its own register barrier so that the vectoriser finds no pair to pack.
+      float tx = w.x * v.x, ty = w.x * v.y;
+      asm volatile("" : "+v"(tx));
+      asm volatile("" : "+v"(ty));
+      tx = fmaf(-w.y, v.y, tx);
+      ty = fmaf(w.y, v.x, ty);
+      float ax = u.x + tx, ay = u.y + ty, bx = u.x - tx, by = u.y - ty;
+      asm volatile("" : "+v"(ax));
+      asm volatile("" : "+v"(ay));
+      asm volatile("" : "+v"(bx));
+      asm volatile("" : "+v"(by));
+      s[a] = make_float2(ax, ay);
+      s[b] = make_float2(bx, by);
     }
   }
   __syncthreads();

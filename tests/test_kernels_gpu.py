@@ -426,6 +426,37 @@ def test_ln_folded_gemm_chain(mode, M, C, T, tile0, sk0, tile1, sk1):
         assert rel_l2(got, y_true) < loose
 
 
+@pytest.mark.parametrize("tile1", [10, 12, 11, 13, 0, 3])
+def test_fused_qkv_is_byte_reproducible_with_two_blocks_per_cu(tile1):
+    """The fused QKV projection at the 320-channel level of the B = 4 CFG step (8192 x 960 x 320, V third stored transposed) on the
+    double-buffered tiles -- two or more blocks per CU, i.e. another block's MFMAs next to this block's epilogue.  Round 6: tiles
+    10 / 12 lost the bias of single V^T elements at random (packed add with the src1 operand select, csrc/common.h pk_add_hi):
+    every repetition must give the bytes of the first one, and those of a one-block-per-CU tile."""
+    E = _eng()
+    M, C, T = 8192, 320, 1024
+    N1 = 3 * C
+    A0, W0 = bf(rnd((M, C), 40)).to(odt()).cuda(), bf(rnd((C, C), 41) / C ** 0.5).to(odt()).cuda()
+    b0, res = (0.1 * rnd((C,), 42)).cuda(), rnd((M, C), 43).cuda()
+    gamma, beta = (1 + 0.2 * rnd((C,), 44)).cuda(), (0.2 * rnd((C,), 45)).cuda()
+    W1 = (rnd((N1, C), 46) / C ** 0.5).cuda()
+
+    def run(tile):
+        t0 = torch.full((M, C), float("nan"), device="cuda")
+        y = torch.full((M, 2 * C), float("nan"), dtype=odt(), device="cuda")
+        vt = torch.zeros(M // T, C, T, dtype=odt(), device="cuda")
+        rc = E.lib(PREC).df_test_ln_chain(ptr(A0), ptr(W0), ptr(b0), ptr(res), ptr(gamma), ptr(beta), ptr(W1), None, ptr(t0), ptr(y),
+                                          ptr(vt), M, C, N1, 2, T, T, 3, 1, tile, 1, stream())
+        assert rc == 0, E.lib(PREC).df_last_error()
+        torch.cuda.synchronize()
+        return y.view(torch.int16), vt.view(torch.int16)
+
+    y_ref, vt_ref = run(0)                  # 128 x 128 tile with the 4-deep ring: 128 KB of LDS, one block per CU
+    for _ in range(10):
+        y, vt = run(tile1)
+        assert torch.equal(y, y_ref)
+        assert torch.equal(vt, vt_ref)
+
+
 @pytest.mark.parametrize("M,N,K,act", [(8, 1280, 320, 1), (8, 20160, 1280, 0), (16, 1280, 1280, 1), (2, 130, 256, 2),
                                        (3, 7, 64, 0)])
 def test_linear_rows_lds(M, N, K, act):
