@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Which launch of the FULL-SIZE UNet plan is not reproducible?  bf16 (or DF_PRECISION) build, B = 4 CFG forward (N = 8), untuned
-unless HUNT_TUNE=1; the same forward is repeated with per-op workspace checksums (df_debug_checksums) and every repetition's
+"""Which launch of the FULL-SIZE UNet plan is not reproducible?  bf16 (or HUNT_PREC) build, B = 4 (or HUNT_B) CFG forward (N = 2B), the
+shipped plan table (DF_TUNED_DEFAULTS=0: the cost-model plans; HUNT_TUNE=1: tuned here); the same forward is repeated with per-op workspace checksums (df_debug_checksums) and every repetition's
 sequence is compared with the first one: the first differing op is the launch that produced different bytes from identical inputs.
 usage: [DF_LIB_OVERRIDE=...] tools/race_hunt.py <reps> [--prec bf16]"""
 import os, sys, json
@@ -16,12 +16,13 @@ m = P.LatentDiffusion(precision=prec, **P.stage2_config())
 m.load_state_dict(synth.make_state_dict(synth.state_dict_spec(), 0))
 m.cuda()
 if os.environ.get("HUNT_TUNE"): m.autotune(True)
-xT = synth.synthetic_xT(4, seed=21).cuda()
-c = m.get_learned_conditioning(synth.synthetic_cavp(4, 32, 512, seed=1234).cuda())
+B = int(os.environ.get("HUNT_B", "4"))
+xT = synth.synthetic_xT(B, seed=21).cuda()
+c = m.get_learned_conditioning(synth.synthetic_cavp(B, 32, 512, seed=1234).cuda())
 uc = torch.zeros_like(c)
 eng = m.engine
 eng.set_context(torch.cat([uc, c]))
-t = torch.full((4,), 961.0, device="cuda")
+t = torch.full((B,), 961.0, device="cuda")
 eng.unet_forward_cfg(xT, t, 4.5)
 torch.cuda.synchronize()
 ref = None
@@ -54,5 +55,5 @@ for it in range(reps):
         if not tl:
             first_ops[lab] += 1
 eng.debug_checksums(False)
-print(json.dumps({"lib": os.environ.get("DF_LIB_OVERRIDE", "product"), "reps": reps, "diverged": sum(first_ops.values()),
+print(json.dumps({"lib": os.environ.get("DF_LIB_OVERRIDE", "product"), "prec": prec, "B": B, "reps": reps, "diverged": sum(first_ops.values()),
                   "nonfinite_outputs": nonfinite, "first_ops": dict(first_ops)}))
