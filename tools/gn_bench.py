@@ -12,7 +12,7 @@ import diff_foley_amd  # noqa
 from diff_foley_amd import engine as E
 
 SHAPES = [(8, 1024, 320), (8, 1024, 640), (8, 1024, 960), (8, 256, 640), (8, 256, 1280), (8, 256, 1920), (8, 64, 1280),
-          (8, 64, 2560), (8, 16, 1280), (8, 16, 2560), (4, 1024, 320)]
+          (8, 64, 2560), (8, 16, 1280), (8, 16, 2560), (4, 1024, 320), (2, 1024, 320), (1, 1024, 320), (2, 256, 640), (2, 64, 1280), (2, 16, 1280)]
 
 
 def main():
