@@ -151,6 +151,34 @@ def _classifier_grad(model, classifier, x, t, origin_cond):
     return classifier.log_prob_grad(x, t, origin_cond)
 
 
+_side_streams = {}
+
+
+def _eps_and_classifier_grad(model, classifier, eps_call, x, t, origin_cond):
+    """eps(x, t) and the classifier's d log p / d x at the same (x, t) (ddim.py:374-380, dpm_solver.py:1377-1393) do not depend on
+    each other, so the gradient's launches go to a second HIP stream beside the UNet step's (round 6).  The gradient plan is ~160
+    launches of small grids at the launch floor (1.14 ms per call at B = 8, profiles/r6_classifier_grad_ops.txt); beside the UNet step
+    they run on CUs the step's kernels leave idle: configs[2] 152.5 -> 171.1 steps/s, latents bit-equal to the one-stream order
+    (tools/cls_overlap_probe.py, profiles/r6_classifier_overlap.txt).  The plans own their workspaces; the only shared inputs are x and
+    t, read-only in both.  (Two UNet chains do NOT overlap this way -- every one of their kernels wants the whole chip:
+    tools/two_chain_probe.py.)  DF_CLS_OVERLAP=0 restores the one-stream order.  Returns (eps, grad), both ready on the current stream."""
+    if _os.environ.get("DF_CLS_OVERLAP", "1") == "0":
+        return eps_call(), _classifier_grad(model, classifier, x, t, origin_cond)
+    cur = torch.cuda.current_stream(x.device)
+    side = _side_streams.get(x.device)
+    if side is None:
+        side = _side_streams[x.device] = torch.cuda.Stream(x.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        g = _classifier_grad(model, classifier, x, t, origin_cond)
+    x.record_stream(side)
+    t.record_stream(side)
+    e = eps_call()
+    cur.wait_stream(side)
+    g.record_stream(cur)
+    return e, g
+
+
 class DDIMSampler(object):
     def __init__(self, model, schedule="linear", **kwargs):
         self.model = model
@@ -193,10 +221,11 @@ class DDIMSampler(object):
             index = total - i - 1
             if paint.on:                     # ddim.py:206-209
                 img = paint.blend(img, steps[i])
-            e_t = eps_fn(img, t_all[i], i)
             a_t, a_prev = tb.alphas[index], tb.alphas_prev[index]
-            if classifier is not None:       # ddim.py:374-380: the classifier gradient first ...
-                g = _classifier_grad(self.model, classifier, img, t_all[i], origin_cond)
+            if classifier is None:
+                e_t = eps_fn(img, t_all[i], i)
+            else:                            # ddim.py:374-380: the classifier gradient first ...
+                e_t, g = _eps_and_classifier_grad(self.model, classifier, lambda: eps_fn(img, t_all[i], i), img, t_all[i], origin_cond)
                 e_t = E.lincomb([(1.0, e_t), (-np.sqrt(np.float32(1.0) - a_t) * classifier_guide_scale, g)])
             if score_corrector is not None:  # ... then the caller's callback on the guided eps (ddim.py:249-251, 382-384)
                 e_t = score_corrector.modify_score(self.model, e_t, img, t_long[i], conditioning, **(corrector_kwargs or {}))
@@ -316,9 +345,10 @@ class DPMSolverSampler(object):
 
         def model_fn(x, k):          # data prediction x0 = (x - sigma*eps)/alpha   (dpm_solver.py:386-393)
             t = ts[k]
-            noise = eps_fn(x, t_in_all[k], k)
-            if classifier is not None and eps_fn.cfg:      # double guidance (dpm_solver.py:1377-1393)
-                g = _classifier_grad(self.model, classifier, x, t_in_all[k], origin_cond)
+            if classifier is None or not eps_fn.cfg:
+                noise = eps_fn(x, t_in_all[k], k)
+            else:                                          # double guidance (dpm_solver.py:1377-1393)
+                noise, g = _eps_and_classifier_grad(self.model, classifier, lambda: eps_fn(x, t_in_all[k], k), x, t_in_all[k], origin_cond)
                 noise = E.lincomb([(1.0, noise), (-classifier_guide_scale * ns.sigma(t), g)])
             a, s = ns.alpha(t), ns.sigma(t)
             return E.lincomb([(1.0 / a, x), (-s / a, noise)])

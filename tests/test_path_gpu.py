@@ -327,6 +327,33 @@ def test_score_corrector_callback(P, tiny):
     assert rel_l2(got[0].cpu(), want.cpu()) < 1e-5 and rel_l2(got[0].cpu(), e_cfg.cpu()) > 1e-4
 
 
+def test_classifier_gradient_on_the_side_stream_is_bit_identical(tiny, P, monkeypatch):
+    """Round 6: the classifier gradient of a guided step runs on a second HIP stream beside the UNet call (samplers.py
+    _eps_and_classifier_grad).  Same latents, bit for bit, as the one-stream order -- DDIM (ddim.py:374-380) and DPM-Solver++
+    double guidance (dpm_solver.py:1377-1393), repeated so that a missing stream dependency would get its chances."""
+    from diff_foley_amd import synth
+    B = 2
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+    uc = torch.zeros_like(c)
+    xT = synth.synthetic_xT(B, seed=21).cuda()
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_TINY)))
+    cls.load_state_dict(tiny_classifier_sd())
+    cls.attach(tiny)
+    vf = synth.synthetic_cavp(B, 33, 64, seed=4321).cuda()
+    for name, steps in (("DDIM", 6), ("DPM_Solver", 8)):
+        kw = dict(origin_cond=vf, batch_size=B, sampler_name=name, ddim_steps=steps, unconditional_guidance_scale=4.5,
+                  unconditional_conditioning=uc, classifier=cls, classifier_guide_scale=50.0)
+        monkeypatch.setenv("DF_CLS_OVERLAP", "0")
+        z0, _ = tiny.sample_log_with_classifier_diff_sampler(c, x_T=xT.clone(), **kw)
+        monkeypatch.setenv("DF_CLS_OVERLAP", "1")
+        for rep in range(4):
+            z1, _ = tiny.sample_log_with_classifier_diff_sampler(c, x_T=xT.clone(), **kw)
+            assert torch.isfinite(z1).all() and torch.equal(z0, z1), (name, rep)
+        monkeypatch.delenv("DF_CLS_OVERLAP")
+        z2, _ = tiny.sample_log_with_classifier_diff_sampler(c, x_T=xT.clone(), **kw)       # the default is the side stream
+        assert torch.equal(z0, z2), name
+
+
 def test_hoisted_time_embedding_is_bit_identical(tiny):
     """df_unet_set_timesteps + df_unet_forward(_cfg)_ts: the time embedding of every announced timestep (integer and fractional,
     as DDIM / DPM-Solver++ visit them) computed before the loop by the plan's own ops; a step that looks its row up returns
