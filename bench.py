@@ -288,6 +288,49 @@ def batch8_block(model, dev, steps, warmup):
             "frac_of_mfma_peak": round(GFLOP_PER_SAMPLE * 2 * B / ms / PEAK_BF16_TFLOPS, 4)}
 
 
+def config2_block(model, dev):
+    """BASELINE configs[2] as the facade runs it: batch 8, 50-step DPM-Solver++(2M), CFG 4.5 + the double-guidance classifier in the
+    loop (sample_log_with_classifier_diff_sampler on the headline model; full-size classifier, procedural weights).  One warm-up
+    call, then the better of two timed calls.  `one_stream` = the classifier gradient behind the UNet step on the same stream
+    (DF_CLS_OVERLAP=0, the order of rounds 1-5) instead of beside it on a second stream (the product default since round 6)."""
+    B, S = 8, 50
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_FULL)))
+    cls.load_state_dict(synth.make_state_dict(synth.classifier_spec(synth.CLS_FULL), 0))
+    cls.attach(model)
+    feats = synth.synthetic_cavp(B, 33).to(dev)
+    xT = synth.synthetic_xT(B).to(dev)
+    c = model.get_learned_conditioning(feats[:, :32])
+    uc = torch.zeros_like(c)
+
+    def run():
+        best = None
+        for it in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            z, _ = model.sample_log_with_classifier_diff_sampler(c, origin_cond=feats, batch_size=B, sampler_name="DPM_Solver", ddim_steps=S,
+                                                                 unconditional_guidance_scale=4.5, unconditional_conditioning=uc,
+                                                                 classifier=cls, classifier_guide_scale=50.0, x_T=xT)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if it and (best is None or dt < best):
+                best = dt
+        return best, bool(torch.isfinite(z).all())
+    keep = os.environ.get("DF_CLS_OVERLAP")
+    try:
+        os.environ.pop("DF_CLS_OVERLAP", None)
+        dt, finite = run()
+        os.environ["DF_CLS_OVERLAP"] = "0"
+        dt0, _ = run()
+    finally:
+        if keep is None:
+            os.environ.pop("DF_CLS_OVERLAP", None)
+        else:
+            os.environ["DF_CLS_OVERLAP"] = keep
+    return {"batch": B, "sampler": "DPM-Solver++(2M)", "nfe": S, "steps_per_s": round(S / dt, 2), "ms_per_sample_call": round(dt * 1e3, 1),
+            "finite": finite, "one_stream": {"steps_per_s": round(S / dt0, 2), "ms_per_sample_call": round(dt0 * 1e3, 1)},
+            "what": "LatentDiffusion.sample_log_with_classifier_diff_sampler, classifier gradient on a second HIP stream beside the UNet step"}
+
+
 def untuned_child(a):
     """`modes.untuned`: the same command in a child process with DF_TUNED_DEFAULTS=0 (the shipped table is imported once per
     process and library, so the cost-model plans need a fresh process): headline loop only."""
@@ -460,6 +503,10 @@ def main():
             out["vae_decode_roofline"] = vae_roofline(main_run["model"], dev, B)
         if world == 1 and not a.no_batch8:
             out["batch8"] = batch8_block(main_run["model"], dev, max(10, a.steps // 2), a.warmup)
+            try:
+                out["config2_classifier_guided"] = config2_block(main_run["model"], dev)
+            except Exception as ex:      # must not hide the headline number
+                out["config2_classifier_guided"] = {"error": f"{type(ex).__name__}: {ex}"}
         if world == 1 and not a.no_modes:
             # both MFMA operand types in ONE driver-run line: steps/s of the same workload + the north-star parity metric
             # (mel MAE of a 25-step DDIM sample against the reference's golden output) measured in this very process
