@@ -375,6 +375,16 @@ def test_hoisted_time_embedding_is_bit_identical(tiny):
         assert torch.equal(a, b), (k, t)
     with pytest.raises(RuntimeError):
         eng.unet_forward_cfg(x, None, 4.5, ts_index=len(ts))
+    # round 6: announcing the timesteps the table already holds is a no-op; other timesteps of the same count rebuild it
+    ref3 = eng.unet_forward_cfg(x, None, 4.5, ts_index=3)
+    eng.set_timesteps(ts, B, 16, 64, True)
+    assert torch.equal(eng.unet_forward_cfg(x, None, 4.5, ts_index=3), ref3)
+    ts2 = [t + 7.0 if t < 900 else t - 7.0 for t in ts]
+    eng.set_timesteps(ts2, B, 16, 64, True)
+    got = eng.unet_forward_cfg(x, None, 4.5, ts_index=3)
+    assert torch.equal(got, eng.unet_forward_cfg(x, torch.full((B,), ts2[3], device="cuda"), 4.5)) and not torch.equal(got, ref3)
+    eng.set_timesteps(ts, B, 16, 64, True)
+    assert torch.equal(eng.unet_forward_cfg(x, None, 4.5, ts_index=3), ref3)
     eng.set_context(c)
     with pytest.raises(RuntimeError):                       # the non-CFG plan of this shape has no table yet
         eng.unet_forward(x, None, ts_index=0)
