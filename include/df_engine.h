@@ -127,7 +127,8 @@ int df_unet_forward_cfg(df_ctx* ctx, const float* x_dev, const float* t_dev, flo
  * timesteps (host memory; integer or fractional), each used for every sample of the batch as the reference samplers do
  * (ddim.py:217).  N, H, W, cfg name the plan (cfg != 0: the CFG plan of df_unet_forward_cfg with B = N).  Call after
  * df_unet_set_context.  The *_ts entry points then take the INDEX of the step's timestep in that table instead of t_dev and
- * replace the four time-embedding launches of a step by one table look-up; results are bit-identical to the t_dev forms. */
+ * replace the four time-embedding launches of a step by one table look-up; results are bit-identical to the t_dev forms.
+ * Announcing the timesteps the plan's table already holds returns at once (a service's sample() calls repeat the same 25 / 50). */
 int df_unet_set_timesteps(df_ctx* ctx, const float* t_host, int S, int N, int H, int W, int cfg, void* stream);
 int df_unet_forward_ts(df_ctx* ctx, const float* x_dev, int ts_index, float* eps_out_dev, int N, int H, int W, void* stream);
 int df_unet_forward_cfg_ts(df_ctx* ctx, const float* x_dev, int ts_index, float* eps_out_dev, int B, int H, int W,
