@@ -1,0 +1,76 @@
+"""Randomised differential test of the plan builder over UNet CONFIGURATIONS: the reference's UNetModel is a constructor over
+(model_channels, channel_mult, num_res_blocks, attention_resolutions, num_heads, context_dim) (openai_unetmodel.py:451-692), and a
+user of the reference may bring another YAML than Stage2_LDM.yaml.  Seeded draws of those arguments (inside what GroupNorm32 and the
+attention kernel's head dimensions admit), procedurally generated weights for each, one ``apply_model`` through the facade
+(libdfengine_f16.so) against the oracle's fp32 forward (oracle/unet.py) at a random latent size / context length / batch, and one
+classifier-free-guidance call against the oracle's two-pass combination.  The goldens pin two configurations (tiny, full) and the
+classifier's; this walks the builder's other branches (levels without attention, one / three ResBlocks per level, odd multipliers,
+a single level pair, head dimensions 32 .. 160).
+
+Tolerance: rel-L2 < 5e-3 for one forward on the fp16-operand build (the tiny configuration's forward sits at 1e-3 .. 1.5e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = 5e-3
+N_CASES = 12
+HEAD_DIMS = (32, 40, 64, 80, 128, 160)          # csrc/attention.hip:attention_supported
+
+
+def _draw(seed):
+    r = np.random.default_rng(4200 + seed)
+    while True:         # channel_mult[0] = 1: the reference's `out` conv takes model_channels inputs (openai_unetmodel.py:682-686)
+        mc = int(r.choice([64, 128, 192]))
+        mult = [list(m) for m in ([1, 2], [1, 2, 4], [1, 1, 2], [1, 2, 2, 4], [1, 3], [1, 1], [1, 2, 4, 4])][int(r.integers(0, 7))]
+        nrb = int(r.choice([1, 2, 3]))
+        levels = len(mult)
+        att = sorted(int(2 ** i) for i in range(levels) if r.random() < 0.7)
+        # channels of the levels that carry attention (ds = 2^level in attention_resolutions) and of the middle block (always)
+        chs = {mc * mult[i] for i in range(levels) if 2 ** i in att} | {mc * mult[-1]}
+        heads = [h for h in (1, 2, 4, 8) if all(ch % h == 0 and ch // h in HEAD_DIMS for ch in chs)]
+        if mc * max(mult) <= 768 and heads:
+            break
+    cfg = dict(in_channels=4, out_channels=4, model_channels=mc, attention_resolutions=att, num_res_blocks=nrb, channel_mult=mult,
+               num_heads=int(r.choice(heads)), context_dim=int(r.choice([64, 128, 192, 320])))
+    q = 2 ** (levels - 1)
+    H = int(r.choice([h for h in (8, 16) if h % q == 0]))
+    W = int(r.choice([w for w in (16, 32, 64) if w % q == 0]))
+    return cfg, dict(B=int(r.choice([1, 2, 3])), H=H, W=W, T=int(r.choice([1, 9, 32])), seed=seed)
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_unet_configuration_product_vs_oracle(seed):
+    import diff_foley_amd as P
+    from diff_foley_amd import synth
+    from oracle import unet as ou
+    cfg, o = _draw(seed)
+    cond = dict(origin_dim=64, embed_dim=cfg["context_dim"], seq_len=40)
+    sd = synth.make_state_dict(synth.state_dict_spec(cfg, synth.VAE_TINY, cond), 100 + seed)
+    m = P.LatentDiffusion(precision="fp16", **P.stage2_config(cfg, synth.VAE_TINY, cond))
+    m.load_state_dict(sd)
+    m.cuda()
+    usd = ou.sub_state_dict(sd, "model.diffusion_model.")
+    g = torch.Generator().manual_seed(300 + seed)
+    B, H, W, T = o["B"], o["H"], o["W"], o["T"]
+    x = torch.randn(B, 4, H, W, generator=g)
+    c = torch.randn(B, T, cfg["context_dim"], generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    ref = ou.unet_forward(usd, cfg, x, t, c)
+    y = m.apply_model(x.cuda(), t.cuda(), c.cuda()).cpu()
+    assert y.shape == ref.shape and torch.isfinite(y).all(), (cfg, o)
+    err = rel_l2(y, ref)
+    # classifier-free guidance through the fused entry point (one 2B-row plan, combine in the last GEMM's reduce / epilogue)
+    uc = 0.3 * torch.randn(B, T, cfg["context_dim"], generator=g)
+    tt = torch.full((B,), int(t[0]))
+    e2 = ou.unet_forward(usd, cfg, torch.cat([x, x]), torch.cat([tt, tt]), torch.cat([uc, c]))
+    ref_cfg = e2[:B] + 3.0 * (e2[B:] - e2[:B])
+    m.engine.set_context(torch.cat([uc, c]).cuda())
+    y_cfg = m.engine.unet_forward_cfg(x.cuda(), tt.float().cuda(), 3.0).cpu()
+    err_cfg = rel_l2(y_cfg, ref_cfg)
+    print(f"case {seed}: {cfg} {o} -> rel-L2 {err:.2e}, CFG {err_cfg:.2e}")
+    assert err < TOL, (cfg, o, err)
+    assert err_cfg < 3 * TOL, (cfg, o, err_cfg)          # guidance amplifies the (e_c - e_u) rounding by the scale
