@@ -245,6 +245,154 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const bf16_t* __rest
   }
 }
 
+// ------------------------------------------------------------------ attention backward, tiled (any T; VALU)
+// The two kernels above keep a whole (head, sample) in LDS -- the shapes of the reference's classifier on the 16 x 64 latent
+// (<= 256 tokens per map).  Longer maps (attention at the full resolution, a wider latent through `size_len`) take this pair: one
+// wavefront per 64 query rows (thread = row: statistics, delta and dQ as in phase A above, K / V streamed through LDS in tiles
+// of 64 keys, three passes), then one wavefront per 64 keys (thread = key: dK, dV as in phase B, Q / dO and the saved row
+// statistics streamed in tiles of 64 queries).  Same arithmetic, same summation order per row / key as the resident kernel.
+template <int D>
+__global__ __launch_bounds__(64) void attention_bwd_tiled_dq_kernel(const bf16_t* __restrict__ Q, int ldq,
+                                                                    const bf16_t* __restrict__ K, int ldk,
+                                                                    const bf16_t* __restrict__ Vt, int ldvt,
+                                                                    const float* __restrict__ dO, int lddo,
+                                                                    bf16_t* __restrict__ dQ, int lddq, float* __restrict__ stats,
+                                                                    int heads, int Tq, int Tk, float scale) {
+  __shared__ float sK[64 * (D + 1)], sV[64 * (D + 1)];
+  const int tid = threadIdx.x, q = blockIdx.x * 64 + tid, h = blockIdx.y, n = blockIdx.z;
+  const bool valid = q < Tq;
+  const int qc = valid ? q : Tq - 1;
+  float qv[D], dv[D], dq[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    qv[d] = bf2f(Q[((long)n * Tq + qc) * ldq + h * D + d]);
+    dv[d] = dO[((long)n * Tq + qc) * lddo + h * D + d];
+    dq[d] = 0.f;
+  }
+  auto stage = [&](int k0, bool with_v) {
+    __syncthreads();
+    for (int i = tid; i < 64 * D; i += 64) {
+      const int j = i / D, d = i - j * D;
+      sK[j * (D + 1) + d] = (k0 + j < Tk) ? bf2f(K[((long)n * Tk + k0 + j) * ldk + h * D + d]) : 0.f;
+    }
+    if (with_v)
+      for (int i = tid; i < 64 * D; i += 64) {
+        const int d = i >> 6, j = i & 63;
+        sV[j * (D + 1) + d] = (k0 + j < Tk) ? bf2f(Vt[((long)n * heads + h) * D * ldvt + (long)d * ldvt + k0 + j]) : 0.f;
+      }
+    __syncthreads();
+  };
+  float m = -INFINITY;
+  for (int k0 = 0; k0 < Tk; k0 += 64) {
+    stage(k0, false);
+    const int nj = min(64, Tk - k0);
+    for (int j = 0; j < nj; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) s += qv[d] * sK[j * (D + 1) + d];
+      m = fmaxf(m, s * scale);
+    }
+  }
+  float l = 0.f, del = 0.f;
+  for (int k0 = 0; k0 < Tk; k0 += 64) {
+    stage(k0, true);
+    const int nj = min(64, Tk - k0);
+    for (int j = 0; j < nj; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        s += qv[d] * sK[j * (D + 1) + d];
+        dp += dv[d] * sV[j * (D + 1) + d];
+      }
+      const float e = __expf(s * scale - m);
+      l += e;
+      del += e * dp;
+    }
+  }
+  del /= l;
+  for (int k0 = 0; k0 < Tk; k0 += 64) {
+    stage(k0, true);
+    const int nj = min(64, Tk - k0);
+    for (int j = 0; j < nj; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        s += qv[d] * sK[j * (D + 1) + d];
+        dp += dv[d] * sV[j * (D + 1) + d];
+      }
+      const float pj = __expf(s * scale - m) / l;
+      const float ds = pj * (dp - del) * scale;
+#pragma unroll
+      for (int d = 0; d < D; ++d) dq[d] += ds * sK[j * (D + 1) + d];
+    }
+  }
+  if (!valid) return;
+  if (stats) {
+    float* st = stats + (((long)n * heads + h) * Tq + q) * 3;
+    st[0] = m;
+    st[1] = l;
+    st[2] = del;
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) dQ[((long)n * Tq + q) * lddq + h * D + d] = f2bf(dq[d]);
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void attention_bwd_tiled_dkv_kernel(const bf16_t* __restrict__ Q, int ldq,
+                                                                     const bf16_t* __restrict__ K, int ldk,
+                                                                     const bf16_t* __restrict__ Vt, int ldvt,
+                                                                     const float* __restrict__ dO, int lddo,
+                                                                     bf16_t* __restrict__ dK, int lddk, bf16_t* __restrict__ dV,
+                                                                     int lddv, const float* __restrict__ stats, int heads, int Tq,
+                                                                     int Tk, float scale) {
+  __shared__ float sQ[64 * (D + 1)], sD[64 * (D + 1)], sS[64 * 3];
+  const int tid = threadIdx.x, j = blockIdx.x * 64 + tid, h = blockIdx.y, n = blockIdx.z;
+  const bool valid = j < Tk;
+  const int jc = valid ? j : Tk - 1;
+  float kv[D], vv[D], dk[D], dvv[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    kv[d] = bf2f(K[((long)n * Tk + jc) * ldk + h * D + d]);
+    vv[d] = bf2f(Vt[((long)n * heads + h) * D * ldvt + (long)d * ldvt + jc]);
+    dk[d] = 0.f;
+    dvv[d] = 0.f;
+  }
+  for (int q0 = 0; q0 < Tq; q0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * D; i += 64) {
+      const int q = i / D, d = i - q * D;
+      const bool in = q0 + q < Tq;
+      sQ[q * (D + 1) + d] = in ? bf2f(Q[((long)n * Tq + q0 + q) * ldq + h * D + d]) : 0.f;
+      sD[q * (D + 1) + d] = in ? dO[((long)n * Tq + q0 + q) * lddo + h * D + d] : 0.f;
+    }
+    for (int i = tid; i < 64 * 3; i += 64)
+      sS[i] = (q0 + i / 3 < Tq) ? stats[(((long)n * heads + h) * Tq + q0) * 3 + i] : 1.f;
+    __syncthreads();
+    const int nq = min(64, Tq - q0);
+    for (int q = 0; q < nq; ++q) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        s += sQ[q * (D + 1) + d] * kv[d];
+        dp += sD[q * (D + 1) + d] * vv[d];
+      }
+      const float pj = __expf(s * scale - sS[q * 3]) / sS[q * 3 + 1];
+      const float ds = pj * (dp - sS[q * 3 + 2]) * scale;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        dk[d] += ds * sQ[q * (D + 1) + d];
+        dvv[d] += pj * sD[q * (D + 1) + d];
+      }
+    }
+  }
+  if (!valid) return;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    dK[((long)n * Tk + j) * lddk + h * D + d] = f2bf(dk[d]);
+    dV[((long)n * Tk + j) * lddv + h * D + d] = f2bf(dvv[d]);
+  }
+}
+
 // ------------------------------------------------------------------ attention backward, MFMA (D = 32, Tk <= 256)
 // One block per (head, sample); wavefront w owns the 32-key tile w (NKT = ceil(Tk/32) <= 8 wavefronts) and keeps
 // dK^T / dV^T of its keys in MFMA accumulators while the block walks the query tiles.  Per (query tile, key tile):
@@ -524,14 +672,33 @@ hipError_t launch_geglu_bwd(const uint16_t* u, const float* dy, uint16_t* du, lo
   return hipGetLastError();
 }
 
+namespace {
+// LDS bytes of the two resident forms; 0 = the form does not take the shape
+size_t attn_bwd_mfma_lds(int D, int Tq, int Tk, int lddk, int lddv) {
+  if (!(D == 32 && Tk <= 256 && (lddk & 3) == 0 && (lddv & 3) == 0)) return 0;
+  const int nkt = (Tk + 31) / 32, nqt = (Tq + 31) / 32;
+  const size_t ldm = (size_t)(2 * nkt + 2 * nqt) * 32 * 40 * 2 + (size_t)(3 * 8 * 32 + 3 * 32 + 8 * 32 * 33) * 4;
+  return ldm <= 160 * 1024 ? ldm : 0;
+}
+size_t attn_bwd_valu_lds(int D, int Tq, int Tk) {
+  const size_t lds = ((size_t)(2 * Tk + 2 * Tq) * (D + 1) + 3 * (size_t)Tq) * 4;
+  return lds <= 160 * 1024 ? lds : 0;
+}
+}  // namespace
+
+size_t attention_bwd_ws_floats(int N, int heads, int D, int Tq, int Tk, int lddk, int lddv, bool want_dkv) {
+  if (attn_bwd_mfma_lds(D, Tq, Tk, lddk, lddv) || attn_bwd_valu_lds(D, Tq, Tk) || !want_dkv) return 0;
+  return (size_t)N * heads * Tq * 3;
+}
+
 hipError_t launch_attention_bwd(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt,
                                 const float* dO, int lddo, uint16_t* dQ, int lddq, uint16_t* dK, int lddk, uint16_t* dV,
-                                int lddv, int N, int heads, int D, int Tq, int Tk, float scale, hipStream_t s) {
-  constexpr bool valu_only = false;
-  if (!valu_only && D == 32 && Tk <= 256 && (lddk & 3) == 0 && (lddv & 3) == 0) {
-    const int nkt = (Tk + 31) / 32, nqt = (Tq + 31) / 32;
-    const size_t ldm = (size_t)(2 * nkt + 2 * nqt) * 32 * 40 * 2 + (size_t)(3 * 8 * 32 + 3 * 32 + 8 * 32 * 33) * 4;
-    if (ldm <= 160 * 1024) {
+                                int lddv, int N, int heads, int D, int Tq, int Tk, float scale, float* ws, hipStream_t s) {
+  if (D != 32 && D != 64) return hipErrorInvalidValue;
+  {
+    const int nkt = (Tk + 31) / 32;
+    const size_t ldm = attn_bwd_mfma_lds(D, Tq, Tk, lddk, lddv);
+    if (ldm) {
       static size_t attr_m = 0;
       if (ldm > attr_m) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_mfma_kernel),
@@ -544,8 +711,23 @@ hipError_t launch_attention_bwd(const uint16_t* Q, int ldq, const uint16_t* K, i
       return hipGetLastError();
     }
   }
-  const size_t lds = ((size_t)(2 * Tk + 2 * Tq) * (D + 1) + 3 * (size_t)Tq) * 4;
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const size_t lds = attn_bwd_valu_lds(D, Tq, Tk);
+  if (!lds) {      // no resident form: the tiled pair (row statistics through `ws`)
+    if (dK && !ws) return hipErrorInvalidValue;
+    const dim3 gq((Tq + 63) / 64, heads, N), gk((Tk + 63) / 64, heads, N);
+#define DF_ABWD_T(DD)                                                                                                             \
+  {                                                                                                                               \
+    hipLaunchKernelGGL(attention_bwd_tiled_dq_kernel<DD>, gq, dim3(64), 0, s, Q, ldq, K, ldk, Vt, ldvt, dO, lddo, dQ, lddq,         \
+                       dK ? ws : nullptr, heads, Tq, Tk, scale);                                                                  \
+    if (dK)                                                                                                                       \
+      hipLaunchKernelGGL(attention_bwd_tiled_dkv_kernel<DD>, gk, dim3(64), 0, s, Q, ldq, K, ldk, Vt, ldvt, dO, lddo, dK, lddk, dV,   \
+                         lddv, ws, heads, Tq, Tk, scale);                                                                         \
+  }
+    if (D == 32) DF_ABWD_T(32)
+    else DF_ABWD_T(64)
+#undef DF_ABWD_T
+    return hipGetLastError();
+  }
 #define DF_ABWD(DD)                                                                                                   \
   {                                                                                                                   \
     static size_t attr = 0;                                                                                           \

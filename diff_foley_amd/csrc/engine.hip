@@ -1921,7 +1921,7 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
         const float* dop = do2.p;
         b.other("attn.cross.bwd", [=](hipStream_t s, const RunArgs&) {
           return launch_attention_bwd(q2, C, ctxK, C, ctxVt, ldvtc, dop, C, dq2, C, nullptr, 0, nullptr, 0, N, heads, D, T, Tc,
-                                      scale, s);
+                                      scale, nullptr, s);
         });
       }
       F32 da2 = lin_bwd(dq2, M, C, wt(tb + ".attn2.to_q.weight"), C, "st.q2.bwd");
@@ -1932,9 +1932,11 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
       bf16_t* dqkv = b.buf<bf16_t>((size_t)M * 3 * C);
       {
         const float* dop = do1.p;
+        const size_t nws = attention_bwd_ws_floats(N, heads, D, T, T, 3 * C, 3 * C, true);      // > 0: the tiled pair (long maps)
+        float* ws = nws ? b.buf<float>(nws) : nullptr;
         b.other("attn.self.bwd", [=](hipStream_t s, const RunArgs&) {
           return launch_attention_bwd(qk, 2 * C, qk + C, 2 * C, vt, ldvt, dop, C, dqkv, 3 * C, dqkv + C, 3 * C, dqkv + 2 * C,
-                                      3 * C, N, heads, D, T, T, scale, s);
+                                      3 * C, N, heads, D, T, T, scale, ws, s);
         });
       }
       const bf16_t* wqkv_t = c->w_stack_t(pre + tb + ".attn1.qkv#t", {pre + tb + ".attn1.to_q.weight", pre + tb + ".attn1.to_k.weight",

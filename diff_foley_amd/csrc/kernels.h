@@ -128,9 +128,13 @@ hipError_t launch_layernorm_bwd(const float* x, int rows, int C, const float* ga
 hipError_t launch_geglu_fwd(const uint16_t* u, uint16_t* y, long rows, int H, hipStream_t s);
 hipError_t launch_geglu_bwd(const uint16_t* u, const float* dy, uint16_t* du, long rows, int H, hipStream_t s);
 // dQ always; dK/dV only when dK != nullptr (cross-attention needs dQ only: the context is a constant)
+// Maps that fit no LDS-resident form (more than ~256 tokens: attention at the full resolution, wider latents) take a tiled kernel
+// pair that hands the softmax row statistics from the dQ pass to the dK / dV pass through `ws`
+// (attention_bwd_ws_floats(...) fp32 values; 0 = a resident form runs, or only dQ is wanted: ws may be null).
+size_t attention_bwd_ws_floats(int N, int heads, int D, int Tq, int Tk, int lddk, int lddv, bool want_dkv);
 hipError_t launch_attention_bwd(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt,
                                 const float* dO, int lddo, uint16_t* dQ, int lddq, uint16_t* dK, int lddk, uint16_t* dV,
-                                int lddv, int N, int heads, int D, int Tq, int Tk, float scale, hipStream_t s);
+                                int lddv, int N, int heads, int D, int Tq, int Tk, float scale, float* ws, hipStream_t s);
 hipError_t launch_cls_head_bwd(const float* prob, const float* w, float* dh, uint16_t* dh_b16, int N, int HW, int C,
                                hipStream_t s);
 // Linear weight [O][I] fp32 -> transposed bf16 written at out[i*ldo + off + o]  (ldo >= off + O)
