@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------ row softmax fp32 -> bf16 (one wave per row)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
-                                                           int rows, int T) {
+                                                           int rows, int T, int ldp) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* sr = s + (long)row * T;
@@ -392,8 +392,9 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   float l = 0.f;
   for (int c = lane; c < T; c += 64) l += __expf(sr[c] - m);
   l = 1.0f / wave_sum(l);
-  bf16_t* pr = p + (long)row * T;
+  bf16_t* pr = p + (long)row * ldp;
   for (int c = lane; c < T; c += 64) pr[c] = f2bf(__expf(sr[c] - m) * l);
+  for (int c = T + lane; c < ldp; c += 64) pr[c] = (bf16_t)0;
 }
 
 // ------------------------------------------------------------------ small-M linear (time-embed MLP, emb projections,
@@ -884,8 +885,9 @@ hipError_t launch_layernorm(const float* x, int ld, int rows, int C, const float
   return hipGetLastError();
 }
 
-hipError_t launch_softmax_rows(const float* sc, uint16_t* p, int rows, int T, hipStream_t st) {
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, p, rows, T);
+hipError_t launch_softmax_rows(const float* sc, uint16_t* p, int rows, int T, int ldp, hipStream_t st) {
+  if (ldp < T) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, sc, p, rows, T, ldp);
   return hipGetLastError();
 }
 

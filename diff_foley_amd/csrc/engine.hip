@@ -571,6 +571,10 @@ struct Builder {
     o.batch = batch;
     o.tag = tag;
     int sk = 1;
+    // the K loop of every GEMM kernel walks whole 64-element steps (gemm_impl.h: nk = K / 64): a ragged K would silently drop its tail
+    if (gp.K % 64 != 0 || (gp.taps != 1 && gp.Cin % 64 != 0))
+      fail("GEMM %s (%dx%dx%d, Cin %d): the contraction length must be a multiple of 64 (channel counts, context_dim and origin_dim "
+           "that are not are outside what libdfengine builds)", tag, gp.M, gp.N, gp.K, gp.Cin);
     choose_tile(gp.M, gp.N, gp.K, batch, gp.geglu != 0, &o.tile, &sk);
     if (gp.taps == 9 && gemm_tile_valid(gp, TILE_HALO_128x64, batch, 1)) {   // halo reuse beats re-fetching A per tap
       o.tile = TILE_HALO_128x64;
@@ -2040,10 +2044,13 @@ void build_vae(df_ctx* c, Plan* pl, int B, int H, int W) {
   {  // AttnBlock (model.py:273-297): single head over hh*ww tokens, head dim = ch -> GEMM + row-softmax + GEMM
     const std::string p = "decoder.mid.attn_1";
     const int T = hh * ww, M = B * T;
+    // the P V contraction runs over the tokens: padded to whole 64-element K steps (zero probabilities against zeroed V^T columns)
+    // for maps whose token count is not a multiple of 64 (any latent but the 16 x 64 one may be: decode_first_stage takes them all)
+    const int Tp = rup(T, 64);
     bf16_t* a = b.groupnorm(h, B, p + ".norm", 1e-6f, 0, nullptr);
     bf16_t* q = b.buf<bf16_t>((size_t)M * ch);
     bf16_t* k = b.buf<bf16_t>((size_t)M * ch);
-    bf16_t* vt = b.buf<bf16_t>((size_t)B * ch * T);
+    bf16_t* vt = b.buf<bf16_t>((size_t)B * ch * Tp);
     {
       GemmParams g = Builder::gp_linear(a, M, ch, c->w_linear(pre + p + ".q.weight"), ch);
       Builder::out_b16(g, q, ch);
@@ -2057,10 +2064,14 @@ void build_vae(df_ctx* c, Plan* pl, int B, int H, int W) {
       b.gemm(g, 1, "vae.k");
     }
     {  // V^T without its bias: softmax rows sum to 1, so P(V + 1 b^T) = P V + b^T -> bias added after P V
+      if (Tp != T) {
+        const size_t nb = (size_t)B * ch * Tp * sizeof(bf16_t);
+        b.other("vae.vT.pad", [=](hipStream_t s, const RunArgs&) { return hipMemsetAsync(vt, 0, nb, s); });
+      }
       GemmParams g = Builder::gp_linear(c->w_linear(pre + p + ".v.weight"), ch, ch, a, T);
       g.w_bs = (long)T * ch;
-      Builder::out_b16(g, vt, T);
-      g.c_bs = (long)ch * T;
+      Builder::out_b16(g, vt, Tp);
+      g.c_bs = (long)ch * Tp;
       b.gemm(g, B, "vae.vT");
     }
     float* sc = b.buf<float>((size_t)B * T * T);
@@ -2073,13 +2084,13 @@ void build_vae(df_ctx* c, Plan* pl, int B, int H, int W) {
       g.alpha = 1.0f / sqrtf((float)ch);
       b.gemm(g, B, "vae.qk");
     }
-    bf16_t* pr = b.buf<bf16_t>((size_t)B * T * T);
-    b.other("vae.softmax", [=](hipStream_t s, const RunArgs&) { return launch_softmax_rows(sc, pr, B * T, T, s); });
+    bf16_t* pr = b.buf<bf16_t>((size_t)B * T * Tp);
+    b.other("vae.softmax", [=](hipStream_t s, const RunArgs&) { return launch_softmax_rows(sc, pr, B * T, T, Tp, s); });
     bf16_t* o = q;
     {
-      GemmParams g = Builder::gp_linear(pr, T, T, vt, ch);
-      g.a_bs = (long)T * T;
-      g.w_bs = (long)ch * T;
+      GemmParams g = Builder::gp_linear(pr, T, Tp, vt, ch);
+      g.a_bs = (long)T * Tp;
+      g.w_bs = (long)ch * Tp;
       Builder::out_b16(g, o, ch);
       g.c_bs = (long)T * ch;
       g.bias = c->f32(pre + p + ".v.bias");

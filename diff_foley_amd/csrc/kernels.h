@@ -48,7 +48,8 @@ hipError_t launch_conv3x3_fewout(const uint16_t* X, const uint16_t* Wt /*[Cout][
                                  int C, int Cout, hipStream_t s);
 
 // Row softmax: fp32 scores [rows][T] -> bf16 probabilities [rows][T]  (VAE single-head attention)
-hipError_t launch_softmax_rows(const float* s, uint16_t* p, int rows, int T, hipStream_t st);
+// p rows have ldp >= T elements; columns [T, ldp) are written as zeros (the K padding of the P V GEMM)
+hipError_t launch_softmax_rows(const float* s, uint16_t* p, int rows, int T, int ldp, hipStream_t st);
 
 // out[m][n] = act_out( sum_k a[m][k] * W[n][k] + bias[n] ),  M <= 16, fp32 activations, bf16 weights.
 hipError_t launch_linear_rows(const float* a, int lda, const uint16_t* W, const float* bias, float* out, int ldo,

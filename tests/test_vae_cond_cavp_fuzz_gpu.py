@@ -1,0 +1,141 @@
+"""Randomised differential tests of the three modules either side of the UNet, over the configurations and shapes the reference's
+constructors and call sites admit, each through the facade (fp16-operand library) against the CPU oracle on the same seeded inputs:
+
+  * ``decode_first_stage`` (ddpm.py:739-797 -> stage1_autoencoder/model.py:557-663): decoder ddconfig draws (ch, ch_mult,
+    num_res_blocks, out_ch), latent sizes from 4 x 8 to 16 x 64, batches 1 .. 5 -- oracle/vae.py;
+  * ``get_learned_conditioning`` (ddpm.py:568-579 -> video_feat_encoder.py:12-18): origin_dim / embed_dim / seq_len draws and
+    sequence lengths up to seq_len -- oracle/vae.py:cond_stage;
+  * ``CAVP_Inference.encode_video`` (cavp_model.py:47-65): stage_blocks draws of the SlowOnly backbone, clips of 1 .. 9 frames,
+    frame sizes 64 .. 160 (multiples of 32), 1 .. 3 clips -- oracle/cavp.py.
+The goldens pin one tiny and the full configuration of each; the plan builders have loops over levels / blocks / stages that only
+other configurations walk."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _vae_draw(seed):
+    r = np.random.default_rng(6100 + seed)
+    cfg = dict(z_channels=4, embed_dim=4, ch=int(r.choice([64, 128])),
+               ch_mult=[list(m) for m in ([1, 2], [1, 2, 2], [1, 2, 4], [1, 1, 2, 2], [1, 1], [1, 2, 4, 4])][int(r.integers(0, 6))],
+               num_res_blocks=int(r.choice([1, 2, 3])), out_ch=int(r.choice([1, 3])))
+    H, W = [(4, 8), (8, 16), (16, 64), (8, 24), (16, 16)][int(r.integers(0, 5))]
+    if cfg["ch"] * max(cfg["ch_mult"]) >= 512 and H * W > 256:        # keep the CPU oracle in seconds
+        H, W = 8, 16
+    return cfg, dict(B=int(r.choice([1, 2, 3, 5])), H=H, W=W)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_vae_decoder_configuration_product_vs_oracle(seed):
+    import diff_foley_amd as P
+    from diff_foley_amd import synth
+    from oracle import unet as ou, vae as ov
+    cfg, o = _vae_draw(seed)
+    sd = synth.make_state_dict(synth.state_dict_spec(synth.UNET_TINY, cfg, synth.COND_TINY), 700 + seed)
+    m = P.LatentDiffusion(precision="fp16", **P.stage2_config(synth.UNET_TINY, cfg, synth.COND_TINY))
+    m.load_state_dict(sd)
+    m.cuda()
+    vsd = ou.sub_state_dict(sd, "first_stage_model.")
+    z = torch.randn(o["B"], 4, o["H"], o["W"], generator=torch.Generator().manual_seed(800 + seed))
+    ref = ov.decode_first_stage(vsd, cfg, z)
+    y = m.decode_first_stage(z.cuda()).cpu()
+    up = 2 ** (len(cfg["ch_mult"]) - 1)
+    assert y.shape == ref.shape == (o["B"], cfg["out_ch"], o["H"] * up, o["W"] * up) and torch.isfinite(y).all(), (cfg, o)
+    err = rel_l2(y, ref)
+    print(f"vae case {seed}: {cfg} {o} -> rel-L2 {err:.2e}")
+    assert err < 3e-3, (cfg, o, err)              # the full decoder measures 9.2e-4 on this build
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_cond_stage_configuration_product_vs_oracle(seed):
+    import diff_foley_amd as P
+    from diff_foley_amd import synth
+    from oracle import unet as ou, vae as ov
+    r = np.random.default_rng(6300 + seed)
+    cond = dict(origin_dim=int(r.choice([64, 128, 512])), embed_dim=int(r.choice([64, 128, 320, 768])), seq_len=int(r.choice([8, 40, 64])))
+    ucfg = dict(synth.UNET_TINY, context_dim=cond["embed_dim"])
+    sd = synth.make_state_dict(synth.state_dict_spec(ucfg, synth.VAE_TINY, cond), 900 + seed)
+    m = P.LatentDiffusion(precision="fp16", **P.stage2_config(ucfg, synth.VAE_TINY, cond))
+    m.load_state_dict(sd)
+    m.cuda()
+    csd = ou.sub_state_dict(sd, "cond_stage_model.")
+    g = torch.Generator().manual_seed(950 + seed)
+    for T in sorted({1, int(r.integers(2, cond["seq_len"] + 1)), cond["seq_len"]}):
+        B = int(r.choice([1, 3, 4]))
+        f = torch.randn(B, T, cond["origin_dim"], generator=g)
+        ref = ov.cond_stage(csd, f)
+        c = m.get_learned_conditioning(f.cuda()).cpu()
+        assert c.shape == ref.shape == (B, T, cond["embed_dim"])
+        err = rel_l2(c, ref)
+        print(f"cond case {seed}: {cond} B={B} T={T} -> rel-L2 {err:.2e}")
+        assert err < 2e-3, (cond, B, T, err)
+    with pytest.raises(RuntimeError):             # longer than the positional table: the reference's broadcast add fails too
+        m.get_learned_conditioning(torch.randn(1, cond["seq_len"] + 1, cond["origin_dim"]).cuda())
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_cavp_configuration_product_vs_oracle(seed):
+    import diff_foley_amd as P
+    from diff_foley_amd import synth
+    from oracle import cavp as ocavp
+    r = np.random.default_rng(6500 + seed)
+    cfg = dict(stage_blocks=[int(v) for v in ([1, 1, 1, 1], [2, 1, 1, 1], [1, 2, 1, 2], [1, 1, 2, 1], [2, 2, 1, 1])[int(r.integers(0, 5))]],
+               base_channels=64, embed_dim=int(r.choice([64, 128, 512])))
+    sd = synth.make_state_dict(synth.cavp_spec(cfg), 1000 + seed)
+    m = P.CAVPInference(embed_dim=cfg["embed_dim"], stage_blocks=cfg["stage_blocks"], precision="fp16")
+    missing, unexpected = m.load_state_dict(sd)
+    assert not missing and not unexpected
+    m.cuda()
+    n, T, S = int(r.choice([1, 2, 3])), int(r.choice([1, 2, 5, 9])), int(r.choice([64, 96, 160]))
+    v = synth.synthetic_video(n, T, S, seed=1100 + seed)
+    for normalize in (True, False):
+        ref = ocavp.encode_video(sd, v, normalize=normalize, stage_blocks=tuple(cfg["stage_blocks"]))
+        f = m.encode_video(v.cuda(), normalize=normalize, pool=False).cpu()
+        assert f.shape == ref.shape == (n, T, cfg["embed_dim"]) and torch.isfinite(f).all()
+        err = rel_l2(f, ref)
+        cos = torch.nn.functional.cosine_similarity(f, ref, dim=-1).min().item()
+        print(f"cavp case {seed}: {cfg} clips={n} frames={T} size={S} normalize={normalize} -> rel-L2 {err:.2e}, min cos {cos:.6f}")
+        assert err < 2e-3 and cos > 0.99999, (cfg, n, T, S, err, cos)
+
+
+@pytest.mark.parametrize("H,W", [(2, 8), (4, 8), (4, 24), (8, 20)])
+def test_vae_decode_latents_whose_token_count_is_not_a_multiple_of_64(H, W):
+    """The decoder's mid attention (model.py:273-297) contracts P V over the H * W tokens; the GEMM kernels walk the contraction in
+    whole 64-element steps, so 16 / 32 / 96 / 160 tokens need the padded form (zero probabilities against zeroed V^T columns).
+    Found by the draws above: before round 6 the tail (all of it below 64 tokens) was dropped silently -- rel-L2 8e-2 .. 1.2e-1."""
+    import diff_foley_amd as P
+    from diff_foley_amd import synth
+    from helpers import tiny_state_dict
+    from oracle import unet as ou, vae as ov
+    sd = tiny_state_dict()
+    vsd = ou.sub_state_dict(sd, "first_stage_model.")
+    for prec, tol in (("fp16", 3e-3), ("bf16", 2e-2)):
+        m = P.LatentDiffusion(precision=prec, **P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
+        m.load_state_dict(sd)
+        m.cuda()
+        z = torch.randn(3, 4, H, W, generator=torch.Generator().manual_seed(H * 100 + W))
+        ref = ov.decode_first_stage(vsd, synth.VAE_TINY, z)
+        y = m.decode_first_stage(z.cuda()).cpu()
+        err = rel_l2(y, ref)
+        print(f"vae {H}x{W} ({H * W} tokens) [{prec}]: rel-L2 {err:.2e}")
+        assert y.shape == ref.shape and err < tol, (H, W, prec, err)
+
+
+def test_a_contraction_length_the_kernels_cannot_walk_fails_loudly():
+    """context_dim = 96 is a legal UNetModel argument; the GEMM kernels' K loop takes whole 64-element steps, so the engine refuses
+    the plan (RuntimeError naming the GEMM) instead of dropping the last 32 context channels."""
+    import diff_foley_amd as P
+    from diff_foley_amd import synth
+    ucfg = dict(synth.UNET_TINY, context_dim=96)
+    cond = dict(origin_dim=64, embed_dim=96, seq_len=40)
+    sd = synth.make_state_dict(synth.state_dict_spec(ucfg, synth.VAE_TINY, cond), 3)
+    m = P.LatentDiffusion(precision="bf16", **P.stage2_config(ucfg, synth.VAE_TINY, cond))
+    m.load_state_dict(sd)
+    m.cuda()
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        c = m.get_learned_conditioning(torch.randn(1, 8, 64).cuda())
+        m.apply_model(torch.randn(1, 4, 16, 64).cuda(), torch.tensor([10]).cuda(), c)
