@@ -2928,6 +2928,12 @@ size_t blob_layout(df_ctx* c, BlobW* w) {
 // ================================================================================================== C ABI
 extern "C" {
 
+// Sizes that come straight from the caller's tensors: an empty batch / map / sequence has no plan (several builders divide by these)
+static void need_positive(const char* what, std::initializer_list<std::pair<const char*, long>> dims) {
+  for (auto& d : dims)
+    if (d.second <= 0) fail("%s: %s = %ld (empty input: every size must be positive)", what, d.first, d.second);
+}
+
 int df_abi_version(void) { return 1; }
 const char* df_operand_dtype(void) {
 #if defined(DF_OPERAND_F16)
@@ -3017,7 +3023,7 @@ int df_autotune(df_ctx* c, int enable) { return guard([&] { c->autotune = enable
 int df_cavp_encode(df_ctx* c, const float* video, float* out, int B, int T, int H, int W, int normalize, void* stream) {
   return guard([&] {
     if (!c->has_cavp) fail("cavp encoder not configured");
-    if (B <= 0 || T <= 0) fail("cavp: empty batch");
+    need_positive("cavp", {{"clips", B}, {"frames", T}, {"H", H}, {"W", W}});
     Plan* p = get_plan(c, keyf("cavp_%d_%d_%d", T, H, W), [&](Plan* pl) { build_cavp(c, pl, T, H, W); });
     for (int i = 0; i < B; ++i) {      // clips are independent (temporal padding is per clip): one plan run each
       RunArgs a;
@@ -3031,6 +3037,7 @@ int df_cavp_encode(df_ctx* c, const float* video, float* out, int B, int T, int 
 
 int df_cavp_pool(const float* feat, float* out, int B, int T, int C, int kernel, int normalize, void* stream) {
   return guard([&] {
+    need_positive("cavp pool", {{"clips", B}, {"frames", T}, {"channels", C}, {"kernel", kernel}});
     HIPCHK(launch_maxpool_time(feat, out, B, T, C, kernel, (hipStream_t)stream));
     if (normalize) HIPCHK(launch_l2norm_rows(out, B * (T / kernel), C, (hipStream_t)stream));
   });
@@ -3039,6 +3046,7 @@ int df_cavp_pool(const float* feat, float* out, int B, int T, int C, int kernel,
 int df_cond_encode(df_ctx* c, const float* feats, float* out, int B, int T, void* stream) {
   return guard([&] {
     if (!c->has_cond) fail("cond stage not configured");
+    need_positive("cond stage", {{"batch", B}, {"sequence length", T}});
     Plan* p = get_plan(c, keyf("cond_%d_%d", B, T), [&](Plan* pl) { build_cond(c, pl, B, T); });
     RunArgs a;
     a.x = feats;
@@ -3049,6 +3057,7 @@ int df_cond_encode(df_ctx* c, const float* feats, float* out, int B, int T, void
 
 static Plan* unet_plan(df_ctx* c, int N, int H, int W, int T, bool cfg) {
   if (!c->has_unet) fail("unet not configured");
+  need_positive("unet", {{"batch", N}, {"H", H}, {"W", W}, {"context length", T}});
   if (H % (1 << (c->ucfg.n_mult - 1)) || W % (1 << (c->ucfg.n_mult - 1))) fail("latent %dx%d not divisible by the UNet downsampling", H, W);
   return get_plan(c, keyf("unet_%d_%d_%d_%d_%d", N, H, W, T, (int)cfg),
                   [&](Plan* pl) { build_unet_like(c, pl, 0, N, H, W, T, cfg, false); });
@@ -3056,6 +3065,7 @@ static Plan* unet_plan(df_ctx* c, int N, int H, int W, int T, bool cfg) {
 
 int df_unet_set_context(df_ctx* c, const float* context, int N, int T, void* stream) {
   return guard([&] {
+    need_positive("unet context", {{"batch", N}, {"context length", T}});
     c->ctx_N = N;
     c->ctx_T = T;
     // the context K/V live inside each forward plan; remember the pointer and (re)run the context ops lazily
@@ -3202,6 +3212,7 @@ static int vae_chunk(df_ctx* c, int H, int W) {
 int df_vae_decode(df_ctx* c, const float* z, float* out, int B, int H, int W, void* stream) {
   return guard([&] {
     if (!c->has_vae) fail("vae not configured");
+    need_positive("vae decode", {{"batch", B}, {"H", H}, {"W", W}});
     // One GEMM operand is addressed with 32-bit buffer offsets (< 2 GiB): the decoder's widest activation is
     // 8 x H x 8 x W pixels x 2*ch channels per sample, so large batches run as slices of at most `chunk` samples through
     // the plan of that size (same kernels, same results; no host round trip between slices).
@@ -3222,6 +3233,7 @@ int df_classifier_forward(df_ctx* c, const float* x, const float* t, const float
                           int W, int T, void* stream) {
   return guard([&] {
     if (!c->has_cls) fail("classifier not configured");
+    need_positive("classifier", {{"batch", B}, {"H", H}, {"W", W}, {"video frames", T}});
     Plan* p = get_plan(c, keyf("cls_%d_%d_%d_%d", B, H, W, T),
                        [&](Plan* pl) { build_unet_like(c, pl, 1, B, H, W, T, false, true); });
     RunArgs a;
@@ -3237,6 +3249,7 @@ int df_classifier_grad(df_ctx* c, const float* x, const float* t, const float* f
                        int H, int W, int T, void* stream) {
   return guard([&] {
     if (!c->has_cls) fail("classifier not configured");
+    need_positive("classifier gradient", {{"batch", B}, {"H", H}, {"W", W}, {"video frames", T}});
     Plan* p = get_plan(c, keyf("clsgrad_%d_%d_%d_%d", B, H, W, T), [&](Plan* pl) { build_classifier_grad(c, pl, B, H, W, T); });
     RunArgs a;
     a.x = x;
@@ -3342,6 +3355,7 @@ int df_frames_to_tensor(const uint8_t* frames, float* out, uint8_t* tmp, int T, 
                         const int32_t* bounds_w, const int32_t* coef_w, int ksize_w, const int32_t* bounds_h,
                         const int32_t* coef_h, int ksize_h, void* stream) {
   return guard([&] {
+    need_positive("frames_to_tensor", {{"frames", T}, {"H", H}, {"W", W}, {"out H", OH}, {"out W", OW}});
     HIPCHK(launch_frames_to_tensor(frames, out, tmp, T, H, W, OH, OW, bounds_w, coef_w, ksize_w, bounds_h, coef_h, ksize_h,
                                    (hipStream_t)stream));
   });
@@ -3349,12 +3363,16 @@ int df_frames_to_tensor(const uint8_t* frames, float* out, uint8_t* tmp, int T, 
 
 int df_mel_to_stft(const float* mel, int B, int n_mels, int T, const float* A, const float* At, const float* Pt, float inv_L,
                    int iters, float* S, void* stream) {
-  return guard([&] { HIPCHK(launch_mel_to_stft(mel, B, n_mels, T, A, At, Pt, inv_L, iters, S, (hipStream_t)stream)); });
+  return guard([&] {
+    need_positive("mel_to_stft", {{"clips", B}, {"mel bins", n_mels}, {"frames", T}});
+    HIPCHK(launch_mel_to_stft(mel, B, n_mels, T, A, At, Pt, inv_L, iters, S, (hipStream_t)stream));
+  });
 }
 int df_griffinlim(const float* S, const float* phase0, int B, int T, int n_iter, float momentum, const float* twiddles,
                   const float* window, const float* wss, float* angles, float* reb0, float* reb1, float* frames, float* wav,
                   void* stream) {
   return guard([&] {
+    need_positive("griffinlim", {{"clips", B}, {"frames", T}});
     HIPCHK(launch_griffinlim(S, phase0, B, T, n_iter, momentum, (const float2*)twiddles, window, wss, (float2*)angles,
                              (float2*)reb0, (float2*)reb1, frames, wav, (hipStream_t)stream));
   });

@@ -193,6 +193,25 @@ def _want_dim(what, got, want):
         raise RuntimeError(f"{what}: last dimension is {got}, the loaded model expects {want}")
 
 
+def _want_nchw(what, x, channels):
+    """x must be [N][channels][H][W]: the engine derives every address from these four numbers."""
+    if x.ndim != 4:
+        raise RuntimeError(f"{what}: expected a 4-D NCHW tensor, got shape {tuple(x.shape)}")
+    if channels is not None and int(x.shape[1]) != int(channels):
+        raise RuntimeError(f"{what}: {x.shape[1]} channels, the loaded model expects {channels}")
+
+
+def _timesteps(t, n, device):
+    """One timestep per batch row.  A one-element t stands for all rows (the reference's time embedding broadcasts over the
+    batch, openai_unetmodel.py:262-271); any other length is the reference's shape error, not an out-of-bounds read."""
+    t = _dev_f32(t, device).reshape(-1)
+    if t.numel() == 1 and n != 1:
+        t = t.expand(n).contiguous()
+    if t.numel() != n:
+        raise RuntimeError(f"timesteps: {t.numel()} values for a batch of {n}")
+    return t
+
+
 def _ilist(cls, n, vals):
     a = (C.c_int * n)()
     for i, v in enumerate(vals):
@@ -398,18 +417,20 @@ class Engine:
 
     def unet_forward(self, x, t, out=None, ts_index=None):
         x = _dev_f32(x, self.device)
+        _want_nchw("UNet input", x, getattr(self, "unet_in_channels", None))
         N, Cc, H, W = x.shape
         if out is None:
             out = torch.empty(N, self.unet_out_channels, H, W, device=self.device, dtype=torch.float32)
         if ts_index is not None:
             _chk(self.L.df_unet_forward_ts(self._h, _ptr(x), int(ts_index), _ptr(out), N, H, W, _stream()), self.L)
             return out
-        t = _dev_f32(t, self.device)
+        t = _timesteps(t, N, self.device)
         _chk(self.L.df_unet_forward(self._h, _ptr(x), _ptr(t), _ptr(out), N, H, W, _stream()), self.L)
         return out
 
     def unet_forward_cfg(self, x, t, scale, out=None, ts_index=None):
         x = _dev_f32(x, self.device)
+        _want_nchw("UNet input", x, getattr(self, "unet_in_channels", None))
         B, Cc, H, W = x.shape
         if out is None:
             out = torch.empty(B, self.unet_out_channels, H, W, device=self.device, dtype=torch.float32)
@@ -417,12 +438,13 @@ class Engine:
             _chk(self.L.df_unet_forward_cfg_ts(self._h, _ptr(x), int(ts_index), _ptr(out), B, H, W, float(scale), _stream()),
                  self.L)
             return out
-        t = _dev_f32(t, self.device)
+        t = _timesteps(t, B, self.device)
         _chk(self.L.df_unet_forward_cfg(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, float(scale), _stream()), self.L)
         return out
 
     def vae_decode(self, z):
         z = _dev_f32(z, self.device)
+        _want_nchw("decode_first_stage: latent", z, getattr(self, "vae_z_channels", None))
         B, Cc, H, W = z.shape
         up = 2 ** (self.vae_n_mult - 1)
         out = torch.empty(B, self.vae_out_ch, H * up, W * up, device=self.device, dtype=torch.float32)
@@ -431,9 +453,12 @@ class Engine:
 
     def classifier_forward(self, x, t, feat):
         x = _dev_f32(x, self.device)
-        t = _dev_f32(t, self.device)
         feat = _dev_f32(feat, self.device)
+        _want_nchw("classifier input", x, getattr(self, "cls_in_channels", None))
         B, Cc, H, W = x.shape
+        t = _timesteps(t, B, self.device)
+        if feat.ndim != 3 or feat.shape[0] != B:
+            raise RuntimeError(f"classifier video_feat: expected [{B}][frames][dim], got shape {tuple(feat.shape)}")
         _want_dim("classifier video_feat", feat.shape[2], getattr(self, "cls_context_dim", None))
         out = torch.empty(B, self.cls_out_channels, device=self.device, dtype=torch.float32)
         _chk(self.L.df_classifier_forward(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(out), B, H, W, feat.shape[1],
@@ -442,9 +467,12 @@ class Engine:
 
     def classifier_grad(self, x, t, feat, want_prob=False):
         x = _dev_f32(x, self.device)
-        t = _dev_f32(t, self.device)
         feat = _dev_f32(feat, self.device)
+        _want_nchw("classifier input", x, getattr(self, "cls_in_channels", None))
         B, Cc, H, W = x.shape
+        t = _timesteps(t, B, self.device)
+        if feat.ndim != 3 or feat.shape[0] != B:
+            raise RuntimeError(f"classifier video_feat: expected [{B}][frames][dim], got shape {tuple(feat.shape)}")
         _want_dim("classifier video_feat", feat.shape[2], getattr(self, "cls_context_dim", None))
         grad = torch.empty_like(x)
         prob = torch.empty(B, 1, device=self.device, dtype=torch.float32) if want_prob else None

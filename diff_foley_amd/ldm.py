@@ -283,6 +283,8 @@ class LatentDiffusion:
         eng.cond_origin_dim = self.cond_cfg["origin_dim"]
         eng.unet_context_dim = self.unet_cfg["context_dim"]
         eng.unet_out_channels = self.unet_cfg["out_channels"]
+        eng.unet_in_channels = self.unet_cfg["in_channels"]
+        eng.vae_z_channels = self.vae_cfg["z_channels"]
         eng.vae_out_ch = self.vae_cfg["out_ch"]
         eng.vae_n_mult = len(self.vae_cfg["ch_mult"])
         return eng
@@ -453,6 +455,7 @@ class AlignmentClassifier:
         self.engine = ldm._require()
         self.engine.config_classifier(self.cfg)
         self.engine.cls_out_channels = self.cfg["out_channels"]
+        self.engine.cls_in_channels = self.cfg["in_channels"]
         self.engine.cls_context_dim = self.cfg["context_dim"]
         for k, v in self._state.items():
             self.engine.load_tensor("classifier." + k, v)
