@@ -398,6 +398,8 @@ class Engine:
         B, T, D = feats.shape
         _want_dim("get_learned_conditioning: video features", D, getattr(self, "cond_origin_dim", None))
         out = torch.empty(B, T, self.cond_embed_dim, device=self.device, dtype=torch.float32)
+        if out.numel() == 0:      # an empty batch / sequence gives an empty result, like the reference's Linear + pos_emb[:0]
+            return out
         _chk(self.L.df_cond_encode(self._h, _ptr(feats), _ptr(out), B, T, _stream()), self.L)
         return out
 
@@ -405,12 +407,16 @@ class Engine:
         ctx = _dev_f32(ctx, self.device)
         N, T, D = ctx.shape
         _want_dim("cross-attention context", D, getattr(self, "unet_context_dim", None))
+        if N == 0:                # empty batch: nothing to precompute (the forward calls return empty tensors)
+            return
         _chk(self.L.df_unet_set_context(self._h, _ptr(ctx), N, T, _stream()), self.L)
 
     def set_timesteps(self, timesteps, batch, H, W, cfg):
         """Hoists the time embedding of a whole sample() call out of the step loop (df_unet_set_timesteps): ``timesteps`` are
         the values the sampler is going to visit, each shared by the whole batch; afterwards ``unet_forward*(…, ts_index=i)``
         takes the table row instead of the time-embedding launches.  ``batch`` = sampler batch (the CFG plan doubles it)."""
+        if int(batch) == 0:
+            return
         ts = (C.c_float * len(timesteps))(*[float(v) for v in timesteps])
         _chk(self.L.df_unet_set_timesteps(self._h, ts, len(timesteps), int(batch), int(H), int(W), 1 if cfg else 0, _stream()),
              self.L)
@@ -421,6 +427,8 @@ class Engine:
         N, Cc, H, W = x.shape
         if out is None:
             out = torch.empty(N, self.unet_out_channels, H, W, device=self.device, dtype=torch.float32)
+        if N == 0:                # an empty batch is an empty result (torch modules accept it; no plan exists for it)
+            return out
         if ts_index is not None:
             _chk(self.L.df_unet_forward_ts(self._h, _ptr(x), int(ts_index), _ptr(out), N, H, W, _stream()), self.L)
             return out
@@ -434,6 +442,8 @@ class Engine:
         B, Cc, H, W = x.shape
         if out is None:
             out = torch.empty(B, self.unet_out_channels, H, W, device=self.device, dtype=torch.float32)
+        if B == 0:
+            return out
         if ts_index is not None:
             _chk(self.L.df_unet_forward_cfg_ts(self._h, _ptr(x), int(ts_index), _ptr(out), B, H, W, float(scale), _stream()),
                  self.L)
@@ -448,6 +458,8 @@ class Engine:
         B, Cc, H, W = z.shape
         up = 2 ** (self.vae_n_mult - 1)
         out = torch.empty(B, self.vae_out_ch, H * up, W * up, device=self.device, dtype=torch.float32)
+        if B == 0:
+            return out
         _chk(self.L.df_vae_decode(self._h, _ptr(z), _ptr(out), B, H, W, _stream()), self.L)
         return out
 
@@ -461,6 +473,8 @@ class Engine:
             raise RuntimeError(f"classifier video_feat: expected [{B}][frames][dim], got shape {tuple(feat.shape)}")
         _want_dim("classifier video_feat", feat.shape[2], getattr(self, "cls_context_dim", None))
         out = torch.empty(B, self.cls_out_channels, device=self.device, dtype=torch.float32)
+        if B == 0:
+            return out
         _chk(self.L.df_classifier_forward(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(out), B, H, W, feat.shape[1],
                                          _stream()), self.L)
         return out
@@ -476,6 +490,8 @@ class Engine:
         _want_dim("classifier video_feat", feat.shape[2], getattr(self, "cls_context_dim", None))
         grad = torch.empty_like(x)
         prob = torch.empty(B, 1, device=self.device, dtype=torch.float32) if want_prob else None
+        if B == 0:
+            return (grad, prob) if want_prob else grad
         _chk(self.L.df_classifier_grad(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(prob) if want_prob else None,
                                       _ptr(grad), B, H, W, feat.shape[1], _stream()), self.L)
         return (grad, prob) if want_prob else grad
@@ -571,6 +587,8 @@ class Engine:
 def cfg_combine(e2, scale):
     B = e2.shape[0] // 2
     e = torch.empty((B,) + tuple(e2.shape[1:]), device=e2.device, dtype=torch.float32)
+    if e.numel() == 0:
+        return e
     _chk(lib().df_cfg_combine(_ptr(e2), _ptr(e), e.numel(), float(scale), _stream()))
     return e
 
@@ -581,6 +599,8 @@ def lincomb(terms, out=None):
     ts = [t.contiguous() for _, t in terms]
     if out is None:
         out = torch.empty_like(ts[0])
+    if out.numel() == 0:
+        return out
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
     coefs = (C.c_float * n)(*[float(c) for c, _ in terms])
     _chk(lib().df_lincomb(_ptr(out), ptrs, coefs, n, out.numel(), _stream()))
@@ -595,6 +615,8 @@ def q_sample_blend(img, x0, noise, mask, sqrt_acp, sqrt_one_minus_acp):
     if mask.dim() != 4 or mask.shape[0] != B or mask.shape[1] not in (1, Cc) or tuple(mask.shape[2:]) != (H, W):
         raise ValueError(f"mask of shape {tuple(mask.shape)} does not match a latent of shape {tuple(img.shape)} ([B][1|C][H][W])")
     out = torch.empty_like(img)
+    if out.numel() == 0:
+        return out
     _chk(lib().df_q_sample_blend(_ptr(img), _ptr(x0), _ptr(noise), _ptr(mask), _ptr(out), img.numel(), Cc * H * W, H * W,
                                  int(mask.shape[1]), float(sqrt_acp), float(sqrt_one_minus_acp), _stream()))
     return out
@@ -603,6 +625,8 @@ def q_sample_blend(img, x0, noise, mask, sqrt_acp, sqrt_one_minus_acp):
 def ddim_update(x, e, a_t, a_prev, sigma_t, sqrt_one_minus_at, noise=None):
     x_prev = torch.empty_like(x)
     pred_x0 = torch.empty_like(x)
+    if x.numel() == 0:
+        return x_prev, pred_x0
     _chk(lib().df_ddim_update(_ptr(x), _ptr(e), _ptr(noise) if noise is not None else None, _ptr(x_prev),
                               _ptr(pred_x0), x.numel(), float(a_t), float(a_prev), float(sigma_t),
                               float(sqrt_one_minus_at), _stream()))

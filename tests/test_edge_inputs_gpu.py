@@ -27,20 +27,38 @@ def cond(tiny):
     return tiny.get_learned_conditioning(synth.synthetic_cavp(2, 32, 64).cuda())
 
 
-def test_empty_inputs_raise_instead_of_crashing(tiny, cond):
+def test_empty_batches_give_empty_results_and_empty_maps_raise(tiny, cond):
+    """A torch module takes a zero-row batch and returns a zero-row result (conv / GroupNorm / attention all do); so does the facade
+    -- without a plan, without a launch -- which is what a rank with an empty shard of a small global batch needs
+    (parallel.shard_range).  Zero-sized MAPS have no reference behaviour worth keeping: they raise."""
     z = lambda *s: torch.zeros(*s).cuda()
-    with pytest.raises(RuntimeError, match="must be positive"):
-        tiny.get_learned_conditioning(z(0, 32, 64))
-    with pytest.raises(RuntimeError, match="must be positive"):
-        tiny.get_learned_conditioning(z(2, 0, 64))
-    with pytest.raises(RuntimeError, match="must be positive"):
-        tiny.decode_first_stage(z(0, 4, 16, 64))
-    with pytest.raises(RuntimeError, match="must be positive"):
-        tiny.apply_model(z(0, 4, 16, 64), z(0), cond[:0])
-    with pytest.raises(RuntimeError, match="must be positive"):
-        tiny.sample_log_diff_sampler(cond[:0], 0, "DDIM", 4)
+    assert tiny.get_learned_conditioning(z(0, 32, 64)).shape == (0, 32, 128)
+    assert tiny.get_learned_conditioning(z(2, 0, 64)).shape == (2, 0, 128)
+    assert tiny.decode_first_stage(z(0, 4, 16, 64)).shape == (0, 3, 64, 256)
+    assert tiny.apply_model(z(0, 4, 16, 64), z(0), cond[:0]).shape == (0, 4, 16, 64)
+    for name in ("DDIM", "PLMS", "DPM_Solver"):
+        zz, inter = tiny.sample_log_diff_sampler(cond[:0], 0, name, 4, unconditional_guidance_scale=4.5,
+                                                 unconditional_conditioning=cond[:0])
+        assert zz.shape == (0, 4, 16, 64)
+        assert inter is None or all(t.shape == (0, 4, 16, 64) for t in inter["x_inter"])
+    zz, inter = tiny.sample(cond[:0], batch_size=0, return_intermediates=True, timesteps=3, shape=(0, 4, 16, 64))
+    assert zz.shape == (0, 4, 16, 64) and len(inter) >= 1
     with pytest.raises(RuntimeError, match="must be positive"):
         tiny.decode_first_stage(z(1, 4, 0, 64))
+    with pytest.raises(RuntimeError, match="must be positive"):
+        tiny.apply_model(z(1, 4, 0, 64), z(1), cond[:1])
+    with pytest.raises(RuntimeError, match="must be positive"):          # a context without tokens: softmax over nothing
+        tiny.apply_model(z(2, 4, 16, 64), z(2), torch.zeros(2, 0, 128).cuda())
+    # straight at the C ABI (a binding that does not check): an exception with a message, never a signal
+    eng = tiny.engine
+    from diff_foley_amd.engine import _chk, _ptr, _stream
+    out = z(1)
+    with pytest.raises(RuntimeError, match="must be positive"):
+        _chk(eng.L.df_cond_encode(eng._h, _ptr(out), _ptr(out), 0, 32, _stream()), eng.L)
+    with pytest.raises(RuntimeError, match="must be positive"):
+        _chk(eng.L.df_vae_decode(eng._h, _ptr(out), _ptr(out), 0, 16, 64, _stream()), eng.L)
+    with pytest.raises(RuntimeError, match="must be positive|UNet batch is 0"):
+        _chk(eng.L.df_unet_forward(eng._h, _ptr(out), _ptr(out), _ptr(out), 0, 16, 64, _stream()), eng.L)
     # the model is still usable afterwards
     assert torch.isfinite(tiny.decode_first_stage(z(1, 4, 16, 64))).all()
 
