@@ -203,8 +203,12 @@ __global__ __launch_bounds__(256) void gl_stft_kernel(const float* __restrict__ 
   const float* yb = y + (f / T) * L;
   for (int j = tid; j < NFFT; j += 256) {
     int i = t * HOPV + j - NFFT / 2;               // np.pad(mode="reflect"): no edge repeat
-    if (i < 0) i = -i;
-    if (i >= L) i = 2 * (L - 1) - i;
+    if (i < 0 || i >= L) {                         // clips shorter than the 512-sample pad (T <= 3) reflect more than once: the
+      const int P = 2 * (L - 1);                   // padded signal is the triangular wave of period 2 (L - 1), as numpy builds it
+      i = P > 0 ? i % P : 0;
+      if (i < 0) i += P;
+      if (i >= L) i = P - i;
+    }
     s[brev10(j)] = make_float2(yb[i] * window[j], 0.f);
   }
   fft1024(s, tw, tid, 1.f);

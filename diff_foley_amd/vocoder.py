@@ -91,6 +91,8 @@ def mel_to_stft(mel, nnls_iters=200):
     B, NM, T = mel.shape
     c = _get_consts(NM, T, mel.device)
     S = torch.empty(B, T, N_BIN, dtype=torch.float32, device=mel.device)
+    if S.numel() == 0:                    # empty batch / no frames: an empty result
+        return S
     L = E.lib()
     E._chk(L.df_mel_to_stft(_p(mel), B, NM, T, _p(c.A), _p(c.At), _p(c.Pt), c.inv_L, int(nnls_iters), _p(S), E._stream()), L)
     return S
@@ -107,6 +109,8 @@ def griffinlim(S, phase0=None, n_iter=32, momentum=0.99, generator=None):
     if phase0 is None:
         phase0 = torch.rand(B, N_BIN, T, device=dev, generator=generator)
     phase0 = phase0.to(dev, torch.float32).contiguous()
+    if B == 0 or T <= 1:                  # no clips, or a single frame (zero hops of audio): an empty waveform
+        return torch.empty(B, HOP * max(T - 1, 0), dtype=torch.float32, device=dev)
     c = _get_consts(128, T, dev)          # window / sum-square / twiddles do not depend on the mel size
     ang = torch.empty(B, T, N_BIN, 2, dtype=torch.float32, device=dev)
     r0, r1 = torch.empty_like(ang), torch.empty_like(ang)
