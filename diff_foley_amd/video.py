@@ -67,6 +67,10 @@ def frames_to_tensor(frames, size=(224, 224)):
     frames = frames.to(dev).contiguous()
     T, H, W, _ = frames.shape
     oh, ow = int(size[0]), int(size[1])
+    if oh <= 0 or ow <= 0 or H <= 0 or W <= 0:
+        raise ValueError(f"frames_to_tensor: frame size {H} x {W} -> {oh} x {ow} (every size must be positive)")
+    if T == 0:
+        return torch.empty(0, 3, oh, ow, dtype=torch.float32, device=dev)
     key = (H, W, oh, ow, dev)
     if key not in _tables:
         _tables[key] = _Tables(H, W, oh, ow, dev)
