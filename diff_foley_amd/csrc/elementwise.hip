@@ -570,17 +570,16 @@ __global__ void pack_latent_kernel(const float* __restrict__ x, bf16_t* __restri
   if (i >= total) return;
   const int px = (int)(i % HW);
   const int b = (int)((i / HW) % B);
-  float v[8];
-  for (int c = 0; c < C; ++c) v[c] = x[((long)b * C + c) * HW + px] * in_scale;
+  const float* xp = x + (long)b * C * HW + px;        // any C <= cpad (the reference's in_channels / z_channels are constructor arguments)
   bf16_t* o = out + i * cpad;
   if (wpq) {
     for (int oc = 0; oc < C; ++oc) {
       float s = bpq[oc];
-      for (int c = 0; c < C; ++c) s += wpq[oc * C + c] * v[c];
+      for (int c = 0; c < C; ++c) s += wpq[oc * C + c] * (xp[(long)c * HW] * in_scale);
       o[oc] = f2bf(s);
     }
   } else {
-    for (int c = 0; c < C; ++c) o[c] = f2bf(v[c]);
+    for (int c = 0; c < C; ++c) o[c] = f2bf(xp[(long)c * HW] * in_scale);
   }
   for (int c = C; c < cpad; ++c) o[c] = 0;
 }
@@ -949,7 +948,7 @@ hipError_t launch_timestep_embedding(const float* t, float* out, int N, int dim,
 
 hipError_t launch_pack_latent(const float* x, uint16_t* out, int B, int C, int HW, int cpad, int rep, float in_scale,
                               const float* wpq, const float* bpq, hipStream_t s) {
-  if (C > 8) return hipErrorInvalidValue;
+  if (C > cpad || C <= 0) return hipErrorInvalidValue;
   const long n = (long)rep * B * HW;
   hipLaunchKernelGGL(pack_latent_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, x, out, B, C, HW, cpad, rep,
                      in_scale, wpq, bpq);
@@ -958,7 +957,7 @@ hipError_t launch_pack_latent(const float* x, uint16_t* out, int B, int C, int H
 
 hipError_t launch_pack_latent_bcast(const float* x, uint16_t* out, int B, int C, int HW, int cpad, int rep, const float* src,
                                     float* dst, int rows, int n, hipStream_t s) {
-  if (C > 8 || n <= 0 || (n & 3) != 0 || rows <= 0) return hipErrorInvalidValue;
+  if (C > cpad || C <= 0 || n <= 0 || (n & 3) != 0 || rows <= 0) return hipErrorInvalidValue;
   const long np = (long)rep * B * HW;
   const int npack = (int)((np + 255) / 256), nb = grid_for(n / 4);
   hipLaunchKernelGGL(pack_latent_bcast_kernel, dim3(npack + nb), dim3(256), 0, s, x, out, B, C, HW, cpad, rep, npack,

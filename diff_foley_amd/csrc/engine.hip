@@ -1433,6 +1433,7 @@ void build_unet_like(df_ctx* c, Plan* pl, int which, int N, int H, int W, int Tc
 
   // ---- input packing: NCHW fp32 -> NHWC bf16 (channels padded to 64), CFG duplication folded in
   const int cin = u.in_channels;
+  if (cin < 1 || cin > 64) fail("in_channels = %d: the first conv's operand is one 64-channel K step (1 .. 64 input channels)", cin);
   // Classifier-free guidance runs the batch [x ; x] with the contexts [uncond ; cond]: everything in front of the first
   // cross-attention -- conv_in, the first ResBlock, and the first SpatialTransformer up to its self-attention out-projection --
   // is identical in both halves.  Those ops run on ONE half; the ops whose outputs the full batch needs (conv_in -> skip +
@@ -1723,6 +1724,7 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
     b.other("t.embproj", [=](hipStream_t s, const RunArgs&) { return launch_linear_rows(semb, temb, w, bb, E, etot, N, etot, temb, 0, s); });
   }
   const int cin = u.in_channels;
+  if (cin < 1 || cin > 64) fail("in_channels = %d: the first conv's operand is one 64-channel K step (1 .. 64 input channels)", cin);
   bf16_t* xin = b.buf<bf16_t>((size_t)N * HW * 64);
   b.other("x.pack", [=](hipStream_t s, const RunArgs& a) { return launch_pack_latent(a.x, xin, N, cin, HW, 64, 1, 1.0f, nullptr, nullptr, s); });
 
@@ -2016,6 +2018,9 @@ void build_vae(df_ctx* c, Plan* pl, int B, int H, int W) {
   const std::string pre = "first_stage_model.";
   Builder b{c, pl, pre, 0};
   const int zc = v.z_channels;
+  if (zc < 1 || zc > 64 || v.embed_dim != zc)
+    fail("vae: z_channels = %d, embed_dim = %d: post_quant_conv is applied as a square 1x1 mix of 1 .. 64 latent channels while the "
+         "latent is packed", zc, v.embed_dim);
   int hh = H, ww = W;
   int ch = v.ch * v.ch_mult[v.n_mult - 1];
   bf16_t* zin = b.buf<bf16_t>((size_t)B * hh * ww * 64);

@@ -1,5 +1,6 @@
 """Randomised differential test of the plan builder over UNet CONFIGURATIONS: the reference's UNetModel is a constructor over
-(model_channels, channel_mult, num_res_blocks, attention_resolutions, num_heads, context_dim) (openai_unetmodel.py:451-692), and a
+(in_channels, out_channels, model_channels, channel_mult, num_res_blocks, attention_resolutions, num_heads, context_dim)
+(openai_unetmodel.py:451-692), and a
 user of the reference may bring another YAML than Stage2_LDM.yaml.  Seeded draws of those arguments (inside what GroupNorm32 and the
 attention kernel's head dimensions admit), procedurally generated weights for each, one ``apply_model`` through the facade
 (libdfengine_f16.so) against the oracle's fp32 forward (oracle/unet.py) at a random latent size / context length / batch, and one
@@ -34,7 +35,8 @@ def _draw(seed):
         heads = [h for h in (1, 2, 4, 8) if all(ch % h == 0 and ch // h in HEAD_DIMS for ch in chs)]
         if mc * max(mult) <= 768 and heads:
             break
-    cfg = dict(in_channels=4, out_channels=4, model_channels=mc, attention_resolutions=att, num_res_blocks=nrb, channel_mult=mult,
+    cin, cout = (4, 4) if seed % 2 == 0 else (int(r.choice([1, 3, 8, 9, 16, 64])), int(r.choice([1, 3, 8, 64])))
+    cfg = dict(in_channels=cin, out_channels=cout, model_channels=mc, attention_resolutions=att, num_res_blocks=nrb, channel_mult=mult,
                num_heads=int(r.choice(heads)), context_dim=int(r.choice([64, 128, 192, 320])))
     q = 2 ** (levels - 1)
     H = int(r.choice([h for h in (8, 16) if h % q == 0]))
@@ -56,7 +58,7 @@ def test_unet_configuration_product_vs_oracle(seed):
     usd = ou.sub_state_dict(sd, "model.diffusion_model.")
     g = torch.Generator().manual_seed(300 + seed)
     B, H, W, T = o["B"], o["H"], o["W"], o["T"]
-    x = torch.randn(B, 4, H, W, generator=g)
+    x = torch.randn(B, cfg["in_channels"], H, W, generator=g)
     c = torch.randn(B, T, cfg["context_dim"], generator=g)
     t = torch.randint(0, 1000, (B,), generator=g)
     ref = ou.unet_forward(usd, cfg, x, t, c)
