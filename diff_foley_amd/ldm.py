@@ -33,6 +33,10 @@ _UNET_FIXED = dict(dims=2, dropout=0, conv_resample=True, num_classes=None, num_
                    use_spatial_transformer=True, transformer_depth=1, n_embed=None, legacy=False)
 
 
+_VAE_FIXED = dict(attn_resolutions=[], dropout=0.0, resamp_with_conv=True, give_pre_end=False, tanh_out=False,
+                  use_linear_attn=False, attn_type="vanilla")
+
+
 def _unet_params(cfg, what):
     p = _params(cfg)
     for k, v in _UNET_FIXED.items():
@@ -157,6 +161,12 @@ class LatentDiffusion:
         self.unet_cfg = _unet_params(unet_config, "unet_config")
         fs = _params(first_stage_config)
         dd = dict(fs["ddconfig"])
+        # Decoder constructor arguments (stage1_autoencoder/model.py:557-561) whose non-default values select code that is not built
+        # here (attention inside the up levels, conv-less / tanh / pre-end outputs, linear attention): refused, not ignored
+        for k, v in _VAE_FIXED.items():
+            if k in dd and (list(dd[k]) if isinstance(v, list) else dd[k]) != v and not (k == "dropout" and float(dd[k]) == 0.0):
+                raise NotImplementedError(f"first_stage_config.ddconfig: {k}={dd[k]!r} is not supported by libdfengine "
+                                          f"(built for {k}={v!r})")
         self.vae_cfg = dict(z_channels=dd["z_channels"], embed_dim=fs["embed_dim"], ch=dd["ch"],
                             ch_mult=[int(v) for v in dd["ch_mult"]], num_res_blocks=dd["num_res_blocks"],
                             out_ch=dd["out_ch"])

@@ -54,6 +54,17 @@ def test_unsupported_unet_variants_are_refused(bad):
         P.AlignmentClassifier(classifier_config=cc)
 
 
+@pytest.mark.parametrize("bad", [dict(attn_resolutions=[16]), dict(resamp_with_conv=False), dict(tanh_out=True),
+                                 dict(give_pre_end=True), dict(use_linear_attn=True), dict(attn_type="linear"), dict(dropout=0.1)])
+def test_unsupported_decoder_variants_are_refused(bad):
+    """Decoder constructor arguments (stage1_autoencoder/model.py:557-561) that select code which is not built: refused when the
+    model is constructed, never ignored (an ignored ``attn_resolutions`` would decode with a different network)."""
+    cfg = P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
+    cfg["first_stage_config"]["params"]["ddconfig"].update(bad)
+    with pytest.raises(NotImplementedError):
+        P.LatentDiffusion(**cfg)
+
+
 def test_reference_yaml_defaults_are_accepted():
     cfg = P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
     cfg["unet_config"]["params"].update(dict(transformer_depth=1, legacy=False, use_checkpoint=True, image_size=32,
