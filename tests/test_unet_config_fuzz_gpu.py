@@ -76,3 +76,32 @@ def test_unet_configuration_product_vs_oracle(seed):
     print(f"case {seed}: {cfg} {o} -> rel-L2 {err:.2e}, CFG {err_cfg:.2e}")
     assert err < TOL, (cfg, o, err)
     assert err_cfg < 3 * TOL, (cfg, o, err_cfg)          # guidance amplifies the (e_c - e_u) rounding by the scale
+
+
+@pytest.mark.parametrize("W", [24, 32, 128])
+def test_full_model_on_other_latent_widths(W):
+    """``size_len`` other than 64 at FULL size (3 s / 4 s / 16 s of audio): the shipped plan table holds the 16 x 64 shapes, so every GEMM
+    takes the entry of its nearest row count (or the cost model's tile) and every halo conv a patch geometry of another map -- one
+    forward, the cond half of the CFG plan and the VAE decode against the oracle's fp32 results on the same inputs."""
+    import diff_foley_amd as P
+    from diff_foley_amd import synth
+    from helpers import full_state_dict
+    from oracle import unet as ou, vae as ov
+    sd = full_state_dict()
+    m = P.LatentDiffusion(**P.stage2_config())          # the facade's default operand type (fp16)
+    m.load_state_dict(sd)
+    m.cuda()
+    usd = ou.sub_state_dict(sd, "model.diffusion_model.")
+    vsd = ou.sub_state_dict(sd, "first_stage_model.")
+    g = torch.Generator().manual_seed(W)
+    x, c, t = torch.randn(1, 4, 16, W, generator=g), torch.randn(1, 32, 768, generator=g) * 0.05, torch.tensor([481])
+    ref = ou.unet_forward(usd, synth.UNET_FULL, x, t, c)
+    y = m.apply_model(x.cuda(), t.cuda(), c.cuda()).cpu()
+    m.engine.set_context(torch.cat([torch.zeros_like(c), c]).cuda())
+    ycfg = m.engine.unet_forward_cfg(x.cuda(), t.float().cuda(), 1.0).cpu()           # scale 1 = the cond half of the 2-row plan
+    z = torch.randn(1, 4, 16, W, generator=g)
+    d = m.decode_first_stage(z.cuda()).cpu()
+    dref = ov.decode_first_stage(vsd, synth.VAE_FULL, z)
+    errs = rel_l2(y, ref), rel_l2(ycfg, ref), rel_l2(d, dref)
+    print(f"full model, 16 x {W} latent: unet {errs[0]:.2e}, CFG plan {errs[1]:.2e}, vae {errs[2]:.2e}")
+    assert errs[0] < 3e-3 and errs[1] < 3e-3 and errs[2] < 3e-3, (W, errs)           # the 16 x 64 goldens' bounds on this build
