@@ -106,3 +106,33 @@ def test_double_guidance_on_a_wide_latent(name, S):
     err = rel_l2(z.cpu(), z_ref)
     print(f"double guidance on a 16 x {W} latent, {name}-{S}: rel-L2 {err:.2e}")
     assert z.shape == (B, 4, 16, W) and err < 1e-2
+
+
+@pytest.mark.parametrize("W", [32, 64, 128, 192])
+def test_full_classifier_gradient_on_other_latent_widths(W):
+    """The FULL alignment classifier (Classifier_Backbone as configured in the reference's double-guidance YAML) on 16 x W latents:
+    W = 128 / 192 put 512 / 768 tokens into its first attention level -- the tiled backward pair -- W = 32 / 64 stay on the
+    LDS-resident MFMA kernel.  Gradient and probability against autograd through the oracle."""
+    import diff_foley_amd as P
+    from diff_foley_amd import synth
+    from helpers import full_classifier_sd
+    from oracle import unet as ou, samplers as osamp
+    host = P.LatentDiffusion(precision="fp16", **P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
+    host.load_state_dict(tiny_state_dict())
+    host.cuda()
+    sd = full_classifier_sd()
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_FULL)))
+    cls.load_state_dict(sd)
+    cls.attach(host)
+    ksd = ou.sub_state_dict(sd, "model.")
+    g = torch.Generator().manual_seed(W)
+    B = 2
+    x = torch.randn(B, 4, 16, W, generator=g)
+    vf = synth.synthetic_cavp(B, 33, 512, seed=W)
+    t = torch.tensor([640.0, 12.0])
+    p_ref = ou.classifier_forward(ksd, synth.CLS_FULL, x, t, vf).detach()
+    g_ref = osamp.classifier_grad(lambda xx, tt, cc: ou.classifier_forward(ksd, synth.CLS_FULL, xx, tt, cc), x, t, vf)
+    grad, prob = host.engine.classifier_grad(x.cuda(), t.cuda(), vf.cuda(), want_prob=True)
+    err = rel_l2(grad.cpu(), g_ref)
+    print(f"full classifier, 16 x {W} latent: p {prob.flatten().tolist()} (ref {p_ref.flatten().tolist()}), grad rel-L2 {err:.2e}")
+    assert torch.allclose(prob.cpu(), p_ref, atol=5e-3) and err < 1e-2, (W, err)
