@@ -16,7 +16,7 @@ from helpers import rel_l2, tiny_state_dict
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-2
-N_CASES = 20
+N_CASES = 16
 
 
 @pytest.fixture(scope="module")
@@ -136,3 +136,49 @@ def test_sampler_options_product_vs_oracle(tiny16, oracle_tiny, seed):
     err = rel_l2(z.cpu(), z_ref)
     print(f"case {seed}: {o} -> rel-L2 {err:.2e}")
     assert err < TOL, (o, err)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_double_guidance_options_product_vs_oracle(tiny16, oracle_tiny, seed):
+    """The classifier-guided samplers (ddim.py:276-396, dpm_solver/sampler.py:90-156 -> dpm_solver.py:1377-1393) over their options:
+    sampler, steps, batch, latent width, CFG scale, classifier scale (0 = the gradient is formed and multiplied away), video frames
+    33 (the notebook's) / 32 / 8, eta for DDIM.  Oracle: the same loops with autograd through the oracle's classifier."""
+    import diff_foley_amd as P
+    from diff_foley_amd import synth
+    from helpers import tiny_classifier_sd
+    from oracle import unet as ou, samplers as osamp
+    apply_model, cond_fn, sched = oracle_tiny
+    r = np.random.default_rng(7600 + seed)
+    name = ["DDIM", "DPM_Solver"][seed % 2]
+    B, W = int(r.choice([1, 2, 3])), int(r.choice([32, 64]))
+    S = int(r.choice([4, 6, 8])) if name == "DDIM" else int(r.choice([3, 6, 16]))
+    scale, cscale = float(r.choice([2.5, 4.5])), float(r.choice([0.0, 10.0, 50.0]))
+    F = int(r.choice([8, 32, 33]))
+    eta = float(r.choice([0.0, 1.0])) if name == "DDIM" else 0.0
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_TINY)))
+    cls.load_state_dict(tiny_classifier_sd())
+    cls.attach(tiny16)
+    ksd = ou.sub_state_dict(tiny_classifier_sd(), "model.")
+    classifier = lambda x, t, c: ou.classifier_forward(ksd, synth.CLS_TINY, x, t, c)
+    g = torch.Generator().manual_seed(9600 + seed)
+    vf = torch.randn(B, F, 64, generator=g)
+    vf = vf / vf.norm(dim=-1, keepdim=True)
+    xT = torch.randn(B, 4, 16, W, generator=g)
+    c_ref = cond_fn(vf[:, :32])
+    c = tiny16.get_learned_conditioning(vf[:, :32].cuda())
+    noise = lambda s: torch.randn(tuple(s))
+    torch.manual_seed(300 + seed)
+    if name == "DDIM":
+        z_ref, _ = osamp.ddim_sample(apply_model, sched["alphas_cumprod"], S, xT, c_ref, scale, torch.zeros_like(c_ref), eta=eta,
+                                     classifier=classifier, origin_cond=vf, classifier_scale=cscale, noise_fn=noise)
+    else:
+        z_ref, _ = osamp.dpm_solver_sample(apply_model, sched["alphas_cumprod"], S, xT, c_ref, scale, torch.zeros_like(c_ref),
+                                           classifier=classifier, origin_cond=vf, classifier_scale=cscale)
+    torch.manual_seed(300 + seed)
+    kw = dict(eta=eta, noise_fn=noise) if name == "DDIM" else {}
+    z, _ = tiny16.sample_log_with_classifier_diff_sampler(
+        c, origin_cond=vf.cuda(), batch_size=B, sampler_name=name, ddim_steps=S, size_len=W, unconditional_guidance_scale=scale,
+        unconditional_conditioning=torch.zeros_like(c), classifier=cls, classifier_guide_scale=cscale, x_T=xT.clone(), **kw)
+    err = rel_l2(z.cpu(), z_ref)
+    print(f"double guidance case {seed}: {name}-{S} B={B} W={W} scale={scale} classifier scale={cscale} frames={F} eta={eta} -> rel-L2 {err:.2e}")
+    assert z.shape == z_ref.shape and err < TOL, (name, S, B, W, scale, cscale, F, eta, err)
