@@ -83,6 +83,7 @@ def test_reload_and_move_keep_results_and_engines_are_released():
     del m
     gc.collect()
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()                               # torch's cached blocks are not what is measured
     free0 = torch.cuda.mem_get_info()[0]
     for _ in range(6):                                     # engines own raw HIP allocations (weights, packed operands, plans)
         mm = _model()
@@ -90,5 +91,6 @@ def test_reload_and_move_keep_results_and_engines_are_released():
         del mm
         gc.collect()
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, (free0, free1)        # nothing accumulates across create / destroy cycles
