@@ -282,6 +282,7 @@ class Engine:
         _chk(self.L.df_create(self.device.index or 0, C.byref(h)), self.L)
         self._h = h
         self._keep = []
+        self._last_stream = {}            # plan family -> the torch stream of its previous call (_on)
         self.autotune_on = False
 
     def close(self):
@@ -327,7 +328,7 @@ class Engine:
         if c3 != 3:
             raise RuntimeError("cavp_encode: video must be (B,T,3,H,W)")
         out = torch.empty(B, T, self.cavp_embed_dim, device=self.device, dtype=torch.float32)
-        _chk(self.L.df_cavp_encode(self._h, _ptr(video), _ptr(out), B, T, H, W, int(bool(normalize)), _stream()), self.L)
+        _chk(self.L.df_cavp_encode(self._h, _ptr(video), _ptr(out), B, T, H, W, int(bool(normalize)), self._on("cavp")), self.L)
         return out
 
     def cavp_encode_pooled(self, video, normalize=True, kernel=16):
@@ -393,6 +394,19 @@ class Engine:
                                      _stream()), self.L)
 
     # ---- network calls (all asynchronous on the current torch stream)
+    def _on(self, family):
+        """The current stream's handle for a call into the plans of ``family``.  A torch module may be called from one stream after
+        another without an explicit wait (its activations are fresh allocations); a plan's workspace, context operands and timestep
+        table are state that lives across calls, so a call from ANOTHER stream than the family's previous one first waits for that
+        stream's submitted work (one event, only when the stream changes).  Families are independent of each other -- the classifier
+        gradient runs beside the UNet step on a second stream (samplers._eps_and_classifier_grad)."""
+        cur = torch.cuda.current_stream(self.device)
+        last = self._last_stream.get(family)
+        if last is not None and last != cur:
+            cur.wait_stream(last)
+        self._last_stream[family] = cur
+        return C.c_void_p(cur.cuda_stream)
+
     def cond_encode(self, feats):
         feats = _dev_f32(feats, self.device)
         B, T, D = feats.shape
@@ -400,7 +414,7 @@ class Engine:
         out = torch.empty(B, T, self.cond_embed_dim, device=self.device, dtype=torch.float32)
         if out.numel() == 0:      # an empty batch / sequence gives an empty result, like the reference's Linear + pos_emb[:0]
             return out
-        _chk(self.L.df_cond_encode(self._h, _ptr(feats), _ptr(out), B, T, _stream()), self.L)
+        _chk(self.L.df_cond_encode(self._h, _ptr(feats), _ptr(out), B, T, self._on("cond")), self.L)
         return out
 
     def set_context(self, ctx):
@@ -409,7 +423,7 @@ class Engine:
         _want_dim("cross-attention context", D, getattr(self, "unet_context_dim", None))
         if N == 0:                # empty batch: nothing to precompute (the forward calls return empty tensors)
             return
-        _chk(self.L.df_unet_set_context(self._h, _ptr(ctx), N, T, _stream()), self.L)
+        _chk(self.L.df_unet_set_context(self._h, _ptr(ctx), N, T, self._on("unet")), self.L)
 
     def set_timesteps(self, timesteps, batch, H, W, cfg):
         """Hoists the time embedding of a whole sample() call out of the step loop (df_unet_set_timesteps): ``timesteps`` are
@@ -418,7 +432,7 @@ class Engine:
         if int(batch) == 0:
             return
         ts = (C.c_float * len(timesteps))(*[float(v) for v in timesteps])
-        _chk(self.L.df_unet_set_timesteps(self._h, ts, len(timesteps), int(batch), int(H), int(W), 1 if cfg else 0, _stream()),
+        _chk(self.L.df_unet_set_timesteps(self._h, ts, len(timesteps), int(batch), int(H), int(W), 1 if cfg else 0, self._on("unet")),
              self.L)
 
     def unet_forward(self, x, t, out=None, ts_index=None):
@@ -430,10 +444,10 @@ class Engine:
         if N == 0:                # an empty batch is an empty result (torch modules accept it; no plan exists for it)
             return out
         if ts_index is not None:
-            _chk(self.L.df_unet_forward_ts(self._h, _ptr(x), int(ts_index), _ptr(out), N, H, W, _stream()), self.L)
+            _chk(self.L.df_unet_forward_ts(self._h, _ptr(x), int(ts_index), _ptr(out), N, H, W, self._on("unet")), self.L)
             return out
         t = _timesteps(t, N, self.device)
-        _chk(self.L.df_unet_forward(self._h, _ptr(x), _ptr(t), _ptr(out), N, H, W, _stream()), self.L)
+        _chk(self.L.df_unet_forward(self._h, _ptr(x), _ptr(t), _ptr(out), N, H, W, self._on("unet")), self.L)
         return out
 
     def unet_forward_cfg(self, x, t, scale, out=None, ts_index=None):
@@ -445,11 +459,11 @@ class Engine:
         if B == 0:
             return out
         if ts_index is not None:
-            _chk(self.L.df_unet_forward_cfg_ts(self._h, _ptr(x), int(ts_index), _ptr(out), B, H, W, float(scale), _stream()),
+            _chk(self.L.df_unet_forward_cfg_ts(self._h, _ptr(x), int(ts_index), _ptr(out), B, H, W, float(scale), self._on("unet")),
                  self.L)
             return out
         t = _timesteps(t, B, self.device)
-        _chk(self.L.df_unet_forward_cfg(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, float(scale), _stream()), self.L)
+        _chk(self.L.df_unet_forward_cfg(self._h, _ptr(x), _ptr(t), _ptr(out), B, H, W, float(scale), self._on("unet")), self.L)
         return out
 
     def vae_decode(self, z):
@@ -460,7 +474,7 @@ class Engine:
         out = torch.empty(B, self.vae_out_ch, H * up, W * up, device=self.device, dtype=torch.float32)
         if B == 0:
             return out
-        _chk(self.L.df_vae_decode(self._h, _ptr(z), _ptr(out), B, H, W, _stream()), self.L)
+        _chk(self.L.df_vae_decode(self._h, _ptr(z), _ptr(out), B, H, W, self._on("vae")), self.L)
         return out
 
     def classifier_forward(self, x, t, feat):
@@ -476,7 +490,7 @@ class Engine:
         if B == 0:
             return out
         _chk(self.L.df_classifier_forward(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(out), B, H, W, feat.shape[1],
-                                         _stream()), self.L)
+                                         self._on("cls")), self.L)
         return out
 
     def classifier_grad(self, x, t, feat, want_prob=False):
@@ -493,7 +507,7 @@ class Engine:
         if B == 0:
             return (grad, prob) if want_prob else grad
         _chk(self.L.df_classifier_grad(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(prob) if want_prob else None,
-                                      _ptr(grad), B, H, W, feat.shape[1], _stream()), self.L)
+                                      _ptr(grad), B, H, W, feat.shape[1], self._on("clsgrad")), self.L)
         return (grad, prob) if want_prob else grad
 
     def test_block(self, prefix, kind, x, semb=None, context=None, cout=None):
@@ -509,7 +523,7 @@ class Engine:
         T = 0 if context is None else context.shape[1]
         _chk(self.L.df_test_unet_block(self._h, prefix.encode(), kind, _ptr(xin), _ptr(semb) if semb is not None else None,
                                        _ptr(context) if context is not None else None, _ptr(out), N, H, W, Cin, cout, T,
-                                       _stream()), self.L)
+                                       self._on("unet")), self.L)
         return out.permute(0, 3, 1, 2).contiguous()
 
     def profile_begin(self):

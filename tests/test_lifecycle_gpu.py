@@ -32,10 +32,16 @@ def test_sampling_on_a_callers_stream_gives_the_default_streams_bits():
     m = _model()
     z0, d0 = _run(m)
     s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        z1, d1 = _run(m)
-    s.synchronize()
-    assert torch.equal(z0, z1) and torch.equal(d0, d1)
+    # no wait between the two: a torch module may be called from one stream right after another (fresh activations per call); the
+    # engine's plans keep workspaces across calls, so it orders the second stream behind the first itself (Engine._on) -- without
+    # that the two sample() calls overlap in one workspace (NaN / garbage, seen once in three suite runs)
+    for _ in range(3):
+        with torch.cuda.stream(s):
+            z1, d1 = _run(m)
+        z2, d2 = _run(m)                                   # ... and back on the default stream, again without a wait
+        s.synchronize()
+        torch.cuda.current_stream().synchronize()
+        assert torch.equal(z0, z1) and torch.equal(d0, d1) and torch.equal(z0, z2) and torch.equal(d0, d2)
     # classifier guidance forks a second stream off the CURRENT one and joins it again
     import diff_foley_amd as P
     from diff_foley_amd import synth
