@@ -21,6 +21,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -2863,8 +2864,14 @@ void build_emb_table(df_ctx* c, int which) {
   c->emb_total[which] = off;
 }
 
+// Every entry point runs under one process-wide lock: contexts share the autotuner's choices, the launchers keep function-attribute
+// high-water marks in statics, and a plan build is not re-entrant.  The calls only enqueue work, so the lock is held for microseconds;
+// what it buys is that two host threads may drive two models (or one) without corrupting any of that.  Recursive: test hooks nest.
+static std::recursive_mutex g_api_lock;
+
 template <class F>
 int guard(F&& f) {
+  std::lock_guard<std::recursive_mutex> hold(g_api_lock);
   try {
     f();
     return 0;

@@ -14,8 +14,10 @@ Method names, kwargs, return shapes/dtypes follow ddpm.py:568 (get_learned_condi
 :925 (apply_model), :1252 (sample), :1270-1356 (sample_log*).  All compute runs in libdfengine.so (HIP); a missing
 library or a CPU-only host raises -- there is no fallback path.
 """
+import functools
 import importlib
 import os
+import threading
 import warnings
 
 import torch
@@ -68,6 +70,16 @@ def instantiate_from_config(config):
         return alias[target](**dict(config.get("params", dict())))
     module, cls = target.rsplit(".", 1)
     return getattr(importlib.import_module(module), cls)(**dict(config.get("params", dict())))
+
+
+def _locked(fn):
+    """One caller at a time per model: a sample() call is a sequence of engine calls that share the model's context operands,
+    timestep table and plan workspaces.  (A torch module's forward is re-entrant from several host threads; this keeps the facade so.)"""
+    @functools.wraps(fn)
+    def run(self, *a, **kw):
+        with self._lock:
+            return fn(self, *a, **kw)
+    return run
 
 
 class _Facade:
@@ -149,6 +161,7 @@ class LatentDiffusion:
         # precision: MFMA operand type of the engine.  None -> env DF_PRECISION -> "fp16", the build that meets the north-star
         # tolerance (mel MAE 5.8e-4); "bf16" (BASELINE configs[1]'s wording, same speed) rounds operands 8x coarser and lands at
         # mel MAE 4.5e-3, outside the tolerance -- selectable, never the default.  Not a reference kwarg.
+        self._lock = threading.RLock()
         self.precision = precision
         # precision=None (and no DF_PRECISION): the operand type is the PRODUCT's choice, so it is also the product's job to keep
         # it safe -- if the range probe behind load_state_dict / .cuda() finds fp16 operands at the saturation point with the loaded
@@ -353,10 +366,12 @@ class LatentDiffusion:
         return cond
 
     # ------------------------------------------------------------------ the path
+    @_locked
     @torch.no_grad()
     def get_learned_conditioning(self, c):
         return self._require().cond_encode(c)
 
+    @_locked
     @torch.no_grad()
     def apply_model(self, x_noisy, t, cond, return_ids=False):
         eng = self._require()
@@ -376,6 +391,7 @@ class LatentDiffusion:
             self._ctx_owner = (c, key)
         return eng.unet_forward(x_noisy, t)
 
+    @_locked
     @torch.no_grad()
     def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):
         if predict_cids:
@@ -383,6 +399,7 @@ class LatentDiffusion:
         # any batch size: df_vae_decode slices batches above 16 samples itself (2 GiB operand addressing, include/df_engine.h)
         return self._require().vae_decode(z)
 
+    @_locked
     @torch.no_grad()
     def sample(self, cond, batch_size=16, return_intermediates=False, x_T=None, verbose=True, timesteps=None,
                quantize_denoised=False, mask=None, x0=None, shape=None, **kwargs):
@@ -402,12 +419,14 @@ class LatentDiffusion:
     def _sampler(self, name):
         return {"DDIM": S.DDIMSampler, "DPM_Solver": S.DPMSolverSampler, "PLMS": S.PLMSSampler}[name](self)
 
+    @_locked
     @torch.no_grad()
     def sample_log(self, cond, batch_size, ddim, ddim_steps, size_len=64, unconditional_guidance_scale=1.0,
                    unconditional_conditioning=None, **kwargs):
         return self.sample_log_diff_sampler(cond, batch_size, "DDIM" if ddim else "DDPM", ddim_steps, size_len,
                                             unconditional_guidance_scale, unconditional_conditioning, **kwargs)
 
+    @_locked
     @torch.no_grad()
     def sample_log_diff_sampler(self, cond, batch_size, sampler_name, ddim_steps, size_len=64,
                                 unconditional_guidance_scale=1.0, unconditional_conditioning=None, **kwargs):
@@ -420,6 +439,7 @@ class LatentDiffusion:
                 unconditional_conditioning=unconditional_conditioning, **kwargs)
         return self.sample(cond=cond, batch_size=batch_size, return_intermediates=True, **kwargs)
 
+    @_locked
     @torch.no_grad()
     def sample_log_with_classifier(self, embed_cond, origin_cond, batch_size, ddim, ddim_steps, size_len=64,
                                    unconditional_guidance_scale=1.0, unconditional_conditioning=None, classifier=None,
@@ -428,6 +448,7 @@ class LatentDiffusion:
             embed_cond, origin_cond, batch_size, "DDIM" if ddim else "DDPM", ddim_steps, size_len,
             unconditional_guidance_scale, unconditional_conditioning, classifier, classifier_guide_scale, **kwargs)
 
+    @_locked
     @torch.no_grad()
     def sample_log_with_classifier_diff_sampler(self, embed_cond, origin_cond, batch_size, sampler_name="DDIM",
                                                 ddim_steps=250, size_len=64, unconditional_guidance_scale=1.0,
@@ -462,14 +483,15 @@ class AlignmentClassifier:
         return [], []
 
     def attach(self, ldm):
-        self.engine = ldm._require()
-        self.engine.config_classifier(self.cfg)
-        self.engine.cls_out_channels = self.cfg["out_channels"]
-        self.engine.cls_in_channels = self.cfg["in_channels"]
-        self.engine.cls_context_dim = self.cfg["context_dim"]
-        for k, v in self._state.items():
-            self.engine.load_tensor("classifier." + k, v)
-        self.engine.finalize()
+        with ldm._lock:                       # (re)loading tensors finalises the engine: not under another thread's sample()
+            self.engine = ldm._require()
+            self.engine.config_classifier(self.cfg)
+            self.engine.cls_out_channels = self.cfg["out_channels"]
+            self.engine.cls_in_channels = self.cfg["in_channels"]
+            self.engine.cls_context_dim = self.cfg["context_dim"]
+            for k, v in self._state.items():
+                self.engine.load_tensor("classifier." + k, v)
+            self.engine.finalize()
         return self
 
     def cuda(self):

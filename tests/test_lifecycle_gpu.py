@@ -100,3 +100,41 @@ def test_reload_and_move_keep_results_and_engines_are_released():
     torch.cuda.empty_cache()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, (free0, free1)        # nothing accumulates across create / destroy cycles
+
+
+def test_host_threads_two_models_and_one_shared_model():
+    """Two host threads, each sampling with its own model, and two threads sharing ONE model with different conditionings: every
+    result is the single-threaded one, bit for bit.  (libdfengine serialises its entry points -- the calls only enqueue work -- and
+    the facade lets one caller at a time run a sample() call on a model, whose context operands / timestep table / workspaces
+    belong to that call.)"""
+    import threading
+    from diff_foley_amd import synth
+    a, b = _model("fp16", 0), _model("fp16", 1)
+
+    def job(m, seed, name, S):
+        c = m.get_learned_conditioning(synth.synthetic_cavp(2, 32, 64, seed=seed).cuda())
+        z, _ = m.sample_log_diff_sampler(c, 2, name, S, unconditional_guidance_scale=4.5, unconditional_conditioning=torch.zeros_like(c),
+                                         x_T=synth.synthetic_xT(2, seed=seed).cuda())
+        return z, m.decode_first_stage(z)
+    plan = [(a, 11, "DDIM", 6), (b, 12, "DPM_Solver", 6), (a, 13, "PLMS", 5), (a, 14, "DPM_Solver", 7)]
+    want = [job(*p) for p in plan]
+    torch.cuda.synchronize()
+    for trial in range(3):
+        got = [None] * len(plan)
+        errs = []
+
+        def run(i):
+            try:
+                for _ in range(3):
+                    got[i] = job(*plan[i])
+            except Exception as e:            # surfaces in the main thread below
+                errs.append((i, repr(e)))
+        th = [threading.Thread(target=run, args=(i,)) for i in range(len(plan))]     # jobs 0, 2, 3 share model a; job 1 drives b
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        assert not errs, errs
+        for i, ((z, d), (zw, dw)) in enumerate(zip(got, want)):
+            assert torch.equal(z, zw) and torch.equal(d, dw), (trial, i)
