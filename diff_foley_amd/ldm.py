@@ -72,6 +72,17 @@ def instantiate_from_config(config):
     return getattr(importlib.import_module(module), cls)(**dict(config.get("params", dict())))
 
 
+def _check_shapes(state, spec, what):
+    """torch's load_state_dict raises on a size mismatch even with strict=False; the engine's packers take a tensor's own shape, so a
+    checkpoint of another architecture would load and run as a different network.  ``spec``: name -> shape of the configured modules
+    (synth.*_spec: the reference's key layout)."""
+    bad = [f"size mismatch for {k}: copying a param with shape {tuple(v.shape)} from checkpoint, the shape in current model is "
+           f"{tuple(spec[k])}" for k, v in state.items() if k in spec and tuple(v.shape) != tuple(spec[k])]
+    if bad:
+        raise RuntimeError(f"Error(s) in loading state_dict for {what}:\n\t" + "\n\t".join(bad[:8]) +
+                           (f"\n\t... and {len(bad) - 8} more" if len(bad) > 8 else ""))
+
+
 def _locked(fn):
     """One caller at a time per model: a sample() call is a sequence of engine calls that share the model's context operands,
     timestep table and plan workspaces.  (A torch module's forward is re-entrant from several host threads; this keeps the facade so.)"""
@@ -210,6 +221,8 @@ class LatentDiffusion:
         need = ("model.diffusion_model.", "first_stage_model.post_quant_conv.", "first_stage_model.decoder.",
                 "cond_stage_model.")
         self._state = {k: v for k, v in state_dict.items() if k.startswith(need)}
+        from . import synth
+        _check_shapes(self._state, synth.state_dict_spec(self.unet_cfg, self.vae_cfg, self.cond_cfg), "LatentDiffusion")
         for k in BUFFER_NAMES:            # checkpoints carry the schedule buffers too
             if k in state_dict:
                 setattr(self, k, state_dict[k].detach().float().cpu())
@@ -480,6 +493,8 @@ class AlignmentClassifier:
 
     def load_state_dict(self, state_dict, strict=False):
         self._state = {k: v for k, v in state_dict.items() if k.startswith("model.")}
+        from . import synth
+        _check_shapes(self._state, synth.classifier_spec(self.cfg), "AlignmentClassifier")
         return [], []
 
     def attach(self, ldm):
@@ -540,6 +555,8 @@ class CAVPInference:
     def load_state_dict(self, state_dict, strict=False):
         keep = ("video_encoder.", "video_project_head.")
         self._state = {k: v for k, v in state_dict.items() if k.startswith(keep) and "num_batches_tracked" not in k}
+        from . import synth
+        _check_shapes(self._state, synth.cavp_spec(self.cfg), "CAVPInference")
         missing = [] if self._state else ["video_encoder.*"]
         return missing, [k for k in state_dict if not k.startswith(keep)]
 

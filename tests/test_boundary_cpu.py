@@ -79,3 +79,31 @@ def test_engine_rejects_wrong_feature_width_before_touching_the_device():
         E._want_dim("cross-attention context", 512, 768)
     E._want_dim("x", 768, 768)
     E._want_dim("x", 5, None)
+
+
+def test_a_checkpoint_of_another_architecture_is_a_size_mismatch_error():
+    """torch's load_state_dict raises on a size mismatch whatever ``strict`` says; the engine's packers take each tensor's own shape,
+    so without this check a checkpoint of another architecture loads and samples as a different network (found by
+    tools/load_probe.py: a conv weight with 63 input channels, a bias of twice the length)."""
+    spec = synth.state_dict_spec(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY)
+    sd = {k: torch.zeros(*shape) for k, shape in spec.items()}
+    m = P.LatentDiffusion(**P.stage2_config(synth.UNET_TINY, synth.VAE_TINY, synth.COND_TINY))
+    assert m.load_state_dict(dict(sd, **{"first_stage_model.encoder.conv_in.weight": torch.zeros(3), "loss.x": torch.zeros(1)}))[0] == []
+    k = "model.diffusion_model.input_blocks.1.0.in_layers.2.weight"
+    for bad in (sd[k][:, :-1], sd[k].reshape(-1), torch.zeros(2, *sd[k].shape)):
+        with pytest.raises(RuntimeError, match="size mismatch for " + k.replace(".", r"\.")):
+            m.load_state_dict(dict(sd, **{k: bad}))
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        m.load_state_dict(dict(sd, **{"cond_stage_model.pos_emb.weight": torch.zeros(41, 128)}))
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        m.load_state_dict(dict(sd, **{"first_stage_model.decoder.conv_out.bias": torch.zeros(1)}))
+    csd = {k: torch.zeros(*shape) for k, shape in synth.classifier_spec(synth.CLS_TINY).items()}
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_TINY)))
+    cls.load_state_dict(csd)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        cls.load_state_dict(dict(csd, **{"model.classifier.weight": torch.zeros(2, 64)}))
+    vsd = {k: torch.zeros(*shape) for k, shape in synth.cavp_spec(synth.CAVP_TINY).items()}
+    enc = P.CAVPInference(embed_dim=synth.CAVP_TINY["embed_dim"], stage_blocks=synth.CAVP_TINY["stage_blocks"])
+    assert enc.load_state_dict(vsd) == ([], [])
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        enc.load_state_dict(dict(vsd, **{"video_project_head.weight": torch.zeros(64, 100)}))
