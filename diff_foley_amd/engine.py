@@ -324,10 +324,12 @@ class Engine:
     def cavp_encode(self, video, normalize=True):
         """video (B,T,3,H,W) fp32 RGB in [0,1] -> (B,T,embed) (CAVP_Inference.encode_video, pool=False)."""
         video = _dev_f32(video, self.device)
+        if video.ndim != 5 or video.shape[2] != 3:
+            raise RuntimeError(f"cavp_encode: video must be (B,T,3,H,W), got shape {tuple(video.shape)}")
         B, T, c3, H, W = video.shape
-        if c3 != 3:
-            raise RuntimeError("cavp_encode: video must be (B,T,3,H,W)")
         out = torch.empty(B, T, self.cavp_embed_dim, device=self.device, dtype=torch.float32)
+        if out.numel() == 0:              # no clips / no frames: an empty result, like the reference's Conv3d stack on an empty batch
+            return out
         _chk(self.L.df_cavp_encode(self._h, _ptr(video), _ptr(out), B, T, H, W, int(bool(normalize)), self._on("cavp")), self.L)
         return out
 

@@ -112,6 +112,8 @@ class ExtractCAVPFeatures:
         """Decoded RGB frames (T, H, W, 3) uint8 at ``fps`` -> (T, embed_dim) numpy features, exactly the loop of
         demo_util.py:141-170: batches of ``batch_size`` frames, ``encode_video(normalize=True, pool=False)``."""
         T = frames.shape[0]
+        if T == 0:                            # np.concatenate([]) of the reference loop would raise: an empty clip has no features
+            raise ValueError("forward_frames: no frames")
         feats = []
         for i in range(0, T, self.batch_size):
             x = frames_to_tensor(frames[i:i + self.batch_size], self.video_shape)          # (t, 3, 224, 224)

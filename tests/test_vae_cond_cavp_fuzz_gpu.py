@@ -139,3 +139,28 @@ def test_a_contraction_length_the_kernels_cannot_walk_fails_loudly():
     with pytest.raises(RuntimeError, match="multiple of 64"):
         c = m.get_learned_conditioning(torch.randn(1, 8, 64).cuda())
         m.apply_model(torch.randn(1, 4, 16, 64).cuda(), torch.tensor([10]).cuda(), c)
+
+
+def test_cavp_edge_inputs():
+    import diff_foley_amd as P
+    from diff_foley_amd import synth
+    m = P.CAVPInference(embed_dim=synth.CAVP_TINY["embed_dim"], stage_blocks=synth.CAVP_TINY["stage_blocks"], precision="fp16")
+    m.load_state_dict(synth.make_state_dict(synth.cavp_spec(synth.CAVP_TINY)))
+    m.cuda()
+    E = synth.CAVP_TINY["embed_dim"]
+    assert m.encode_video(torch.zeros(0, 4, 3, 64, 64).cuda(), normalize=True, pool=False).shape == (0, 4, E)
+    assert m.encode_video(torch.zeros(2, 0, 3, 64, 64).cuda(), normalize=True, pool=False).shape == (2, 0, E)
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        m.encode_video(torch.zeros(1, 2, 3, 72, 64).cuda(), normalize=True, pool=False)
+    with pytest.raises(RuntimeError, match=r"\(B,T,3,H,W\)"):
+        m.encode_video(torch.zeros(2, 3, 64, 64).cuda(), normalize=True, pool=False)
+    with pytest.raises(RuntimeError, match=r"\(B,T,3,H,W\)"):
+        m.encode_video(torch.zeros(1, 2, 4, 64, 64).cuda(), normalize=True, pool=False)
+    ex = P.ExtractCAVPFeatures(fps=4, batch_size=4, video_shape=(64, 64), stage1_model=m)
+    f = np.random.default_rng(0).integers(0, 256, (9, 40, 56, 3), dtype=np.uint8)
+    a = ex.forward_frames(f)                          # 4 + 4 + 1 frames
+    assert a.shape == (9, E)
+    b = ex.forward_frames(f[:4])                      # exactly one batch
+    assert np.array_equal(a[:4], b)
+    with pytest.raises(ValueError):
+        ex.forward_frames(f[:0])
