@@ -78,6 +78,10 @@ def _check_shapes(state, spec, what):
     (synth.*_spec: the reference's key layout)."""
     bad = [f"size mismatch for {k}: copying a param with shape {tuple(v.shape)} from checkpoint, the shape in current model is "
            f"{tuple(spec[k])}" for k, v in state.items() if k in spec and tuple(v.shape) != tuple(spec[k])]
+    nonfinite = [k for k, v in state.items() if k in spec and v.is_floating_point() and not bool(torch.isfinite(v).all())]
+    if nonfinite:       # the reference would sample NaN; the fp16-operand build's saturating stores would hide it (DESIGN.md section 4)
+        warnings.warn(f"{what}: {len(nonfinite)} checkpoint tensor(s) hold non-finite values ({nonfinite[0]} ...): the fp32 reference "
+                      f"would produce NaN with them", RuntimeWarning, stacklevel=3)
     if bad:
         raise RuntimeError(f"Error(s) in loading state_dict for {what}:\n\t" + "\n\t".join(bad[:8]) +
                            (f"\n\t... and {len(bad) - 8} more" if len(bad) > 8 else ""))

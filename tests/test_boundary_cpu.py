@@ -107,3 +107,5 @@ def test_a_checkpoint_of_another_architecture_is_a_size_mismatch_error():
     assert enc.load_state_dict(vsd) == ([], [])
     with pytest.raises(RuntimeError, match="size mismatch"):
         enc.load_state_dict(dict(vsd, **{"video_project_head.weight": torch.zeros(64, 100)}))
+    with pytest.warns(RuntimeWarning, match="non-finite"):
+        m.load_state_dict(dict(sd, **{k: torch.full_like(sd[k], float("nan"))}))
