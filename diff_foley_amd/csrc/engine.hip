@@ -95,6 +95,10 @@ struct Plan {
   double gemm_flops = 0, weight_bytes = 0;
   size_t ext_hint = 0;           // largest external (caller-owned) buffer the plan touches, when above 32 MB (autotune dummies)
   size_t n_ctx = 0;              // UNet plans: ops [0, n_ctx) depend on the context only (run by df_unet_set_context)
+  // Classifier-gradient plans: ops [0, n_feat) turn the video features into the cross-attention K / V^T of every transformer
+  // block; feat_token != 0 names the features those buffers were last computed from (df_classifier_grad_cached)
+  size_t n_feat = 0;
+  uint64_t feat_token = 0;
   // Hoisted time embedding: ops [op_t0, op_tl) map the timestep to the stacked emb projections E [N][etot] (they depend on t
   // only); op_tl = "t.lookup" copies row ts_index of Etab [S][etot] to every row of E instead.  df_unet_set_timesteps fills the
   // table by running [op_t0, op_tl) once per timestep of a sample() call; the step loop then runs [op_tl, end).
@@ -1698,10 +1702,9 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
       kv[d.prefix] = {K, Vt};
     }
   }
-  float* tbuf = b.buf<float>(N);
-  b.other("t.copy", [=](hipStream_t s, const RunArgs& a) { return hipMemcpyAsync(tbuf, a.t, (size_t)N * 4, hipMemcpyDeviceToDevice, s); });
+  pl->n_feat = pl->ops.size();        // everything above depends on the features only: skipped while the caller's token stands
   float* te = b.buf<float>((size_t)N * mc);
-  b.other("t.embed", [=](hipStream_t s, const RunArgs&) { return launch_timestep_embedding(tbuf, te, N, mc, s); });
+  b.other("t.embed", [=](hipStream_t s, const RunArgs& a) { return launch_timestep_embedding(a.t, te, N, mc, s); });
   float* e1 = b.buf<float>((size_t)N * temb);
   float* semb = b.buf<float>((size_t)N * temb);
   {
@@ -3257,8 +3260,8 @@ int df_classifier_forward(df_ctx* c, const float* x, const float* t, const float
   });
 }
 
-int df_classifier_grad(df_ctx* c, const float* x, const float* t, const float* feat, float* prob, float* grad, int B,
-                       int H, int W, int T, void* stream) {
+int df_classifier_grad_cached(df_ctx* c, const float* x, const float* t, const float* feat, float* prob, float* grad, int B,
+                              int H, int W, int T, uint64_t feat_token, void* stream) {
   return guard([&] {
     if (!c->has_cls) fail("classifier not configured");
     need_positive("classifier gradient", {{"batch", B}, {"H", H}, {"W", W}, {"video frames", T}});
@@ -3269,8 +3272,18 @@ int df_classifier_grad(df_ctx* c, const float* x, const float* t, const float* f
     a.aux = feat;
     a.out = grad;
     a.out2 = prob;
-    run_ops(c, p, 0, p->ops.size(), (hipStream_t)stream, a);
+    // the plan, not the caller, knows whether its K / V^T buffers hold these features: a plan rebuilt since the last call
+    // (other shape, dropped plans, reloaded weights) starts at token 0 and recomputes
+    const bool reuse = feat_token != 0 && p->feat_token == feat_token;
+    if (!reuse) p->feat_token = 0;        // a failing launch below must not leave a token on half-written buffers
+    run_ops(c, p, reuse ? p->n_feat : 0, p->ops.size(), (hipStream_t)stream, a);
+    p->feat_token = feat_token;
   });
+}
+
+int df_classifier_grad(df_ctx* c, const float* x, const float* t, const float* feat, float* prob, float* grad, int B,
+                       int H, int W, int T, void* stream) {
+  return df_classifier_grad_cached(c, x, t, feat, prob, grad, B, H, W, T, 0, stream);
 }
 
 // ---- packed-operand blob (helpers above the C ABI block)

@@ -5,6 +5,7 @@ and dtype/shape bookkeeping.  There is NO fallback: if the shared library is mis
 a RuntimeError is raised -- results never come from a torch/CPU path.
 """
 import ctypes as C
+import itertools
 import os
 
 import torch
@@ -76,6 +77,8 @@ _SIGS = {
                               C.c_int, C.c_void_p],
     "df_classifier_grad": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                            C.c_int, C.c_int, C.c_void_p],
+    "df_classifier_grad_cached": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_uint64, C.c_void_p],
     "df_prepack": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int],
     "df_packed_size": [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "df_export_packed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -232,6 +235,7 @@ def unet_config(cfg):
 
 
 TUNED_DIR = os.path.join(_HERE, "tuned")
+_feat_tokens = itertools.count(1)      # process-wide: tokens of different engines / classifiers never coincide
 _tuned_loaded = {}      # precision -> path of the shipped plan table imported into that library (or None)
 
 
@@ -283,6 +287,7 @@ class Engine:
         self._h = h
         self._keep = []
         self._last_stream = {}            # plan family -> the torch stream of its previous call (_on)
+        self._cls_feat = None             # (feature tensor, (shape, dtype, version), token) of the last classifier_grad call
         self.autotune_on = False
 
     def close(self):
@@ -495,8 +500,25 @@ class Engine:
                                          self._on("cls")), self.L)
         return out
 
+    def _feat_token(self, feat):
+        """Token naming the CONTENTS of the caller's feature tensor for df_classifier_grad_cached: the same token as long as the
+        caller passes the very same tensor object with an unchanged version counter (a guidance loop hands origin_cond through all
+        its steps: ddim.py:374-380), a new one otherwise.  Same rule as the UNet's context cache (ldm.LatentDiffusion.apply_model):
+        the tensor is held by a strong reference so that its storage cannot be handed to another tensor while it is the key;
+        tensors without a version counter (torch.inference_mode) get token 0 = recompute every call."""
+        try:
+            ver = feat._version
+        except RuntimeError:
+            self._cls_feat = None
+            return 0
+        key = (tuple(feat.shape), feat.dtype, ver)
+        if self._cls_feat is None or self._cls_feat[0] is not feat or self._cls_feat[1] != key:
+            self._cls_feat = (feat, key, next(_feat_tokens))
+        return self._cls_feat[2]
+
     def classifier_grad(self, x, t, feat, want_prob=False):
         x = _dev_f32(x, self.device)
+        token = 0 if os.environ.get("DF_CLS_FEAT_CACHE", "1") == "0" else self._feat_token(feat)
         feat = _dev_f32(feat, self.device)
         _want_nchw("classifier input", x, getattr(self, "cls_in_channels", None))
         B, Cc, H, W = x.shape
@@ -508,8 +530,8 @@ class Engine:
         prob = torch.empty(B, 1, device=self.device, dtype=torch.float32) if want_prob else None
         if B == 0:
             return (grad, prob) if want_prob else grad
-        _chk(self.L.df_classifier_grad(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(prob) if want_prob else None,
-                                      _ptr(grad), B, H, W, feat.shape[1], self._on("clsgrad")), self.L)
+        _chk(self.L.df_classifier_grad_cached(self._h, _ptr(x), _ptr(t), _ptr(feat), _ptr(prob) if want_prob else None,
+                                             _ptr(grad), B, H, W, feat.shape[1], token, self._on("clsgrad")), self.L)
         return (grad, prob) if want_prob else grad
 
     def test_block(self, prefix, kind, x, semb=None, context=None, cout=None):

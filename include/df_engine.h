@@ -150,6 +150,15 @@ int df_classifier_forward(df_ctx* ctx, const float* x_dev, const float* t_dev, c
 int df_classifier_grad(df_ctx* ctx, const float* x_dev, const float* t_dev, const float* feat_dev, float* prob_dev,
                        float* grad_dev, int B, int H, int W, int T, void* stream);
 
+/* The same call for a guidance loop, which hands the classifier the SAME video features at every step (ddim.py:374-380 passes
+ * origin_cond unchanged through all S steps; dpm_solver.py:1377-1393 closes over it): feat_token != 0 names the CONTENTS of
+ * feat_dev.  While consecutive calls on a plan carry the same token, the feature-only launches (cast + cross-attention K / V^T
+ * of every transformer block: 7 of the call's launches at the Stage-2 classifier) are skipped and feat_dev is not read.  The
+ * caller changes the token whenever the features change; token 0 = no reuse (df_classifier_grad).  The plan holds the token:
+ * a plan that was rebuilt (other shape, reloaded weights) recomputes whatever token it is handed first. */
+int df_classifier_grad_cached(df_ctx* ctx, const float* x_dev, const float* t_dev, const float* feat_dev, float* prob_dev,
+                              float* grad_dev, int B, int H, int W, int T, uint64_t feat_token, void* stream);
+
 /* ---- video frame pre-processing in front of the CAVP encoder (Extract_CAVP_Features.forward, inference/demo_util.py:
  * 100-104, 150-151): per frame torchvision Resize((OH, OW)) on a PIL image (= PIL.Image.resize BILINEAR: antialiased,
  * 8-bit fixed point, horizontal pass then vertical pass) + ToTensor().  frames uint8 [T][H][W][3] RGB ->

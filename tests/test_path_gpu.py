@@ -354,6 +354,63 @@ def test_classifier_gradient_on_the_side_stream_is_bit_identical(tiny, P, monkey
         assert torch.equal(z0, z2), name
 
 
+def test_classifier_feature_operands_are_reused_across_a_guidance_loop(tiny, P, monkeypatch):
+    """df_classifier_grad_cached: a guidance loop passes the SAME video features at every step (origin_cond, ddim.py:374-380,
+    dpm_solver.py:1377-1393), so the feature-only launches of the gradient plan (cast + cross-attention K / V^T per transformer
+    block) run once per features, not once per step.  A reused call returns the bits of a recomputing call; a new tensor object, an
+    in-place edit (version counter) or a rebuilt plan recomputes; an edit torch cannot see (``.data``) is NOT picked up -- the same
+    rule as the UNet's context cache -- which also shows that the reuse really skips the feature launches; DF_CLS_FEAT_CACHE=0 is
+    the reference's recompute-every-call behaviour; the samplers give the same latents either way."""
+    from diff_foley_amd import synth
+    B = 2
+    cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_TINY)))
+    cls.load_state_dict(tiny_classifier_sd())
+    cls.attach(tiny)
+    eng = cls.engine
+    vf = synth.synthetic_cavp(B, 33, 64, seed=4321).cuda()
+    xs = [synth.synthetic_xT(B, seed=30 + k).cuda() for k in range(3)]
+    ts = [torch.tensor([900.0, 900.0]).cuda(), torch.tensor([500.5, 37.0]).cuda(), torch.tensor([1.0, 999.0]).cuda()]
+    fresh = [eng.classifier_grad(x, t, vf.clone(), want_prob=True) for x, t in zip(xs, ts)]       # a new object every call: recomputed
+    for rep in range(2):
+        for k, (x, t) in enumerate(zip(xs, ts)):                                                  # one object: computed once
+            g, p = eng.classifier_grad(x, t, vf, want_prob=True)
+            assert torch.equal(g, fresh[k][0]) and torch.equal(p, fresh[k][1]), (rep, k)
+    # an in-place edit bumps the version counter: recomputed
+    vf2 = vf.clone()
+    g_a = eng.classifier_grad(xs[0], ts[0], vf2)
+    vf2.mul_(-1.0)
+    g_b = eng.classifier_grad(xs[0], ts[0], vf2)
+    g_b_want = eng.classifier_grad(xs[0], ts[0], (-vf).contiguous())
+    assert torch.equal(g_b, g_b_want) and not torch.equal(g_a, g_b)
+    # an edit behind torch's back is not seen (documented): the K / V^T operands of the previous call are still in use
+    vf3 = vf.clone()
+    g_c = eng.classifier_grad(xs[1], ts[1], vf3)
+    vf3.data.mul_(-1.0)
+    assert torch.equal(eng.classifier_grad(xs[1], ts[1], vf3), g_c)
+    monkeypatch.setenv("DF_CLS_FEAT_CACHE", "0")
+    assert not torch.equal(eng.classifier_grad(xs[1], ts[1], vf3), g_c)
+    monkeypatch.delenv("DF_CLS_FEAT_CACHE")
+    # a rebuilt plan starts without operands whatever token it is handed
+    g_d = eng.classifier_grad(xs[2], ts[2], vf)
+    eng.finalize()
+    assert torch.equal(eng.classifier_grad(xs[2], ts[2], vf), g_d)
+    # another batch = another plan with its own operands, interleaved with the first
+    vf1 = vf[:1].contiguous()
+    g1 = eng.classifier_grad(xs[0][:1].contiguous(), ts[0][:1], vf1)
+    assert torch.equal(eng.classifier_grad(xs[2], ts[2], vf), g_d)
+    assert torch.equal(eng.classifier_grad(xs[0][:1].contiguous(), ts[0][:1], vf1), g1)
+    assert torch.equal(g1, eng.classifier_grad(xs[0][:1].contiguous(), ts[0][:1], vf1.clone()))
+    # through the samplers
+    c = tiny.get_learned_conditioning(synth.synthetic_cavp(B, 32, 64, seed=1234).cuda())
+    kw = dict(origin_cond=vf, batch_size=B, sampler_name="DDIM", ddim_steps=5, unconditional_guidance_scale=4.5,
+              unconditional_conditioning=torch.zeros_like(c), classifier=cls, classifier_guide_scale=50.0)
+    xT = synth.synthetic_xT(B, seed=21).cuda()
+    z1, _ = tiny.sample_log_with_classifier_diff_sampler(c, x_T=xT.clone(), **kw)
+    monkeypatch.setenv("DF_CLS_FEAT_CACHE", "0")
+    z0, _ = tiny.sample_log_with_classifier_diff_sampler(c, x_T=xT.clone(), **kw)
+    assert torch.isfinite(z1).all() and torch.equal(z0, z1)
+
+
 def test_hoisted_time_embedding_is_bit_identical(tiny):
     """df_unet_set_timesteps + df_unet_forward(_cfg)_ts: the time embedding of every announced timestep (integer and fractional,
     as DDIM / DPM-Solver++ visit them) computed before the loop by the plan's own ops; a step that looks its row up returns
