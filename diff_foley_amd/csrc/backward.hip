@@ -604,15 +604,21 @@ __global__ __launch_bounds__(512) void attention_bwd_mfma_kernel(const bf16_t* _
 // ------------------------------------------------------------------ classifier head backward
 // p = sigmoid(z), objective sum log p  ->  dz = 1 - p;  pooled = mean_px(h);  z = w . pooled + b
 //   dh[n][px][c] = (1 - p_n) * w[c] / HW          (out_channels == 1)
+//   dh_b16: the same values as the next conv's gradient operand, rows of Cp >= C columns, the pad columns zero
 __global__ void cls_head_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ w, float* __restrict__ dh,
-                                    bf16_t* __restrict__ dh_b16, int N, int HW, int C) {
-  const long total = (long)N * HW * C;
+                                    bf16_t* __restrict__ dh_b16, int N, int HW, int C, int Cp) {
+  const long total = (long)N * HW * Cp;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int n = (int)(i / ((long)HW * C));
-    const float v = (1.0f - prob[n]) * w[c] / (float)HW;
-    dh[i] = v;
-    if (dh_b16) dh_b16[i] = f2bf(v);
+    const int c = (int)(i % Cp);
+    const long row = i / Cp;
+    const int n = (int)(row / HW);
+    if (c < C) {
+      const float v = (1.0f - prob[n]) * w[c] / (float)HW;
+      dh[row * C + c] = v;
+      if (dh_b16) dh_b16[i] = f2bf(v);
+    } else if (dh_b16) {
+      dh_b16[i] = (bf16_t)0;
+    }
   }
 }
 
@@ -747,9 +753,10 @@ hipError_t launch_attention_bwd(const uint16_t* Q, int ldq, const uint16_t* K, i
   return hipGetLastError();
 }
 
-hipError_t launch_cls_head_bwd(const float* prob, const float* w, float* dh, uint16_t* dh_b16, int N, int HW, int C,
+hipError_t launch_cls_head_bwd(const float* prob, const float* w, float* dh, uint16_t* dh_b16, int N, int HW, int C, int Cp,
                                hipStream_t s) {
-  hipLaunchKernelGGL(cls_head_bwd_kernel, dim3(grid_for((long)N * HW * C)), dim3(256), 0, s, prob, w, dh, dh_b16, N, HW, C);
+  if (Cp < C) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cls_head_bwd_kernel, dim3(grid_for((long)N * HW * Cp)), dim3(256), 0, s, prob, w, dh, dh_b16, N, HW, C, Cp);
   return hipGetLastError();
 }
 

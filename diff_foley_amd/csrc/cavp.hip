@@ -141,7 +141,7 @@ __global__ void l2norm_rows_kernel(float* __restrict__ x, int rows, int C) {
 // ------------------------------------------------------------------ frame pre-processing (demo_util.py:100-104, 150-151)
 // torchvision Resize((h, w)) on a PIL image = PIL.Image.resize(BILINEAR): separable, antialiased (triangle filter whose
 // support grows with the down-scaling factor), 8-bit fixed point exactly as Pillow's Resample.c: horizontal pass into a
-// uint8 intermediate, then the vertical pass; every value is (2^21 + sum pixel * coeff) >> 22, clipped to 0..255.  The
+// uint8 intermediate, then the vertical pass (the other way round on frames with H > 100 W, below); every value is (2^21 + sum pixel * coeff) >> 22, clipped to 0..255.  The
 // 22-bit coefficient tables are computed on the host in double precision (diff_foley_amd/video.py).  The vertical pass
 // also does ToTensor(): HWC uint8 -> CHW float / 255.  Results are bit-identical to Pillow.
 __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ tmp, long rows,
@@ -177,6 +177,47 @@ __global__ __launch_bounds__(256) void resize_v_totensor_kernel(const uint8_t* _
     const int* k = coef + (long)oy * ksize;
     int acc = 1 << 21;
     for (int y = 0; y < n; ++y) acc += (int)src[(long)y * OW * 3] * k[y];
+    acc >>= 22;
+    out[e] = (float)min(max(acc, 0), 255) / 255.0f;
+  }
+}
+
+// Pass order.  Pillow runs the horizontal pass first -- except on frames more than 100 times taller than wide (H > 100 W), where it
+// runs the vertical pass first (observed on Pillow 12.2.0: the switch sits at exactly H = 100 W + 1 for every output size, 497 random
+// geometries in tests/test_video_cpu.py).  The uint8 rounding of the intermediate makes the two orders differ by one count in up to
+// 10 % of the values, so the order is part of the result.  No real video has that shape; the kernels below exist for bit parity.
+__global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ tmp, int T, int H, int W,
+                                                       int OH, const int* __restrict__ bounds, const int* __restrict__ coef,
+                                                       int ksize) {
+  const long total = (long)T * OH * W * 3;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long xc = e % (3L * W);                      // (x, c) inside a row
+    const int oy = (int)((e / (3L * W)) % OH);
+    const int t = (int)(e / (3L * W * OH));
+    const int y0 = bounds[2 * oy], n = bounds[2 * oy + 1];
+    const uint8_t* src = in + ((long)t * H + y0) * W * 3 + xc;
+    const int* k = coef + (long)oy * ksize;
+    int acc = 1 << 21;
+    for (int y = 0; y < n; ++y) acc += (int)src[(long)y * W * 3] * k[y];
+    acc >>= 22;
+    tmp[e] = (uint8_t)min(max(acc, 0), 255);
+  }
+}
+
+__global__ __launch_bounds__(256) void resize_h_totensor_kernel(const uint8_t* __restrict__ tmp, float* __restrict__ out, int T,
+                                                                int W, int OH, int OW, const int* __restrict__ bounds,
+                                                                const int* __restrict__ coef, int ksize) {
+  const long total = (long)T * 3 * OH * OW;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(e % OW);
+    const int oy = (int)((e / OW) % OH);
+    const int c = (int)((e / ((long)OW * OH)) % 3);
+    const int t = (int)(e / (3L * OW * OH));
+    const int x0 = bounds[2 * ox], n = bounds[2 * ox + 1];
+    const uint8_t* src = tmp + (((long)t * OH + oy) * W + x0) * 3 + c;
+    const int* k = coef + (long)ox * ksize;
+    int acc = 1 << 21;
+    for (int x = 0; x < n; ++x) acc += (int)src[3 * x] * k[x];
     acc >>= 22;
     out[e] = (float)min(max(acc, 0), 255) / 255.0f;
   }
@@ -246,9 +287,15 @@ hipError_t launch_frames_to_tensor(const uint8_t* frames, float* out, uint8_t* t
                                    const int* bounds_w, const int* coef_w, int ksize_w, const int* bounds_h,
                                    const int* coef_h, int ksize_h, hipStream_t s) {
   if (T <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || ksize_w <= 0 || ksize_h <= 0) return hipErrorInvalidValue;
-  const long n1 = (long)T * H * OW * 3, n2 = (long)T * 3 * OH * OW;
+  const bool v_first = (long)H > 100L * W;          // Pillow's pass order (see resize_v_kernel)
+  const long n1 = v_first ? (long)T * OH * W * 3 : (long)T * H * OW * 3, n2 = (long)T * 3 * OH * OW;
   const int g1 = (int)std::min<long>((n1 + 255) / 256, 65535), g2 = (int)std::min<long>((n2 + 255) / 256, 65535);
-  hipLaunchKernelGGL(resize_h_kernel, dim3(g1), dim3(256), 0, s, frames, tmp, (long)T * H, W, OW, bounds_w, coef_w, ksize_w);
-  hipLaunchKernelGGL(resize_v_totensor_kernel, dim3(g2), dim3(256), 0, s, tmp, out, T, H, OH, OW, bounds_h, coef_h, ksize_h);
+  if (v_first) {
+    hipLaunchKernelGGL(resize_v_kernel, dim3(g1), dim3(256), 0, s, frames, tmp, T, H, W, OH, bounds_h, coef_h, ksize_h);
+    hipLaunchKernelGGL(resize_h_totensor_kernel, dim3(g2), dim3(256), 0, s, tmp, out, T, W, OH, OW, bounds_w, coef_w, ksize_w);
+  } else {
+    hipLaunchKernelGGL(resize_h_kernel, dim3(g1), dim3(256), 0, s, frames, tmp, (long)T * H, W, OW, bounds_w, coef_w, ksize_w);
+    hipLaunchKernelGGL(resize_v_totensor_kernel, dim3(g2), dim3(256), 0, s, tmp, out, T, H, OH, OW, bounds_h, coef_h, ksize_h);
+  }
   return hipGetLastError();
 }

@@ -383,16 +383,17 @@ struct df_ctx {
     packed[key] = o;
     return o;
   }
-  // 3x3 conv weight OIHW -> backward-data packing bf16 [I][ky'][kx'][O] (flipped taps)
+  // 3x3 conv weight OIHW -> backward-data packing bf16 [I][ky'][kx'][Opad] (flipped taps).  Opad = Cout rounded up to the 64-channel
+  // K step with zero rows behind the real ones: the gradient operand of such a conv carries Opad columns, the pad ones zero (the
+  // classifier head's conv halves the channels: 64 -> 32, 320 -> 160; every other conv on the tape has Cout % 64 == 0)
   const bf16_t* w_conv3_bwd(const std::string& name) {
     const std::string key = name + "#c3bwd";
     auto it = packed.find(key);
     if (it != packed.end()) return (const bf16_t*)it->second;
     const RawT& t = rt(name);
-    const int O = (int)t.shape[0], I = (int)t.shape[1];
-    if (O % 64 != 0) fail("'%s': backward-data packing needs Cout %% 64 == 0", name.c_str());
-    bf16_t* o = (bf16_t*)pmalloc((size_t)I * 9 * O * 2);
-    HIPCHK(launch_pack_conv_bwd(t.d, o, O, I, O, pack_stream));
+    const int O = (int)t.shape[0], I = (int)t.shape[1], Opad = (O + 63) / 64 * 64;
+    bf16_t* o = (bf16_t*)pmalloc((size_t)I * 9 * Opad * 2);
+    HIPCHK(launch_pack_conv_bwd(t.d, o, O, I, Opad, pack_stream));
     packed[key] = o;
     return o;
   }
@@ -2004,14 +2005,15 @@ void build_classifier_grad(df_ctx* c, Plan* pl, int N, int H, int W, int Tc) {
     });
   }
   // ---- backward: head, then the tape in reverse
+  const int cop = rup(co, 64);          // the gradient operand's row length: co columns + zero pad up to the K step (w_conv3_bwd)
   F32 dho = f32buf(h.rows, co);
-  bf16_t* dhob = b.buf<bf16_t>((size_t)h.rows * co);
+  bf16_t* dhob = b.buf<bf16_t>((size_t)h.rows * cop);
   {
     const float* wcls = c->f32(pre + "classifier.weight");
     float* dp = dho.p;
-    b.other("cls.head.bwd", [=](hipStream_t s, const RunArgs&) { return launch_cls_head_bwd(prob, wcls, dp, dhob, N, hw2, co, s); });
+    b.other("cls.head.bwd", [=](hipStream_t s, const RunArgs&) { return launch_cls_head_bwd(prob, wcls, dp, dhob, N, hw2, co, cop, s); });
   }
-  F32 d_ah = conv_bwd(dhob, hm, wmid, co, pre + "out.2.weight", chf, "cls.out.bwd");
+  F32 d_ah = conv_bwd(dhob, hm, wmid, cop, pre + "out.2.weight", chf, "cls.out.bwd");
   F32 g = gn_bwd(h, "out.0", 1e-5f, 1, d_ah, nullptr, true, nullptr);
   for (int i = (int)tape.size() - 1; i >= 0; --i) g = tape[i](g);
 }

@@ -136,7 +136,7 @@ size_t attention_bwd_ws_floats(int N, int heads, int D, int Tq, int Tk, int lddk
 hipError_t launch_attention_bwd(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt,
                                 const float* dO, int lddo, uint16_t* dQ, int lddq, uint16_t* dK, int lddk, uint16_t* dV,
                                 int lddv, int N, int heads, int D, int Tq, int Tk, float scale, float* ws, hipStream_t s);
-hipError_t launch_cls_head_bwd(const float* prob, const float* w, float* dh, uint16_t* dh_b16, int N, int HW, int C,
+hipError_t launch_cls_head_bwd(const float* prob, const float* w, float* dh, uint16_t* dh_b16, int N, int HW, int C, int Cp,
                                hipStream_t s);
 // Linear weight [O][I] fp32 -> transposed bf16 written at out[i*ldo + off + o]  (ldo >= off + O)
 hipError_t launch_pack_linear_t(const float* w, uint16_t* out, int O, int I, int ldo, int off, hipStream_t s);

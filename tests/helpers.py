@@ -53,3 +53,10 @@ def full_classifier_sd(seed=0):
 def rel_l2(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def fuzz_seeds(n):
+    """Seeds of a randomised differential test: 0 .. n - 1 in the suite; ``DF_FUZZ_SEED0`` / ``DF_FUZZ_CASES`` move and widen the
+    range for an exploratory sweep on a GPU box (every case is a function of its seed alone, so a failing seed reproduces)."""
+    s0 = int(os.environ.get("DF_FUZZ_SEED0", "0"))
+    return range(s0, s0 + int(os.environ.get("DF_FUZZ_CASES", str(n))))

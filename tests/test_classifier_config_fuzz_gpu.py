@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import rel_l2, tiny_state_dict
+from helpers import fuzz_seeds, rel_l2, tiny_state_dict
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +37,12 @@ def _draw(seed):
     return cfg, dict(B=int(r.choice([1, 2, 3])), H=H, W=W, T=int(r.choice([8, 32, 33])))
 
 
-@pytest.mark.parametrize("seed", range(N_CASES))
+# seeds a wider sweep (DF_FUZZ_SEED0=100 DF_FUZZ_CASES=60, round 6) failed on: model_channels 64 with channel_mult [1, 1] -- the head's
+# conv halves 64 channels to 32, and the backward-data packing refused a Cout that is not a multiple of the 64-channel K step
+REGRESSION_SEEDS = [119, 152]
+
+
+@pytest.mark.parametrize("seed", sorted(set(fuzz_seeds(N_CASES)) | set(REGRESSION_SEEDS)))
 def test_classifier_gradient_product_vs_autograd(seed):
     import diff_foley_amd as P
     from diff_foley_amd import synth

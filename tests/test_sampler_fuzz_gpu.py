@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import rel_l2, tiny_state_dict
+from helpers import fuzz_seeds, rel_l2, tiny_state_dict
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +63,7 @@ def _draw(seed):
     return o
 
 
-@pytest.mark.parametrize("seed", range(N_CASES))
+@pytest.mark.parametrize("seed", fuzz_seeds(N_CASES))
 def test_sampler_options_product_vs_oracle(tiny16, oracle_tiny, seed):
     from oracle import samplers as osamp
     apply_model, cond_fn, sched = oracle_tiny

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import rel_l2
+from helpers import fuzz_seeds, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +44,7 @@ def _draw(seed):
     return cfg, dict(B=int(r.choice([1, 2, 3])), H=H, W=W, T=int(r.choice([1, 9, 32])), seed=seed)
 
 
-@pytest.mark.parametrize("seed", range(N_CASES))
+@pytest.mark.parametrize("seed", fuzz_seeds(N_CASES))
 def test_unet_configuration_product_vs_oracle(seed):
     import diff_foley_amd as P
     from diff_foley_amd import synth

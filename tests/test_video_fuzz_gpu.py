@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import fuzz_seeds
+
 pytestmark = pytest.mark.gpu
 
 
@@ -19,7 +21,7 @@ def _draw(seed):
     return int(r.integers(1, 8)), H, W, oh, ow
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", fuzz_seeds(24))
 def test_frames_to_tensor_equals_oracle_and_pillow(seed):
     import diff_foley_amd as P
     from oracle import video as ov
@@ -40,6 +42,25 @@ def test_frames_to_tensor_equals_oracle_and_pillow(seed):
     bil = getattr(getattr(Image, "Resampling", Image), "BILINEAR")
     pil = np.stack([np.asarray(Image.fromarray(fr).resize((ow, oh), bil)) for fr in f])
     assert torch.equal(t, torch.from_numpy(pil).permute(0, 3, 1, 2).float() / 255.0), (T, H, W, oh, ow)
+
+
+@pytest.mark.parametrize("H,W,oh,ow", [(224, 2, 64, 111), (1080, 7, 5, 256), (641, 2, 64, 64), (200, 2, 64, 16), (201, 2, 64, 16),
+                                        (501, 5, 5, 16), (500, 5, 5, 16), (1081, 1, 9, 9), (301, 3, 301, 8), (301, 3, 17, 3)])
+def test_tall_frames_take_pillows_pass_order(H, W, oh, ow):
+    """Frames more than 100 times taller than wide: Pillow runs the vertical pass first and the product follows (resize_v_kernel /
+    resize_h_totensor_kernel; the rule and how it was found: tests/test_video_cpu.py).  Both sides of the boundary, one-pass cases."""
+    import diff_foley_amd as P
+    from oracle import video as ov
+    f = np.random.default_rng(H * 7 + W).integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+    t = P.frames_to_tensor(f, (oh, ow)).cpu()
+    assert torch.equal(t, torch.from_numpy(ov.frames_to_tensor(f, (oh, ow)))), (H, W, oh, ow)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    bil = getattr(getattr(Image, "Resampling", Image), "BILINEAR")
+    pil = np.stack([np.asarray(Image.fromarray(fr).resize((ow, oh), bil)) for fr in f])
+    assert torch.equal(t, torch.from_numpy(pil).permute(0, 3, 1, 2).float() / 255.0), (H, W, oh, ow)
 
 
 def test_frames_to_tensor_rejects_what_it_cannot_read():
