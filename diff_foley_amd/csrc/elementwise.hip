@@ -870,16 +870,16 @@ hipError_t launch_layernorm(const float* x, int ld, int rows, int C, const float
                             float eps, uint16_t* out, hipStream_t s) {
   const int blocks = (rows + 3) / 4;
 #define DF_LN(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, dim3(blocks), dim3(256), 0, s, x, ld, rows, gamma, beta, eps, out)
-  switch (C) {
-    case 64: DF_LN(1); break;
-    case 128: DF_LN(2); break;
-    case 256: DF_LN(4); break;
-    case 320: DF_LN(5); break;
-    case 512: DF_LN(8); break;
-    case 640: DF_LN(10); break;
-    case 1280: DF_LN(20); break;
+  // one instantiation per row length C = 64 NV, NV = 1 .. 32 (the Stage-2 UNet meets 320 / 640 / 1280 and the classifier 128 / 256 /
+  // 512; other model_channels x channel_mult products -- 192, 384, 768, 1024 ... -- reach this kernel on 1- / 2- / 3-token maps)
+  if (C <= 0 || C % 64 != 0 || C > 2048) return hipErrorInvalidValue;
+#define DF_LN4(N0) case N0: DF_LN(N0); break; case N0 + 1: DF_LN(N0 + 1); break; case N0 + 2: DF_LN(N0 + 2); break; \
+                   case N0 + 3: DF_LN(N0 + 3); break;
+  switch (C / 64) {
+    DF_LN4(1) DF_LN4(5) DF_LN4(9) DF_LN4(13) DF_LN4(17) DF_LN4(21) DF_LN4(25) DF_LN4(29)
     default: return hipErrorInvalidValue;
   }
+#undef DF_LN4
 #undef DF_LN
   return hipGetLastError();
 }

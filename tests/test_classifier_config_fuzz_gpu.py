@@ -6,6 +6,8 @@ the oracle's fp32 forward (oracle/unet.py:classifier_forward) at a random latent
 G6 pins the tiny and the full configuration; the tape builder has a branch per block kind and per channel change, which this walks.
 
 Tolerance (fp16-operand build): probability within 5e-3, gradient rel-L2 < 1.5e-2 (the full-size configuration measures 3.7e-3)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -17,10 +19,13 @@ pytestmark = pytest.mark.gpu
 N_CASES = 10
 
 
+WIDE = os.environ.get("DF_FUZZ_WIDE", "0") != "0"      # exploratory sweeps: wider maps, batches and widths than the suite draws
+
+
 def _draw(seed):
     r = np.random.default_rng(5200 + seed)
     while True:
-        mc = int(r.choice([64, 128]))
+        mc = int(r.choice([64, 128, 192, 320] if WIDE else [64, 128]))
         mult = [list(m) for m in ([1, 2], [1, 2, 2], [1, 1, 2], [1, 2, 4], [1, 1])][int(r.integers(0, 5))]
         nrb = int(r.choice([1, 2]))
         levels = len(mult)
@@ -32,6 +37,10 @@ def _draw(seed):
     cfg = dict(in_channels=4, out_channels=1, model_channels=mc, attention_resolutions=att, num_res_blocks=nrb, channel_mult=mult,
                num_heads=int(r.choice(heads)), context_dim=int(r.choice([64, 128, 512])))
     q = 2 ** (levels - 1)
+    if WIDE:
+        H = int(r.choice([h for h in (8, 16, 24, 32) if h % q == 0]))
+        W = int(r.choice([w for w in (8, 16, 24, 32, 40, 64, 96) if w % q == 0]))
+        return cfg, dict(B=int(r.choice([1, 2, 3, 4, 5, 8])), H=H, W=W, T=int(r.choice([1, 8, 31, 32, 33, 40])))
     H = int(r.choice([h for h in (8, 16) if h % q == 0]))
     W = int(r.choice([w for w in (16, 32, 64) if w % q == 0]))
     return cfg, dict(B=int(r.choice([1, 2, 3])), H=H, W=W, T=int(r.choice([8, 32, 33])))

@@ -267,8 +267,11 @@ def test_groupnorm_finishes_its_producers_split_k(N, HW, C, c_own, nslab, silu):
     assert rel_l2(out.float().cpu().permute(0, 2, 1), ref) < 4e-3
 
 
+# row lengths beyond the Stage-2 models' (320 / 640 / 1280; classifier 128 / 256 / 512): every multiple of 64 up to 2048 -- a UNet with
+# model_channels 256 x channel_mult 4 or 192 x 2 reaches the kernel with 1024- / 384-wide rows on its 2- and 3-token maps (round-6 wide
+# sweep of tests/test_unet_config_fuzz_gpu.py: "op 93 (layernorm) failed: invalid argument")
 @pytest.mark.parametrize("rows,C", [(1024, 320), (77, 640), (16, 1280), (128, 64), (8192, 320), (3, 128), (5, 256),
-                                    (7, 512), (513, 1280)])
+                                    (7, 512), (513, 1280), (2, 192), (3, 384), (6, 768), (2, 1024), (9, 960), (5, 2048), (4, 1344)])
 def test_layernorm(rows, C):
     E = _eng()
     x = rnd((rows, C), 9) * 3 - 1

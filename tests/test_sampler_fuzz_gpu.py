@@ -7,6 +7,8 @@ cond stage, on the same x_T, features and noise.  The goldens pin a handful of o
 
 Tolerance: rel-L2 of the final latent < 1e-2 on the fp16-operand build of the tiny configuration (measured 3e-5 .. 2e-3 over the 20
 cases; a wrong coefficient, table index, noise order or blend is an O(0.1 .. 1) difference)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -17,6 +19,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-2
 N_CASES = 16
+WIDE = os.environ.get("DF_FUZZ_WIDE", "0") != "0"
 
 
 @pytest.fixture(scope="module")
@@ -47,6 +50,9 @@ def _draw(seed):
     r = np.random.default_rng(7000 + seed)
     name = ["DDIM", "PLMS", "DPM_Solver", "DDPM"][seed % 4]            # every sampler gets its share whatever N_CASES is
     o = dict(name=name, B=int(r.choice([1, 2, 3])), W=int(r.choice([32, 64])), T=int(r.choice([1, 17, 32, 40])))
+    if WIDE:      # exploratory sweeps (DF_FUZZ_WIDE=1): more batches, latent widths (multiples of the UNet's 8 x downsampling) and contexts
+        o = dict(name=name, B=int(r.choice([1, 2, 3, 4, 5, 7])), W=int(r.choice([8, 16, 24, 32, 40, 64, 72, 96])),
+                 T=int(r.choice([1, 2, 17, 31, 32, 33, 40])))
     o["S"] = int(r.integers(4, 11)) if name != "DPM_Solver" else int(r.choice([2, 3, 7, 12, 16]))
     if name == "DDPM":
         o["S"] = int(r.integers(3, 7))

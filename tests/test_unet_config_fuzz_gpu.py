@@ -9,6 +9,8 @@ classifier's; this walks the builder's other branches (levels without attention,
 a single level pair, head dimensions 32 .. 160).
 
 Tolerance: rel-L2 < 5e-3 for one forward on the fp16-operand build (the tiny configuration's forward sits at 1e-3 .. 1.5e-3)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -22,10 +24,13 @@ N_CASES = 12
 HEAD_DIMS = (32, 40, 64, 80, 128, 160)          # csrc/attention.hip:attention_supported
 
 
+WIDE = os.environ.get("DF_FUZZ_WIDE", "0") != "0"      # exploratory sweeps: wider maps, batches, contexts and widths than the suite draws
+
+
 def _draw(seed):
     r = np.random.default_rng(4200 + seed)
     while True:         # channel_mult[0] = 1: the reference's `out` conv takes model_channels inputs (openai_unetmodel.py:682-686)
-        mc = int(r.choice([64, 128, 192]))
+        mc = int(r.choice([64, 128, 192, 256, 320] if WIDE else [64, 128, 192]))
         mult = [list(m) for m in ([1, 2], [1, 2, 4], [1, 1, 2], [1, 2, 2, 4], [1, 3], [1, 1], [1, 2, 4, 4])][int(r.integers(0, 7))]
         nrb = int(r.choice([1, 2, 3]))
         levels = len(mult)
@@ -33,12 +38,18 @@ def _draw(seed):
         # channels of the levels that carry attention (ds = 2^level in attention_resolutions) and of the middle block (always)
         chs = {mc * mult[i] for i in range(levels) if 2 ** i in att} | {mc * mult[-1]}
         heads = [h for h in (1, 2, 4, 8) if all(ch % h == 0 and ch // h in HEAD_DIMS for ch in chs)]
-        if mc * max(mult) <= 768 and heads:
+        if mc * max(mult) <= (1280 if WIDE else 768) and heads:
             break
     cin, cout = (4, 4) if seed % 2 == 0 else (int(r.choice([1, 3, 8, 9, 16, 64])), int(r.choice([1, 3, 8, 64])))
     cfg = dict(in_channels=cin, out_channels=cout, model_channels=mc, attention_resolutions=att, num_res_blocks=nrb, channel_mult=mult,
                num_heads=int(r.choice(heads)), context_dim=int(r.choice([64, 128, 192, 320])))
     q = 2 ** (levels - 1)
+    if WIDE:
+        H = int(r.choice([h for h in (8, 16, 24, 32, 40) if h % q == 0]))
+        W = int(r.choice([w for w in (8, 16, 24, 32, 40, 48, 64, 72, 96) if w % q == 0]))
+        if mc * max(mult) > 768 and H * W > 512:          # keep the CPU oracle in seconds
+            H, W = 8 if 8 % q == 0 else 16, 16
+        return cfg, dict(B=int(r.choice([1, 2, 3, 4, 5, 7])), H=H, W=W, T=int(r.choice([1, 2, 9, 31, 32, 33, 40])), seed=seed)
     H = int(r.choice([h for h in (8, 16) if h % q == 0]))
     W = int(r.choice([w for w in (16, 32, 64) if w % q == 0]))
     return cfg, dict(B=int(r.choice([1, 2, 3])), H=H, W=W, T=int(r.choice([1, 9, 32])), seed=seed)
@@ -76,6 +87,30 @@ def test_unet_configuration_product_vs_oracle(seed):
     print(f"case {seed}: {cfg} {o} -> rel-L2 {err:.2e}, CFG {err_cfg:.2e}")
     assert err < TOL, (cfg, o, err)
     assert err_cfg < 3 * TOL, (cfg, o, err_cfg)          # guidance amplifies the (e_c - e_u) rounding by the scale
+
+
+@pytest.mark.parametrize("mc,mult,H,W", [(256, [1, 2, 2, 4], 8, 16), (256, [1, 2, 2, 4], 8, 24), (192, [1, 2], 8, 8)])
+def test_transformer_blocks_on_two_and_three_token_maps_of_other_widths(mc, mult, H, W):
+    """Attention at the deepest level of a small latent: 1 x 2, 1 x 3 and 4 x 4 token maps with 1024- / 384-wide rows take the stand-alone
+    LayerNorm kernel, which knew the Stage-2 row lengths only (found by the DF_FUZZ_WIDE sweep of the test above, round 6)."""
+    import diff_foley_amd as P
+    from diff_foley_amd import synth
+    from oracle import unet as ou
+    att = [2 ** (len(mult) - 1)]
+    cfg = dict(in_channels=4, out_channels=4, model_channels=mc, attention_resolutions=att, num_res_blocks=1, channel_mult=mult,
+               num_heads=8 if mc == 256 else 6, context_dim=64)
+    cond = dict(origin_dim=64, embed_dim=64, seq_len=40)
+    sd = synth.make_state_dict(synth.state_dict_spec(cfg, synth.VAE_TINY, cond), 77)
+    m = P.LatentDiffusion(precision="fp16", **P.stage2_config(cfg, synth.VAE_TINY, cond))
+    m.load_state_dict(sd)
+    m.cuda()
+    g = torch.Generator().manual_seed(78)
+    x, c, t = torch.randn(2, 4, H, W, generator=g), torch.randn(2, 9, 64, generator=g), torch.tensor([900, 17])
+    ref = ou.unet_forward(ou.sub_state_dict(sd, "model.diffusion_model."), cfg, x, t, c)
+    y = m.apply_model(x.cuda(), t.cuda(), c.cuda()).cpu()
+    err = rel_l2(y, ref)
+    print(f"mc {mc} mult {mult} on {H} x {W}: rel-L2 {err:.2e}")
+    assert torch.isfinite(y).all() and err < TOL, err
 
 
 @pytest.mark.parametrize("W", [24, 32, 128])
