@@ -24,6 +24,9 @@ N_CASES = 12
 HEAD_DIMS = (32, 40, 64, 80, 128, 160)          # csrc/attention.hip:attention_supported
 
 
+PREC = os.environ.get("DF_FUZZ_PREC", "fp16")          # exploratory: the bf16-operand build (8 x the rounding unit)
+PREC_SCALE = 8.0 if PREC == "bf16" else 1.0
+TUNE = os.environ.get("DF_FUZZ_TUNE", "0") != "0"
 WIDE = os.environ.get("DF_FUZZ_WIDE", "0") != "0"      # exploratory sweeps: wider maps, batches, contexts and widths than the suite draws
 
 
@@ -63,9 +66,11 @@ def test_unet_configuration_product_vs_oracle(seed):
     cfg, o = _draw(seed)
     cond = dict(origin_dim=64, embed_dim=cfg["context_dim"], seq_len=40)
     sd = synth.make_state_dict(synth.state_dict_spec(cfg, synth.VAE_TINY, cond), 100 + seed)
-    m = P.LatentDiffusion(precision="fp16", **P.stage2_config(cfg, synth.VAE_TINY, cond))
+    m = P.LatentDiffusion(precision=PREC, **P.stage2_config(cfg, synth.VAE_TINY, cond))
     m.load_state_dict(sd)
     m.cuda()
+    if TUNE:                      # exploratory: the in-plan autotuner walks its top candidates per GEMM (tiles the cost model does not pick)
+        m.autotune(True)
     usd = ou.sub_state_dict(sd, "model.diffusion_model.")
     g = torch.Generator().manual_seed(300 + seed)
     B, H, W, T = o["B"], o["H"], o["W"], o["T"]
@@ -85,8 +90,8 @@ def test_unet_configuration_product_vs_oracle(seed):
     y_cfg = m.engine.unet_forward_cfg(x.cuda(), tt.float().cuda(), 3.0).cpu()
     err_cfg = rel_l2(y_cfg, ref_cfg)
     print(f"case {seed}: {cfg} {o} -> rel-L2 {err:.2e}, CFG {err_cfg:.2e}")
-    assert err < TOL, (cfg, o, err)
-    assert err_cfg < 3 * TOL, (cfg, o, err_cfg)          # guidance amplifies the (e_c - e_u) rounding by the scale
+    assert err < TOL * PREC_SCALE, (cfg, o, err)
+    assert err_cfg < 3 * TOL * PREC_SCALE, (cfg, o, err_cfg)          # guidance amplifies the (e_c - e_u) rounding by the scale
 
 
 @pytest.mark.parametrize("mc,mult,H,W", [(256, [1, 2, 2, 4], 8, 16), (256, [1, 2, 2, 4], 8, 24), (192, [1, 2], 8, 8)])

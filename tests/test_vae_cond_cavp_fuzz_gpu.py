@@ -20,6 +20,9 @@ from helpers import fuzz_seeds, rel_l2
 pytestmark = pytest.mark.gpu
 
 
+PREC = os.environ.get("DF_FUZZ_PREC", "fp16")          # exploratory: the bf16-operand build (8 x the rounding unit), in-plan autotuner
+PREC_SCALE = 8.0 if PREC == "bf16" else 1.0
+TUNE = os.environ.get("DF_FUZZ_TUNE", "0") != "0"
 WIDE = os.environ.get("DF_FUZZ_WIDE", "0") != "0"      # exploratory sweeps: wider spaces than the suite draws
 
 
@@ -50,9 +53,11 @@ def test_vae_decoder_configuration_product_vs_oracle(seed):
     from oracle import unet as ou, vae as ov
     cfg, o = _vae_draw(seed)
     sd = synth.make_state_dict(synth.state_dict_spec(synth.UNET_TINY, cfg, synth.COND_TINY), 700 + seed)
-    m = P.LatentDiffusion(precision="fp16", **P.stage2_config(synth.UNET_TINY, cfg, synth.COND_TINY))
+    m = P.LatentDiffusion(precision=PREC, **P.stage2_config(synth.UNET_TINY, cfg, synth.COND_TINY))
     m.load_state_dict(sd)
     m.cuda()
+    if TUNE:
+        m.autotune(True)
     vsd = ou.sub_state_dict(sd, "first_stage_model.")
     z = torch.randn(o["B"], 4, o["H"], o["W"], generator=torch.Generator().manual_seed(800 + seed))
     ref = ov.decode_first_stage(vsd, cfg, z)
@@ -61,7 +66,7 @@ def test_vae_decoder_configuration_product_vs_oracle(seed):
     assert y.shape == ref.shape == (o["B"], cfg["out_ch"], o["H"] * up, o["W"] * up) and torch.isfinite(y).all(), (cfg, o)
     err = rel_l2(y, ref)
     print(f"vae case {seed}: {cfg} {o} -> rel-L2 {err:.2e}")
-    assert err < 3e-3, (cfg, o, err)              # the full decoder measures 9.2e-4 on this build
+    assert err < 3e-3 * PREC_SCALE, (cfg, o, err)              # the full decoder measures 9.2e-4 on this build
 
 
 @pytest.mark.parametrize("seed", fuzz_seeds(6))
@@ -103,7 +108,7 @@ def test_cavp_configuration_product_vs_oracle(seed):
     cfg = dict(stage_blocks=[int(v) for v in ([1, 1, 1, 1], [2, 1, 1, 1], [1, 2, 1, 2], [1, 1, 2, 1], [2, 2, 1, 1])[int(r.integers(0, 5))]],
                base_channels=64, embed_dim=int(r.choice([64, 128, 512])))
     sd = synth.make_state_dict(synth.cavp_spec(cfg), 1000 + seed)
-    m = P.CAVPInference(embed_dim=cfg["embed_dim"], stage_blocks=cfg["stage_blocks"], precision="fp16")
+    m = P.CAVPInference(embed_dim=cfg["embed_dim"], stage_blocks=cfg["stage_blocks"], precision=PREC)
     missing, unexpected = m.load_state_dict(sd)
     assert not missing and not unexpected
     m.cuda()
@@ -120,7 +125,7 @@ def test_cavp_configuration_product_vs_oracle(seed):
         err = rel_l2(f, ref)
         cos = torch.nn.functional.cosine_similarity(f, ref, dim=-1).min().item()
         print(f"cavp case {seed}: {cfg} clips={n} frames={T} size={S} normalize={normalize} -> rel-L2 {err:.2e}, min cos {cos:.6f}")
-        assert err < 2e-3 and cos > 0.99999, (cfg, n, T, S, err, cos)
+        assert err < 2e-3 * PREC_SCALE and cos > 1 - 1e-5 * PREC_SCALE ** 2, (cfg, n, T, S, err, cos)
 
 
 @pytest.mark.parametrize("H,W", [(2, 8), (4, 8), (4, 24), (8, 20)])
