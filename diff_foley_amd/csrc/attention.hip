@@ -331,13 +331,30 @@ hipError_t launch_d(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, cons
 
 }  // namespace
 
-bool attention_supported(int D) { return D == 32 || D == 40 || D == 64 || D == 80 || D == 128 || D == 160; }
+// Head dims: 40 / 80 / 160 are the Stage-2 UNet's (320 / 640 / 1280 channels over 8 heads), 32 / 64 / 128 the classifier's and the
+// power-of-two configurations'; 16 / 24 / 48 / 56 / 72 / 96 / 112 / 192 cover the other model_channels x channel_mult / num_heads
+// quotients a UNetModel constructor admits (192 channels over 2 / 4 / 8 heads, 384 over 4 / 8, 448 over 8, 576 over 8 ...).
+bool attention_supported(int D) {
+  switch (D) {
+    case 16: case 24: case 32: case 40: case 48: case 56: case 64: case 72: case 80: case 96: case 112: case 128: case 160: case 192:
+      return true;
+    default: return false;
+  }
+}
 
 hipError_t launch_attention(const uint16_t* Q, int ldq, const uint16_t* K, int ldk, const uint16_t* Vt, int ldvt,
                             uint16_t* O, int ldo, int N, int heads, int D, int Tq, int Tk, float scale,
                             hipStream_t s) {
   if (ldvt % 32 != 0 || ldvt < ((Tk + 31) / 32) * 32) return hipErrorInvalidValue;
   switch (D) {
+    case 16:  return launch_d<16>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    case 24:  return launch_d<24>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    case 48:  return launch_d<48>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    case 56:  return launch_d<56>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    case 72:  return launch_d<72>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    case 96:  return launch_d<96>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    case 112: return launch_d<112>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
+    case 192: return launch_d<192>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
     case 32:  return launch_d<32>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
     case 40:  return launch_d<40>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);
     case 64:  return launch_d<64>(Q, ldq, K, ldk, Vt, ldvt, O, ldo, N, heads, Tq, Tk, scale, s);

@@ -287,7 +287,11 @@ def test_layernorm(rows, C):
 
 @pytest.mark.parametrize("N,heads,D,Tq,Tk", [(2, 8, 40, 1024, 1024), (2, 8, 80, 256, 256), (1, 8, 160, 64, 64),
                                              (2, 8, 160, 16, 16), (2, 8, 40, 1024, 32), (2, 8, 32, 128, 33),
-                                             (1, 2, 64, 256, 256), (1, 2, 128, 64, 32), (1, 8, 80, 256, 32)])
+                                             (1, 2, 64, 256, 256), (1, 2, 128, 64, 32), (1, 8, 80, 256, 32),
+                                             # head dims of other model_channels / num_heads quotients (round 6, closing session)
+                                             (2, 4, 48, 256, 256), (1, 8, 24, 128, 128), (2, 2, 96, 64, 64), (1, 12, 16, 1024, 1024),
+                                             (2, 8, 56, 256, 32), (1, 8, 72, 64, 33), (2, 4, 112, 16, 16), (1, 2, 192, 256, 256),
+                                             (1, 4, 96, 1024, 1024), (2, 2, 192, 16, 9), (1, 4, 48, 2, 2), (1, 8, 24, 3, 3)])
 def test_attention(N, heads, D, Tq, Tk):
     E = _eng()
     C_ = heads * D
