@@ -141,7 +141,7 @@ __global__ void l2norm_rows_kernel(float* __restrict__ x, int rows, int C) {
 // ------------------------------------------------------------------ frame pre-processing (demo_util.py:100-104, 150-151)
 // torchvision Resize((h, w)) on a PIL image = PIL.Image.resize(BILINEAR): separable, antialiased (triangle filter whose
 // support grows with the down-scaling factor), 8-bit fixed point exactly as Pillow's Resample.c: horizontal pass into a
-// uint8 intermediate, then the vertical pass (the other way round on frames with H > 100 W, below); every value is (2^21 + sum pixel * coeff) >> 22, clipped to 0..255.  The
+// uint8 intermediate, then the vertical pass (the other way round on shrinking frames with H > 100 W, below); every value is (2^21 + sum pixel * coeff) >> 22, clipped to 0..255.  The
 // 22-bit coefficient tables are computed on the host in double precision (diff_foley_amd/video.py).  The vertical pass
 // also does ToTensor(): HWC uint8 -> CHW float / 255.  Results are bit-identical to Pillow.
 __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ tmp, long rows,
@@ -182,10 +182,11 @@ __global__ __launch_bounds__(256) void resize_v_totensor_kernel(const uint8_t* _
   }
 }
 
-// Pass order.  Pillow runs the horizontal pass first -- except on frames more than 100 times taller than wide (H > 100 W), where it
-// runs the vertical pass first (observed on Pillow 12.2.0: the switch sits at exactly H = 100 W + 1 for every output size, 497 random
-// geometries in tests/test_video_cpu.py).  The uint8 rounding of the intermediate makes the two orders differ by one count in up to
-// 10 % of the values, so the order is part of the result.  No real video has that shape; the kernels below exist for bit parity.
+// Pass order.  Pillow runs the horizontal pass first -- except on frames more than 100 times taller than wide (H > 100 W) whose height
+// shrinks (OH < H), where it runs the vertical pass first (observed on Pillow 12.2.0: the switch sits at exactly H = 100 W + 1 and at
+// OH = H - 1 whatever the output width; ~1000 random geometries against PIL, tests/test_video_cpu.py walks both boundaries).  The uint8
+// rounding of the intermediate makes the two orders differ by one count in up to 10 % of the values, so the order is part of the result.
+// No real video has that shape; the kernels below exist for bit parity.
 __global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ tmp, int T, int H, int W,
                                                        int OH, const int* __restrict__ bounds, const int* __restrict__ coef,
                                                        int ksize) {
@@ -287,7 +288,7 @@ hipError_t launch_frames_to_tensor(const uint8_t* frames, float* out, uint8_t* t
                                    const int* bounds_w, const int* coef_w, int ksize_w, const int* bounds_h,
                                    const int* coef_h, int ksize_h, hipStream_t s) {
   if (T <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || ksize_w <= 0 || ksize_h <= 0) return hipErrorInvalidValue;
-  const bool v_first = (long)H > 100L * W;          // Pillow's pass order (see resize_v_kernel)
+  const bool v_first = (long)H > 100L * W && OH < H;          // Pillow's pass order (see resize_v_kernel)
   const long n1 = v_first ? (long)T * OH * W * 3 : (long)T * H * OW * 3, n2 = (long)T * 3 * OH * OW;
   const int g1 = (int)std::min<long>((n1 + 255) / 256, 65535), g2 = (int)std::min<long>((n2 + 255) / 256, 65535);
   if (v_first) {

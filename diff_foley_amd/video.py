@@ -76,9 +76,9 @@ def frames_to_tensor(frames, size=(224, 224)):
         _tables[key] = _Tables(H, W, oh, ow, dev)
     tb = _tables[key]
     out = torch.empty(T, 3, oh, ow, dtype=torch.float32, device=dev)
-    # first pass's result: horizontal pass first, [T][H][ow][3] -- except H > 100 W, where Pillow (and the library) run the vertical
-    # pass first: [T][oh][W][3]
-    tmp = torch.empty(T * (oh * W if H > 100 * W else H * ow) * 3, dtype=torch.uint8, device=dev)
+    # first pass's result: horizontal pass first, [T][H][ow][3] -- except on shrinking frames with H > 100 W, where Pillow (and the
+    # library) run the vertical pass first: [T][oh][W][3]
+    tmp = torch.empty(T * (oh * W if (H > 100 * W and oh < H) else H * ow) * 3, dtype=torch.uint8, device=dev)
     L = E.lib()
     p = lambda t: C.c_void_p(t.data_ptr())
     E._chk(L.df_frames_to_tensor(p(frames), p(out), p(tmp), T, H, W, oh, ow, p(tb.bw), p(tb.kw), tb.ksw, p(tb.bh), p(tb.kh),

@@ -161,11 +161,11 @@ int df_classifier_grad_cached(df_ctx* ctx, const float* x_dev, const float* t_de
 
 /* ---- video frame pre-processing in front of the CAVP encoder (Extract_CAVP_Features.forward, inference/demo_util.py:
  * 100-104, 150-151): per frame torchvision Resize((OH, OW)) on a PIL image (= PIL.Image.resize BILINEAR: antialiased,
- * 8-bit fixed point, horizontal pass then vertical pass -- vertical pass first on frames with H > 100 W, as Pillow does)
+ * 8-bit fixed point, horizontal pass then vertical pass -- vertical pass first on frames with H > 100 W and OH < H, as Pillow does)
  * + ToTensor().  frames uint8 [T][H][W][3] RGB ->
  * out fp32 [T][3][OH][OW] in [0, 1], bit-identical to Pillow.  bounds_* int32 [out][2] = (first input index, taps),
  * coef_* int32 [out][ksize] 22-bit fixed-point filter weights (computed in double precision on the host:
- * diff_foley_amd/video.py); tmp uint8 scratch for the first pass's result: [T][H][OW][3], or [T][OH][W][3] when H > 100 W.
+ * diff_foley_amd/video.py); tmp uint8 scratch for the first pass's result: [T][H][OW][3], or [T][OH][W][3] when H > 100 W and OH < H.
  * All pointers device memory. */
 int df_frames_to_tensor(const uint8_t* frames_dev, float* out_dev, uint8_t* tmp_dev, int T, int H, int W, int OH, int OW,
                         const int32_t* bounds_w_dev, const int32_t* coef_w_dev, int ksize_w, const int32_t* bounds_h_dev,

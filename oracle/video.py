@@ -7,7 +7,7 @@ through ``transforms.Compose([Resize((224, 224)), ToTensor()])`` (demo_util.py:1
 The resize itself lives in a third-party dependency, Pillow (the reference pins no version; torchvision calls
 ``PIL.Image.resize``).  Its published algorithm (src/libImaging/Resample.c, 8 bits per channel path) is restated here:
 separable convolution with a triangle filter whose support scales with the down-scaling factor (antialiasing),
-horizontal pass first into a uint8 intermediate, then the vertical pass (vertical first on frames with H > 100 W); coefficients are normalised in double precision
+horizontal pass first into a uint8 intermediate, then the vertical pass (vertical first on shrinking frames with H > 100 W); coefficients are normalised in double precision
 and rounded to 22-bit fixed point; every output value is (2^21 + sum pixel * coeff) >> 22 clipped to 0..255.
 Pinned: bit-exact against Pillow 12.2.0 itself in this container (tests/test_oracle_golden.py) and through the golden
 fixture tests/golden/g9_video_frames.npz (made by tests/golden/make_golden.py --video from PIL's output)."""
@@ -69,10 +69,11 @@ def resize_bilinear_u8(frame, out_h, out_w):
     H, W = frame.shape[:2]
     bw, kw = resample_coeffs(W, out_w)
     bh, kh = resample_coeffs(H, out_h)
-    if H > 100 * W:
-        # frames more than 100 times taller than wide: Pillow runs the VERTICAL pass first.  Observed, not read: Pillow 12.2.0 in
-        # this container switches at exactly H = 100 W + 1 whatever the output size (tests/test_video_cpu.py walks the boundary and
-        # random geometries against PIL); the uint8 intermediate makes the orders differ by one count in up to 10 % of the values.
+    if H > 100 * W and out_h < H:
+        # frames more than 100 times taller than wide whose height shrinks: Pillow runs the VERTICAL pass first.  Observed, not read:
+        # Pillow 12.2.0 in this container switches at exactly H = 100 W + 1 and at out_h = H - 1, whatever the output width
+        # (tests/test_video_cpu.py walks both boundaries and random geometries against PIL); the uint8 intermediate makes the orders
+        # differ by one count in up to 10 % of the values.
         tmp = _pass(frame, bh, kh, 0) if H != out_h else frame
         return _pass(tmp, bw, kw, 1) if W != out_w else tmp
     tmp = _pass(frame, bw, kw, 1) if W != out_w else frame          # horizontal first (ImagingResampleInner)

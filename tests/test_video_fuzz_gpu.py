@@ -45,7 +45,8 @@ def test_frames_to_tensor_equals_oracle_and_pillow(seed):
 
 
 @pytest.mark.parametrize("H,W,oh,ow", [(224, 2, 64, 111), (1080, 7, 5, 256), (641, 2, 64, 64), (200, 2, 64, 16), (201, 2, 64, 16),
-                                        (501, 5, 5, 16), (500, 5, 5, 16), (1081, 1, 9, 9), (301, 3, 301, 8), (301, 3, 17, 3)])
+                                        (501, 5, 5, 16), (500, 5, 5, 16), (1081, 1, 9, 9), (301, 3, 301, 8), (301, 3, 17, 3),
+                                        (224, 2, 256, 5), (224, 2, 223, 5), (224, 2, 225, 5), (801, 2, 1600, 3), (501, 5, 500, 8)])
 def test_tall_frames_take_pillows_pass_order(H, W, oh, ow):
     """Frames more than 100 times taller than wide: Pillow runs the vertical pass first and the product follows (resize_v_kernel /
     resize_h_totensor_kernel; the rule and how it was found: tests/test_video_cpu.py).  Both sides of the boundary, one-pass cases."""
