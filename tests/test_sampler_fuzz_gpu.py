@@ -144,7 +144,7 @@ def test_sampler_options_product_vs_oracle(tiny16, oracle_tiny, seed):
     assert err < TOL, (o, err)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", fuzz_seeds(6))
 def test_double_guidance_options_product_vs_oracle(tiny16, oracle_tiny, seed):
     """The classifier-guided samplers (ddim.py:276-396, dpm_solver/sampler.py:90-156 -> dpm_solver.py:1377-1393) over their options:
     sampler, steps, batch, latent width, CFG scale, classifier scale (0 = the gradient is formed and multiplied away), video frames
@@ -160,6 +160,8 @@ def test_double_guidance_options_product_vs_oracle(tiny16, oracle_tiny, seed):
     S = int(r.choice([4, 6, 8])) if name == "DDIM" else int(r.choice([3, 6, 16]))
     scale, cscale = float(r.choice([2.5, 4.5])), float(r.choice([0.0, 10.0, 50.0]))
     F = int(r.choice([8, 32, 33]))
+    if WIDE:
+        B, W, F = int(r.choice([1, 2, 3, 4, 5])), int(r.choice([8, 16, 24, 32, 40, 64, 96])), int(r.choice([1, 8, 31, 32, 33, 40]))
     eta = float(r.choice([0.0, 1.0])) if name == "DDIM" else 0.0
     cls = P.AlignmentClassifier(classifier_config=dict(params=dict(synth.CLS_TINY)))
     cls.load_state_dict(tiny_classifier_sd())
